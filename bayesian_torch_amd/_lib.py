@@ -1,0 +1,87 @@
+"""ctypes binding of libbtx.so (include/btx.h).  The HIP library is THE product path: there is no fallback —
+`lib()` raises if it is missing, and every non-zero return code raises `BtxError`."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KIND_REPARAM, KIND_FLIPOUT = 0, 1
+ACT_F32, ACT_BF16 = 0, 1
+PREC_F32, PREC_BF16 = 0, 1
+FLAG_TRANSPOSED, FLAG_KL_ACCUM = 1, 2
+STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
+ABI_VERSION = 1
+
+
+class BtxError(RuntimeError):
+    pass
+
+
+class Geom(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "NB", "D", "H", "W", "C", "N", "KD", "KH", "KW", "sd", "sh", "sw", "pd", "ph", "pw",
+        "dd", "dh", "dw", "od", "oh", "ow", "groups")]
+
+
+class Rng(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("sample_idx", ctypes.c_uint32), ("layer_id", ctypes.c_uint32)]
+
+
+class Noise(ctypes.Structure):
+    _fields_ = [("eps_w", ctypes.c_void_p), ("eps_b", ctypes.c_void_p),
+                ("sign_in", ctypes.c_void_p), ("sign_out", ctypes.c_void_p)]
+
+
+EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss",
+           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
+           "btx_mc_packed_floats", "btx_mc_accumulate")
+
+
+def lib_path():
+    return os.path.join(_HERE, "libbtx.so")
+
+
+def lib():
+    """Load libbtx.so once.  Raises BtxError (loudly) when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise BtxError("libbtx.so not found at %s — build it with `python __graft_entry__.py build` "
+                       "(hipcc --offload-arch=gfx950); there is no fallback path." % path)
+    L = ctypes.CDLL(path)
+    vp, sz, u32, i32, f32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int, ctypes.c_float
+    L.btx_abi_version.restype = i32
+    L.btx_abi_version.argtypes = []
+    L.btx_strerror.restype = ctypes.c_char_p
+    L.btx_strerror.argtypes = [i32]
+    L.btx_kl_workspace_bytes.restype = sz
+    L.btx_kl_workspace_bytes.argtypes = [sz]
+    L.btx_kl_gauss.restype = i32
+    L.btx_kl_gauss.argtypes = [vp, vp, sz, vp, vp, f32, f32, vp, u32, vp, sz, vp]
+    L.btx_contract_workspace_bytes.restype = sz
+    L.btx_contract_workspace_bytes.argtypes = [ctypes.POINTER(Geom), i32, i32, i32, u32]
+    L.btx_contract_fwd.restype = i32
+    L.btx_contract_fwd.argtypes = [i32, ctypes.POINTER(Geom), vp, vp, vp, vp, vp, vp, ctypes.POINTER(Rng),
+                                   ctypes.POINTER(Noise), i32, i32, u32, vp, sz, vp]
+    L.btx_out_shape.restype = i32
+    L.btx_out_shape.argtypes = [ctypes.POINTER(Geom), u32] + [ctypes.POINTER(ctypes.c_int32)] * 3
+    L.btx_fill_eps.restype = i32
+    L.btx_fill_eps.argtypes = [vp, sz, ctypes.POINTER(Rng), u32, vp]
+    L.btx_fill_sign.restype = i32
+    L.btx_fill_sign.argtypes = [vp, sz, ctypes.POINTER(Rng), u32, vp]
+    L.btx_mc_packed_floats.restype = sz
+    L.btx_mc_packed_floats.argtypes = [i32, i32]
+    L.btx_mc_accumulate.restype = i32
+    L.btx_mc_accumulate.argtypes = [vp, i32, i32, i32, f32, vp, vp]
+    if L.btx_abi_version() != ABI_VERSION:
+        raise BtxError("libbtx.so ABI %d != expected %d" % (L.btx_abi_version(), ABI_VERSION))
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise BtxError("libbtx: %s (code %d)" % (lib().btx_strerror(rc).decode(), rc))

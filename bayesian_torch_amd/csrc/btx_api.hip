@@ -1,0 +1,368 @@
+// btx_api.hip — the C-ABI of libbtx.so (include/btx.h) + the small HBM-bound kernels
+// (KL reduce, noise materialisation, MC predictive accumulation).  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include "../../include/btx.h"
+#include "btx_contract.h"
+#include "btx_rng.h"
+
+using namespace btx;
+
+// ========================================================================================================
+// K1: KL(q||p) mean.  Reference: layers/base_variational_layer.py:65-68 (kl_div), sigma = log1p(exp(rho))
+// from e.g. layers/flipout_layers/conv_flipout.py:362-368.  Each term is evaluated in f32 exactly as the
+// reference spells it; the sum is carried in f64 and reduced in a fixed order (deterministic, no atomics).
+// HBM-bound: 8 B/element read once.
+// ========================================================================================================
+constexpr int KL_BLOCK = 256;
+constexpr int KL_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ float kl_term(float mu, float rho, float pmu, float psig) {
+  const float sig = log1pf(expf(rho));
+  const float dm = mu - pmu;
+  return logf(psig) - logf(sig) + (sig * sig + dm * dm) / (2.0f * (psig * psig)) - 0.5f;
+}
+
+__global__ __launch_bounds__(KL_BLOCK) void kl_partial_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
+                                                              size_t n, const float* __restrict__ pmu_t,
+                                                              const float* __restrict__ psig_t, float pmu, float psig,
+                                                              double* __restrict__ partials) {
+  double acc = 0.0;
+  const size_t nthreads = (size_t)gridDim.x * KL_BLOCK;
+  const size_t t = (size_t)blockIdx.x * KL_BLOCK + threadIdx.x;
+  const size_t n4 = n >> 2;
+  const bool vec_ok = ((((uintptr_t)mu | (uintptr_t)rho) & 15) == 0) && !pmu_t && !psig_t;
+  if (vec_ok) {
+    for (size_t i = t; i < n4; i += nthreads) {
+      const f32x4 m = ((const f32x4*)mu)[i];
+      const f32x4 r = ((const f32x4*)rho)[i];
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += kl_term(m[e], r[e], pmu, psig);
+      acc += (double)s;
+    }
+    for (size_t i = (n4 << 2) + t; i < n; i += nthreads) acc += (double)kl_term(mu[i], rho[i], pmu, psig);
+  } else {
+    for (size_t i = t; i < n; i += nthreads)
+      acc += (double)kl_term(mu[i], rho[i], pmu_t ? pmu_t[i] : pmu, psig_t ? psig_t[i] : psig);
+  }
+  // wave64 shuffle reduce -> LDS -> one value per block
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double wsum[KL_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < KL_BLOCK / 64; ++w) s += wsum[w];
+    partials[blockIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(64) void kl_final_kernel(const double* __restrict__ partials, int nblocks, double inv_n,
+                                                      float* __restrict__ out, int accumulate) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) acc += partials[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) {
+    const float kl = (float)(acc * inv_n);
+    out[0] = accumulate ? out[0] + kl : kl;
+  }
+}
+
+// ========================================================================================================
+// noise materialisation (BTX-RNG v1)
+// ========================================================================================================
+__global__ __launch_bounds__(256) void fill_eps_kernel(float* __restrict__ out, size_t n, uint32_t k0, uint32_t k1,
+                                                       uint32_t sample, uint32_t layer, uint32_t stream) {
+  const size_t nblk = (n + 3) >> 2;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nblk; b += (size_t)gridDim.x * 256) {
+    float z[4];
+    btx_normal4((uint32_t)b, sample, layer, stream, k0, k1, z);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((b << 2) + e < n) out[(b << 2) + e] = z[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_sign_kernel(int8_t* __restrict__ out, size_t n, uint32_t ka, uint32_t kb) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint32_t w = btx_sign_word((uint32_t)(i >> 5), ka, kb);
+    out[i] = ((w >> btx_sign_bitpos((uint32_t)i & 31u)) & 1u) ? (int8_t)-1 : (int8_t)1;
+  }
+}
+
+// ========================================================================================================
+// K6: MC predictive accumulation.  Reference (host side, numpy/torch): torch.stack(output_mc) -> softmax(dim=2)
+// -> mean(dim=0)  examples/main_bayesian_imagenet_dnn2bnn.py:483-499 ; predictive_entropy / mutual_information
+// utils/util.py:41-60.  One workgroup per batch row; the row is owned by that workgroup so no atomics.
+// ========================================================================================================
+template <typename ACT>
+__global__ __launch_bounds__(256) void mc_accumulate_kernel(const ACT* __restrict__ logits, int bs, int C, float kl,
+                                                            float* __restrict__ packed) {
+  const int row = blockIdx.x;
+  const ACT* lr = logits + (size_t)row * C;
+  __shared__ float red[4];
+  __shared__ float bc;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, (float)lr[c]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  mx = bc;
+  float se = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) se += expf((float)lr[c] - mx);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) se += __shfl_down(se, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  const float inv = 1.0f / bc;
+  float ent = 0.f;
+  float* sp = packed + (size_t)row * C;
+  float* sp2 = packed + (size_t)bs * C + (size_t)row * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float pr = expf((float)lr[c] - mx) * inv;
+    sp[c] += pr;
+    sp2[c] += pr * pr;
+    ent -= pr * logf(pr + 1e-15f);  // utils/util.py:44 epsilon
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ent += __shfl_down(ent, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ent;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    packed[(size_t)2 * bs * C + row] += red[0] + red[1] + red[2] + red[3];
+    if (row == 0) {
+      packed[(size_t)2 * bs * C + bs] += kl;
+      packed[(size_t)2 * bs * C + bs + 1] += 1.0f;
+    }
+  }
+}
+
+// ========================================================================================================
+// host side
+// ========================================================================================================
+static void sign_keys(const BtxRng* rng, uint32_t stream, uint32_t* ka, uint32_t* kb) {
+  const BtxPhilox4 k = btx_philox4x32_10(0u, rng->sample_idx, rng->layer_id, stream, (uint32_t)rng->seed,
+                                         (uint32_t)(rng->seed >> 32));
+  *ka = k.x[0];
+  *kb = k.x[1];
+}
+
+extern "C" {
+
+int btx_abi_version(void) { return BTX_ABI_VERSION; }
+
+const char* btx_strerror(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case BTX_E_NULL: return "btx: required pointer is NULL";
+    case BTX_E_SHAPE: return "btx: inconsistent or non-positive shape";
+    case BTX_E_UNSUPPORTED: return "btx: unsupported configuration";
+    case BTX_E_WORKSPACE: return "btx: workspace too small";
+    case BTX_E_DTYPE: return "btx: unknown dtype / precision code";
+    case BTX_E_ALIGN: return "btx: pointer not 16-byte aligned";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "btx: unknown error";
+  }
+}
+
+size_t btx_kl_workspace_bytes(size_t n) {
+  (void)n;
+  return (size_t)KL_MAX_BLOCKS * sizeof(double);
+}
+
+int btx_kl_gauss(const float* mu, const float* rho, size_t n, const float* prior_mu_t, const float* prior_sigma_t,
+                 float prior_mu, float prior_sigma, float* kl_out, uint32_t flags, void* ws, size_t ws_bytes,
+                 void* stream) {
+  if (!mu || !rho || !kl_out || !ws) return BTX_E_NULL;
+  if (n == 0) return BTX_E_SHAPE;
+  if (ws_bytes < btx_kl_workspace_bytes(n)) return BTX_E_WORKSPACE;
+  if (((uintptr_t)ws & 7) != 0) return BTX_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  size_t want = (n + (size_t)KL_BLOCK * 8 - 1) / ((size_t)KL_BLOCK * 8);
+  int nblocks = (int)(want < 1 ? 1 : (want > KL_MAX_BLOCKS ? KL_MAX_BLOCKS : want));
+  hipLaunchKernelGGL(kl_partial_kernel, dim3(nblocks), dim3(KL_BLOCK), 0, st, mu, rho, n, prior_mu_t, prior_sigma_t,
+                     prior_mu, prior_sigma, (double*)ws);
+  hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblocks, 1.0 / (double)n, kl_out,
+                     (flags & BTX_FLAG_KL_ACCUM) ? 1 : 0);
+  return (int)hipGetLastError();
+}
+
+int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, int32_t* Wo) {
+  if (!g || !Do || !Ho || !Wo) return BTX_E_NULL;
+  if (g->NB <= 0 || g->D <= 0 || g->H <= 0 || g->W <= 0 || g->C <= 0 || g->N <= 0 || g->KD <= 0 || g->KH <= 0 ||
+      g->KW <= 0 || g->sd <= 0 || g->sh <= 0 || g->sw <= 0 || g->dd <= 0 || g->dh <= 0 || g->dw <= 0 ||
+      g->pd < 0 || g->ph < 0 || g->pw < 0 || g->groups <= 0)
+    return BTX_E_SHAPE;
+  if (g->C % g->groups || g->N % g->groups) return BTX_E_SHAPE;
+  if (flags & BTX_FLAG_TRANSPOSED) {
+    *Do = (g->D - 1) * g->sd - 2 * g->pd + g->dd * (g->KD - 1) + g->od + 1;
+    *Ho = (g->H - 1) * g->sh - 2 * g->ph + g->dh * (g->KH - 1) + g->oh + 1;
+    *Wo = (g->W - 1) * g->sw - 2 * g->pw + g->dw * (g->KW - 1) + g->ow + 1;
+  } else {
+    *Do = (g->D + 2 * g->pd - g->dd * (g->KD - 1) - 1) / g->sd + 1;
+    *Ho = (g->H + 2 * g->ph - g->dh * (g->KH - 1) - 1) / g->sh + 1;
+    *Wo = (g->W + 2 * g->pw - g->dw * (g->KW - 1) - 1) / g->sw + 1;
+  }
+  if (*Do <= 0 || *Ho <= 0 || *Wo <= 0) return BTX_E_SHAPE;
+  return 0;
+}
+
+// tiling plan shared by btx_contract_workspace_bytes and btx_contract_fwd
+struct Plan {
+  int Do, Ho, Wo, Cg, Ng, M, K, mtiles, ntiles, ksplits, kper, nwg;
+};
+
+static int make_plan(const BtxGeom* g, int prec, uint32_t flags, Plan* pl) {
+  int rc = btx_out_shape(g, flags, &pl->Do, &pl->Ho, &pl->Wo);
+  if (rc) return rc;
+  if (prec != BTX_PREC_F32 && prec != BTX_PREC_BF16) return BTX_E_DTYPE;
+  pl->Cg = g->C / g->groups;
+  pl->Ng = g->N / g->groups;
+  const long long M = (long long)g->NB * pl->Do * pl->Ho * pl->Wo;
+  const long long K = (long long)g->KD * g->KH * g->KW * pl->Cg;
+  if (M > 0x7fffffffLL || K > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
+  pl->M = (int)M;
+  pl->K = (int)K;
+  const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
+  pl->mtiles = (pl->M + BM - 1) / BM;
+  pl->ntiles = (pl->Ng + BN - 1) / BN;
+  const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
+  const int stages = (pl->K + bk - 1) / bk;
+  int ks = 1;
+  if (base < 192) {
+    ks = (int)((256 + base - 1) / base);
+    const int max_ks = stages / 4 > 1 ? stages / 4 : 1;  // keep >= 4 stages per split
+    if (ks > max_ks) ks = max_ks;
+    if (ks > 32) ks = 32;
+  }
+  int per_stages = (stages + ks - 1) / ks;
+  pl->kper = per_stages * bk;
+  pl->ksplits = (pl->K + pl->kper - 1) / pl->kper;
+  const long long nwg = base * pl->ksplits;
+  if (nwg > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
+  pl->nwg = (int)nwg;
+  return 0;
+}
+
+size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, int prec, uint32_t flags) {
+  (void)kind; (void)act_dtype;
+  Plan pl;
+  if (!g || make_plan(g, prec, flags, &pl)) return 0;
+  return pl.ksplits > 1 ? (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
+}
+
+int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
+                     const float* mu_b, const float* rho_b, void* out, const BtxRng* rng, const BtxNoise* noise,
+                     int act_dtype, int prec, uint32_t flags, void* ws, size_t ws_bytes, void* stream) {
+  if (!g || !x || !mu_w || !rho_w || !out || !rng) return BTX_E_NULL;
+  if ((mu_b == nullptr) != (rho_b == nullptr)) return BTX_E_NULL;
+  if (kind != BTX_KIND_REPARAM && kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
+  if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
+  Plan pl;
+  int rc = make_plan(g, prec, flags, &pl);
+  if (rc) return rc;
+  const size_t need = pl.ksplits > 1 ? (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
+  if (need && (!ws || ws_bytes < need)) return BTX_E_WORKSPACE;
+  if (need && (((uintptr_t)ws) & 15)) return BTX_E_ALIGN;
+
+  ContractParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.mu = mu_w; p.rho = rho_w; p.mu_b = mu_b; p.rho_b = rho_b; p.out = out;
+  p.partial = need ? (float*)ws : nullptr;
+  if (noise) {
+    p.eps_w = noise->eps_w; p.eps_b = noise->eps_b;
+    p.sign_in = noise->sign_in; p.sign_out = noise->sign_out;
+  }
+  p.NB = g->NB; p.D = g->D; p.H = g->H; p.W = g->W; p.C = g->C; p.Cg = pl.Cg;
+  p.Do = pl.Do; p.Ho = pl.Ho; p.Wo = pl.Wo; p.N = g->N; p.Ng = pl.Ng;
+  p.KD = g->KD; p.KH = g->KH; p.KW = g->KW;
+  p.sd = g->sd; p.sh = g->sh; p.sw = g->sw; p.pd = g->pd; p.ph = g->ph; p.pw = g->pw;
+  p.dd = g->dd; p.dh = g->dh; p.dw = g->dw;
+  p.M = pl.M; p.K = pl.K;
+  p.mtiles = pl.mtiles; p.ntiles = pl.ntiles; p.groups = g->groups; p.ksplits = pl.ksplits; p.kper = pl.kper;
+  p.transposed = (flags & BTX_FLAG_TRANSPOSED) ? 1 : 0;
+  p.seed_lo = (uint32_t)rng->seed; p.seed_hi = (uint32_t)(rng->seed >> 32);
+  p.sample = rng->sample_idx; p.layer = rng->layer_id;
+  sign_keys(rng, BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
+  sign_keys(rng, BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
+
+  // fast (granule) path needs whole 16-byte granules everywhere; otherwise the element-wise gather path
+  const int G = (prec == BTX_PREC_BF16) ? 8 : 4;
+  const uintptr_t al = (uintptr_t)x | (uintptr_t)mu_w | (uintptr_t)rho_w | (uintptr_t)out |
+                       (uintptr_t)(noise && noise->eps_w ? noise->eps_w : nullptr) |
+                       (uintptr_t)(noise && noise->sign_in ? noise->sign_in : nullptr);
+  const bool explicit_kloop = noise && (noise->eps_w || noise->sign_in);  // parity mode runs the gather kernel
+  const bool gen = (pl.Cg % G != 0) || (al & 15) || explicit_kloop;
+
+  hipStream_t st = (hipStream_t)stream;
+  rc = (prec == BTX_PREC_BF16) ? launch_contract_bf16(kind, act_dtype == BTX_ACT_BF16, gen, p, pl.nwg, st)
+                               : launch_contract_f32(kind, act_dtype == BTX_ACT_BF16, gen, p, pl.nwg, st);
+  if (rc) return rc;
+  if (pl.ksplits > 1) {
+    const long long total = (long long)pl.M * g->N;
+    long long blocks = (total / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (act_dtype == BTX_ACT_BF16)
+      hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, (const float*)ws,
+                         (__bf16*)out, total, pl.ksplits);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)ws,
+                         (float*)out, total, pl.ksplits);
+    rc = (int)hipGetLastError();
+  }
+  return rc;
+}
+
+int btx_fill_eps(float* out, size_t n, const BtxRng* rng, uint32_t rng_stream, void* stream) {
+  if (!out || !rng) return BTX_E_NULL;
+  if (n == 0) return 0;
+  size_t blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_eps_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, n,
+                     (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx, rng->layer_id, rng_stream);
+  return (int)hipGetLastError();
+}
+
+int btx_fill_sign(int8_t* out, size_t n, const BtxRng* rng, uint32_t rng_stream, void* stream) {
+  if (!out || !rng) return BTX_E_NULL;
+  if (n == 0) return 0;
+  uint32_t ka, kb;
+  sign_keys(rng, rng_stream, &ka, &kb);
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fill_sign_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, n, ka, kb);
+  return (int)hipGetLastError();
+}
+
+size_t btx_mc_packed_floats(int bs, int C) {
+  if (bs <= 0 || C <= 0) return 0;
+  return (size_t)2 * bs * C + (size_t)bs + 2;
+}
+
+int btx_mc_accumulate(const void* logits, int bs, int C, int act_dtype, float kl, float* packed, void* stream) {
+  if (!logits || !packed) return BTX_E_NULL;
+  if (bs <= 0 || C <= 0) return BTX_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (act_dtype == BTX_ACT_F32)
+    hipLaunchKernelGGL(mc_accumulate_kernel<float>, dim3(bs), dim3(256), 0, st, (const float*)logits, bs, C, kl, packed);
+  else if (act_dtype == BTX_ACT_BF16)
+    hipLaunchKernelGGL(mc_accumulate_kernel<__bf16>, dim3(bs), dim3(256), 0, st, (const __bf16*)logits, bs, C, kl,
+                       packed);
+  else
+    return BTX_E_DTYPE;
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

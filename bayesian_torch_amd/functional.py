@@ -1,0 +1,290 @@
+"""Host-side plumbing between torch tensors and the C-ABI (include/btx.h).
+
+torch is used here for device memory, streams and layout views only; all arithmetic of the hot path on a GPU
+tensor happens inside libbtx.so.  CPU tensors take the ATen route (`*_aten` below: the reference's own op chain —
+BASELINE.json config 0, "plumbing, no GPU"); a CUDA tensor NEVER does: if the library is missing or a case is
+unsupported the call raises.
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from . import rng as _rng
+
+_PRECISION = os.environ.get("BTX_PRECISION", "f32")  # "f32" (parity mode) | "bf16" (throughput mode)
+
+
+def set_precision(prec):
+    """Contraction precision of the HIP path: "f32" = v_mfma_f32_32x32x2_f32 (exact f32 fma chain, parity to
+    ~1e-6 rel), "bf16" = v_mfma_f32_32x32x16_bf16 with f32 accumulation (rel-L2 ~3e-3, stated in DESIGN.md)."""
+    global _PRECISION
+    if prec not in ("f32", "bf16"):
+        raise ValueError("precision must be 'f32' or 'bf16'")
+    _PRECISION = prec
+
+
+def get_precision():
+    return _PRECISION
+
+
+def _triple(v, nd, fill):
+    """int or nd-tuple -> 3-tuple in (D, H, W) order, padded in front with `fill`."""
+    if isinstance(v, int):
+        v = (v,) * max(nd, 1)
+    v = tuple(int(a) for a in v)
+    if len(v) != max(nd, 1) and nd > 0:
+        raise ValueError("expected %d values, got %r" % (nd, v))
+    if nd == 0:
+        return (fill, fill, fill)
+    return (fill,) * (3 - nd) + v
+
+
+class OpDesc:
+    """Geometry of one variational contraction (Linear: nd=0)."""
+
+    __slots__ = ("nd", "transposed", "kernel", "stride", "padding", "dilation", "output_padding", "groups",
+                 "in_channels", "out_channels")
+
+    def __init__(self, nd, in_channels, out_channels, kernel=1, stride=1, padding=0, dilation=1, groups=1,
+                 transposed=False, output_padding=0):
+        self.nd, self.transposed, self.groups = nd, bool(transposed), int(groups)
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.kernel = _triple(kernel, nd, 1)
+        self.stride = _triple(stride, nd, 1)
+        self.padding = _triple(padding, nd, 0)
+        self.dilation = _triple(dilation, nd, 1)
+        self.output_padding = _triple(output_padding, nd, 0)
+
+    def out_spatial(self, spatial):
+        out = []
+        for i, k, s, p, d, op in zip(spatial, self.kernel, self.stride, self.padding, self.dilation,
+                                     self.output_padding):
+            if self.transposed:
+                out.append((i - 1) * s - 2 * p + d * (k - 1) + op + 1)
+            else:
+                out.append((i + 2 * p - d * (k - 1) - 1) // s + 1)
+        return tuple(out)
+
+
+def pack_gemm_major(w, op):
+    """logical parameter tensor -> the kernel's [N][tap][Cg] f32 layout (a pure layout permute).
+    Linear [out,in]: unchanged.  Conv [Cout, Cin/g, *k] -> [Cout, *k, Cin/g] (== channels_last storage).
+    ConvTranspose [Cin, Cout/g, *k] -> [g, Cout/g, taps, Cin/g]."""
+    if op.nd == 0:
+        return w.contiguous()
+    if not op.transposed:
+        perm = (0,) + tuple(range(2, 2 + op.nd)) + (1,)
+        return w.permute(perm).contiguous()
+    g = op.groups
+    cin, ng = w.shape[0], w.shape[1]
+    t = w.reshape(g, cin // g, ng, -1)  # [g, Cg, Ng, T]
+    return t.permute(0, 2, 3, 1).contiguous()  # [g, Ng, T, Cg]
+
+
+class PackedParams:
+    """Caches the GEMM-major copies of (mu, rho) and re-packs only when a parameter changed
+    (in-place update bumps `_version`; `.data = ...` changes `data_ptr`)."""
+
+    def __init__(self):
+        self._key = None
+        self._mu = self._rho = None
+
+    def get(self, mu, rho, op):
+        key = (mu.data_ptr(), mu._version, rho.data_ptr(), rho._version, mu.device)
+        if key != self._key:
+            with torch.no_grad():
+                self._mu = pack_gemm_major(mu.detach().float(), op)
+                self._rho = pack_gemm_major(rho.detach().float(), op)
+            self._key = key
+        return self._mu, self._rho
+
+
+_WS = {}
+
+
+def _workspace(device, nbytes, stream):
+    key = (device, stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _to_channels_last(x, op):
+    """-> (physical channels-last contiguous tensor, NB, (D,H,W), restore(out_phys, out_spatial) -> logical)."""
+    if op.nd == 0:
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        return x2, x2.shape[0], (1, 1, 1), lambda o, sp: o.reshape(*lead, op.out_channels)
+    if x.dim() != op.nd + 2:
+        raise ValueError("expected %dD input, got %dD" % (op.nd + 2, x.dim()))
+    nb = x.shape[0]
+    if op.nd == 1:
+        x4 = x.unsqueeze(2).contiguous(memory_format=torch.channels_last)
+        return x4, nb, (1, 1, x.shape[2]), lambda o, sp: o.squeeze(2)
+    if op.nd == 2:
+        return (x.contiguous(memory_format=torch.channels_last), nb, (1, x.shape[2], x.shape[3]),
+                lambda o, sp: o)
+    return (x.contiguous(memory_format=torch.channels_last_3d), nb, tuple(x.shape[2:]), lambda o, sp: o)
+
+
+def _alloc_out(op, nb, out_sp, dtype, device):
+    if op.nd == 0:
+        return torch.empty((nb, op.out_channels), dtype=dtype, device=device)
+    if op.nd == 3:
+        return torch.empty((nb, op.out_channels) + tuple(out_sp), dtype=dtype, device=device,
+                           memory_format=torch.channels_last_3d)
+    return torch.empty((nb, op.out_channels, out_sp[1], out_sp[2]), dtype=dtype, device=device,
+                       memory_format=torch.channels_last)
+
+
+def _sign_to_int8_cl(s, op):
+    """explicit +/-1 sign tensor in logical layout -> int8 channels-last physical buffer."""
+    phys, _, _, _ = _to_channels_last(s.to(torch.int8), op)
+    return phys
+
+
+def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_id, prec=None, noise=None):
+    """One fused sample-and-contract forward on the GPU (btx_contract_fwd).  `mu_p`/`rho_p` are GEMM-major packed.
+    `noise` (parity mode) = dict with optional eps_w (logical weight layout), eps_b, sign_in, sign_out."""
+    L = _lib.lib()
+    if not x.is_cuda:
+        raise _lib.BtxError("contract_hip needs a CUDA (ROCm) tensor")
+    if x.dtype == torch.float32:
+        act = _lib.ACT_F32
+    elif x.dtype == torch.bfloat16:
+        act = _lib.ACT_BF16
+    else:
+        raise _lib.BtxError("activations must be float32 or bfloat16, got %s" % x.dtype)
+    prec = prec or _PRECISION
+    prec_c = _lib.PREC_BF16 if prec == "bf16" else _lib.PREC_F32
+    xp, nb, spatial, restore = _to_channels_last(x, op)
+    out_sp = op.out_spatial(spatial)
+    if min(out_sp) <= 0:
+        raise ValueError("output size is too small")
+    g = _lib.Geom()
+    g.NB, (g.D, g.H, g.W), g.C, g.N = nb, spatial, op.in_channels, op.out_channels
+    g.KD, g.KH, g.KW = op.kernel
+    g.sd, g.sh, g.sw = op.stride
+    g.pd, g.ph, g.pw = op.padding
+    g.dd, g.dh, g.dw = op.dilation
+    g.od, g.oh, g.ow = op.output_padding
+    g.groups = op.groups
+    flags = _lib.FLAG_TRANSPOSED if op.transposed else 0
+    out = _alloc_out(op, nb, out_sp, x.dtype, x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    need = L.btx_contract_workspace_bytes(ctypes.byref(g), kind, act, prec_c, flags)
+    ws = _workspace(x.device, need, stream) if need else None
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    keep = []
+    nz = None
+    if noise:
+        nz = _lib.Noise()
+        if noise.get("eps_w") is not None:
+            t = pack_gemm_major(noise["eps_w"].to(device=x.device, dtype=torch.float32), op)
+            keep.append(t); nz.eps_w = t.data_ptr()
+        if noise.get("eps_b") is not None:
+            t = noise["eps_b"].to(device=x.device, dtype=torch.float32).contiguous()
+            keep.append(t); nz.eps_b = t.data_ptr()
+        if noise.get("sign_in") is not None:
+            t = _sign_to_int8_cl(noise["sign_in"].to(x.device), op)
+            keep.append(t); nz.sign_in = t.data_ptr()
+        if noise.get("sign_out") is not None:
+            so = noise["sign_out"].to(x.device)
+            if op.nd == 0:
+                so = so.reshape(-1, op.out_channels)
+            t = _sign_to_int8_cl(so, op)
+            keep.append(t); nz.sign_out = t.data_ptr()
+    rc = L.btx_contract_fwd(kind, ctypes.byref(g), xp.data_ptr(), mu_p.data_ptr(), rho_p.data_ptr(),
+                            mu_b.data_ptr() if mu_b is not None else None,
+                            rho_b.data_ptr() if rho_b is not None else None,
+                            out.data_ptr(), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None,
+                            act, prec_c, flags, ws.data_ptr() if ws is not None else None,
+                            ws.numel() if ws is not None else 0, stream)
+    _lib.check(rc)
+    return restore(out, out_sp)
+
+
+def kl_hip(mu, rho, prior_mu, prior_sigma, prior_mu_t=None, prior_sigma_t=None, out=None, accumulate=False):
+    """mean Gaussian KL of one parameter tensor on the GPU (btx_kl_gauss) -> 0-d f32 tensor."""
+    L = _lib.lib()
+    mu_c, rho_c = mu.detach().contiguous(), rho.detach().contiguous()
+    if mu_c.dtype != torch.float32 or rho_c.dtype != torch.float32:
+        raise _lib.BtxError("KL kernel needs float32 parameters")
+    n = mu_c.numel()
+    stream = torch.cuda.current_stream(mu.device).cuda_stream
+    ws = _workspace(mu.device, L.btx_kl_workspace_bytes(n), stream)
+    if out is None:
+        out = torch.empty((), dtype=torch.float32, device=mu.device)
+    pm = prior_mu_t.detach().contiguous() if prior_mu_t is not None else None
+    ps = prior_sigma_t.detach().contiguous() if prior_sigma_t is not None else None
+    rc = L.btx_kl_gauss(mu_c.data_ptr(), rho_c.data_ptr(), n, pm.data_ptr() if pm is not None else None,
+                        ps.data_ptr() if ps is not None else None, float(prior_mu), float(prior_sigma),
+                        out.data_ptr(), _lib.FLAG_KL_ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), stream)
+    _lib.check(rc)
+    return out
+
+
+def fill_eps_hip(shape_like, seed, sample_idx, layer_id, rng_stream):
+    """BTX-RNG v1 eps for a flat index space of shape_like.numel() elements, as a flat f32 CUDA tensor."""
+    L = _lib.lib()
+    out = torch.empty(shape_like.numel(), dtype=torch.float32, device=shape_like.device)
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    _lib.check(L.btx_fill_eps(out.data_ptr(), out.numel(), ctypes.byref(r), rng_stream,
+                              torch.cuda.current_stream(out.device).cuda_stream))
+    return out
+
+
+def fill_sign_hip(n, device, seed, sample_idx, layer_id, rng_stream):
+    L = _lib.lib()
+    out = torch.empty(int(n), dtype=torch.int8, device=device)
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    _lib.check(L.btx_fill_sign(out.data_ptr(), out.numel(), ctypes.byref(r), rng_stream,
+                               torch.cuda.current_stream(out.device).cuda_stream))
+    return out
+
+
+def unpack_gemm_major(flat, w_shape, op):
+    """inverse of pack_gemm_major for a flat [N*taps*Cg] tensor -> logical parameter layout."""
+    if op.nd == 0:
+        return flat.reshape(w_shape)
+    k = tuple(w_shape[2:])
+    if not op.transposed:
+        t = flat.reshape((w_shape[0],) + k + (w_shape[1],))
+        perm = (0, op.nd + 1) + tuple(range(1, op.nd + 1))
+        return t.permute(perm).contiguous()
+    g = op.groups
+    cin, ng = w_shape[0], w_shape[1]
+    t = flat.reshape(g, ng, -1, cin // g).permute(0, 3, 1, 2).contiguous()  # [g, Cg, Ng, T]
+    return t.reshape((cin, ng) + k)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# ATen route for CPU tensors (BASELINE.json config 0) and for autograd-on-request (`backend="torch"`).
+# Same op chain and the same torch-generator draw order as the reference methods cited in each layer class.
+# --------------------------------------------------------------------------------------------------------------
+_CONV = {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}
+_CONVT = {1: F.conv_transpose1d, 2: F.conv_transpose2d, 3: F.conv_transpose3d}
+
+
+def contract_aten(x, w, b, op):
+    nd = op.nd
+    if nd == 0:
+        return F.linear(x, w, b)
+    st, pd, dl, opd = op.stride[3 - nd:], op.padding[3 - nd:], op.dilation[3 - nd:], op.output_padding[3 - nd:]
+    if op.transposed:
+        return _CONVT[nd](x, w, b, st, pd, opd, op.groups, dl)
+    return _CONV[nd](x, w, b, st, pd, dl, op.groups)
+
+
+def softplus_naive(rho):
+    return torch.log1p(torch.exp(rho))
+
+
+def kl_aten(mu_q, sigma_q, mu_p, sigma_p):
+    kl = torch.log(sigma_p) - torch.log(sigma_q) + (sigma_q ** 2 + (mu_q - mu_p) ** 2) / (2 * (sigma_p ** 2)) - 0.5
+    return kl.mean()

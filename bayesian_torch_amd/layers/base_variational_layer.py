@@ -1,0 +1,298 @@
+"""BaseVariationalLayer_ and the shared implementation of every variational layer.
+
+API mirror of reference `layers/base_variational_layer.py:35-68` (get_kernel_size, dnn_to_bnn_flag, kl_div) plus
+`_VariationalNd`, the one implementation behind the 14 public classes (Linear / Conv{1,2,3}d / ConvTranspose{1,2,3}d
+x Reparameterization / Flipout).  On a CUDA tensor `forward` is ONE call into libbtx.so (fused sampling +
+implicit-GEMM contraction) and `kl_loss` is the HIP KL reduction, cached per parameter version; on a CPU tensor it
+is the ATen op chain of the cited reference method with the reference's torch-generator draw order.
+"""
+import collections
+import warnings
+from itertools import repeat
+
+import torch
+import torch.nn as nn
+from torch.nn import Parameter
+
+from .. import _lib
+from .. import functional as BF
+from .. import rng as _rng
+
+_BACKEND = "auto"  # "auto": CUDA+no-grad -> hip, CPU or autograd -> aten ; "hip": strict ; "torch": always aten
+_warned_autograd = False
+
+
+def set_backend(name):
+    global _BACKEND
+    if name not in ("auto", "hip", "torch"):
+        raise ValueError("backend must be auto|hip|torch")
+    _BACKEND = name
+
+
+def get_kernel_size(x, n):
+    if isinstance(x, collections.abc.Iterable):
+        return tuple(x)
+    return tuple(repeat(x, n))
+
+
+class BaseVariationalLayer_(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._dnn_to_bnn_flag = False
+
+    @property
+    def dnn_to_bnn_flag(self):
+        return self._dnn_to_bnn_flag
+
+    @dnn_to_bnn_flag.setter
+    def dnn_to_bnn_flag(self, value):
+        self._dnn_to_bnn_flag = value
+
+    def kl_div(self, mu_q, sigma_q, mu_p, sigma_p):
+        """KL(Q||P) of two diagonal Gaussians, MEAN-reduced (reference base_variational_layer.py:53-68)."""
+        return BF.kl_aten(mu_q, sigma_q, mu_p, sigma_p)
+
+
+class _VariationalNd(BaseVariationalLayer_):
+    """family: "reparam" | "flipout".  nd: 0 Linear, 1/2/3 Conv.  Draw orders:
+    reparam: eps_w, eps_b ; linear flipout: eps_w, eps_b, s_in, s_out ; conv flipout: s_in, s_out, eps_w, eps_b."""
+
+    _family = "reparam"
+    _nd = 0
+    _transposed = False
+
+    def _setup(self, in_ch, out_ch, kernel_size, stride, padding, dilation, groups, output_padding,
+               prior_mean, prior_variance, posterior_mu_init, posterior_rho_init, bias, check_groups):
+        nd = self._nd
+        if nd > 0 and check_groups:
+            if in_ch % groups != 0:
+                raise ValueError('invalid in_channels size')
+            if out_ch % groups != 0:
+                raise ValueError('invalid in_channels size')
+        self.prior_mean = prior_mean
+        self.prior_variance = prior_variance
+        self.bias = bias
+        wn = "weight" if nd == 0 else "kernel"
+        self._wn = wn
+        if nd == 0:
+            self.in_features, self.out_features = in_ch, out_ch
+            wshape = (out_ch, in_ch)
+            ksz = 1
+        else:
+            self.in_channels, self.out_channels = in_ch, out_ch
+            self.kernel_size = kernel_size
+            self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+            if self._transposed:
+                self.output_padding = output_padding
+            ksz = get_kernel_size(kernel_size, nd)
+            if len(ksz) != nd:
+                raise ValueError("kernel_size must have %d entries" % nd)
+            wshape = ((in_ch, out_ch // groups) if self._transposed else (out_ch, in_ch // groups)) + tuple(ksz)
+        self._op = BF.OpDesc(nd, in_ch, out_ch, ksz if nd else 1, stride if nd else 1, padding if nd else 0,
+                             dilation if nd else 1, groups if nd else 1, self._transposed,
+                             output_padding if (nd and self._transposed) else 0)
+        setattr(self, "mu_" + wn, Parameter(torch.Tensor(*wshape)))
+        setattr(self, "rho_" + wn, Parameter(torch.Tensor(*wshape)))
+        self.register_buffer("eps_" + wn, torch.Tensor(*wshape), persistent=False)
+        self.register_buffer("prior_weight_mu", torch.Tensor(*wshape), persistent=False)
+        self.register_buffer("prior_weight_sigma", torch.Tensor(*wshape), persistent=False)
+        if bias:
+            self.mu_bias = Parameter(torch.Tensor(out_ch))
+            self.rho_bias = Parameter(torch.Tensor(out_ch))
+            self.register_buffer("eps_bias", torch.Tensor(out_ch), persistent=False)
+            self.register_buffer("prior_bias_mu", torch.Tensor(out_ch), persistent=False)
+            self.register_buffer("prior_bias_sigma", torch.Tensor(out_ch), persistent=False)
+        else:
+            self.register_parameter("mu_bias", None)
+            self.register_parameter("rho_bias", None)
+            self.register_buffer("eps_bias", None, persistent=False)
+            self.register_buffer("prior_bias_mu", None, persistent=False)
+            self.register_buffer("prior_bias_sigma", None, persistent=False)
+        # MI355X-side state (not part of the reference surface)
+        self._btx_layer_id = _rng.next_layer_id()
+        self._btx_sample = 0
+        self._btx_packed = BF.PackedParams()
+        self._btx_kl_cache = (None, None)
+        self.precision = None  # None -> functional.get_precision(); or "f32" / "bf16"
+        self.init_parameters()
+        self._btx_prior_versions = self._prior_versions()
+        self.quant_prepare = False
+
+    # ---- reference surface --------------------------------------------------------------------------------
+    def _w(self):
+        return getattr(self, "mu_" + self._wn), getattr(self, "rho_" + self._wn)
+
+    def _mu_rho_init(self):
+        mu0, rho0 = self.posterior_mu_init, self.posterior_rho_init
+        if isinstance(mu0, tuple):  # the Reparameterization classes keep 1-tuples (reference quirk)
+            mu0, rho0 = mu0[0], rho0[0]
+        return mu0, rho0
+
+    def init_parameters(self):
+        mu, rho = self._w()
+        mu0, rho0 = self._mu_rho_init()
+        self.prior_weight_mu.fill_(self.prior_mean)
+        self.prior_weight_sigma.fill_(self.prior_variance)
+        mu.data.normal_(mean=mu0, std=0.1)
+        rho.data.normal_(mean=rho0, std=0.1)
+        if self.mu_bias is not None:
+            self.prior_bias_mu.fill_(self.prior_mean)
+            self.prior_bias_sigma.fill_(self.prior_variance)
+            self.mu_bias.data.normal_(mean=mu0, std=0.1)
+            self.rho_bias.data.normal_(mean=rho0, std=0.1)
+
+    def _prior_versions(self):
+        v = [self.prior_weight_mu._version, self.prior_weight_sigma._version]
+        if self.prior_bias_mu is not None:
+            v += [self.prior_bias_mu._version, self.prior_bias_sigma._version]
+        return tuple(v)
+
+    def _use_hip(self, t):
+        if _BACKEND == "torch" or not t.is_cuda:
+            if _BACKEND == "hip" and not t.is_cuda:
+                raise _lib.BtxError("backend 'hip' needs CUDA (ROCm) tensors")
+            return False
+        mu, rho = self._w()
+        needs_grad = torch.is_grad_enabled() and (mu.requires_grad or rho.requires_grad or
+                                                  (t.requires_grad if t.is_floating_point() else False))
+        if needs_grad:
+            if _BACKEND == "hip":
+                raise _lib.BtxError("autograd through the HIP forward is not implemented; wrap the call in "
+                                    "torch.no_grad() or set_backend('torch')")
+            global _warned_autograd
+            if not _warned_autograd:
+                warnings.warn("bayesian_torch_amd: autograd requested — this call uses the ATen op chain; the fused "
+                              "HIP kernels are forward-only (use torch.no_grad() for MC inference).")
+                _warned_autograd = True
+            return False
+        return True
+
+    def kl_loss(self):
+        mu, rho = self._w()
+        if not self._use_hip(mu):
+            kl = self.kl_div(mu, BF.softplus_naive(rho), self.prior_weight_mu, self.prior_weight_sigma)
+            if self.mu_bias is not None:
+                kl = kl + self.kl_div(self.mu_bias, BF.softplus_naive(self.rho_bias), self.prior_bias_mu,
+                                      self.prior_bias_sigma)
+            return kl
+        key = (mu.data_ptr(), mu._version, rho.data_ptr(), rho._version, self._prior_versions(),
+               None if self.mu_bias is None else (self.mu_bias.data_ptr(), self.mu_bias._version,
+                                                  self.rho_bias.data_ptr(), self.rho_bias._version))
+        if self._btx_kl_cache[0] != key:
+            # priors are scalars unless someone (utils.util.MOPED) overwrote the full-shape buffers
+            tens = self._prior_versions() != self._btx_prior_versions
+            kl = BF.kl_hip(mu, rho, self.prior_mean, self.prior_variance,
+                           self.prior_weight_mu if tens else None, self.prior_weight_sigma if tens else None)
+            if self.mu_bias is not None:
+                BF.kl_hip(self.mu_bias, self.rho_bias, self.prior_mean, self.prior_variance,
+                          self.prior_bias_mu if tens else None, self.prior_bias_sigma if tens else None,
+                          out=kl, accumulate=True)
+            self._btx_kl_cache = (key, kl)
+        return self._btx_kl_cache[1].clone()  # callers (get_kl_loss) += into the returned tensor
+
+    def forward(self, input, return_kl=True):
+        if self.dnn_to_bnn_flag:
+            return_kl = False
+        if self._use_hip(input):
+            out = self._forward_hip(input)
+            if return_kl:
+                return out, self.kl_loss()
+            return out
+        return self._forward_aten(input, return_kl)
+
+    # ---- MI355X path -----------------------------------------------------------------------------------------
+    def _forward_hip(self, x, noise=None, sample_idx=None):
+        mu, rho = self._w()
+        mu_p, rho_p = self._btx_packed.get(mu, rho, self._op)
+        if sample_idx is None:
+            sample_idx = self._btx_sample
+            self._btx_sample += 1
+        kind = _lib.KIND_FLIPOUT if self._family == "flipout" else _lib.KIND_REPARAM
+        mb = self.mu_bias.detach() if self.mu_bias is not None else None
+        rb = self.rho_bias.detach() if self.rho_bias is not None else None
+        return BF.contract_hip(kind, x, mu_p, rho_p, mb, rb, self._op, _rng.seed(), sample_idx,
+                               self._btx_layer_id, prec=self.precision, noise=noise)
+
+    def materialize_noise(self, sample_idx, x_shape=None, out_shape=None):
+        """The noise BTX-RNG v1 defines for MC sample `sample_idx` of this layer, in the reference's logical
+        layouts: dict(eps_w, eps_b[, sign_in, sign_out]).  Also refreshes the eps_* buffers (the reference's
+        observable side effect, conv_variational.py:362)."""
+        mu, _ = self._w()
+        op, seed, lid = self._op, _rng.seed(), self._btx_layer_id
+        flat = BF.fill_eps_hip(mu, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+        d = {"eps_w": BF.unpack_gemm_major(flat, tuple(mu.shape), op)}
+        getattr(self, "eps_" + self._wn).copy_(d["eps_w"])
+        if self.mu_bias is not None:
+            d["eps_b"] = BF.fill_eps_hip(self.mu_bias, seed, sample_idx, lid, _lib.STREAM_EPS_B)
+            self.eps_bias.copy_(d["eps_b"])
+        if self._family == "flipout" and x_shape is not None:
+            def cl_to_logical(flat8, shape):
+                if op.nd == 0:
+                    return flat8.reshape(shape)
+                n, c, sp = shape[0], shape[1], tuple(shape[2:])
+                t = flat8.reshape((n,) + sp + (c,))
+                return t.permute((0, op.nd + 1) + tuple(range(1, op.nd + 1)))
+            nin = 1
+            for v in x_shape:
+                nin *= v
+            nout = 1
+            for v in out_shape:
+                nout *= v
+            d["sign_in"] = cl_to_logical(BF.fill_sign_hip(nin, mu.device, seed, sample_idx, lid,
+                                                          _lib.STREAM_SIGN_IN), tuple(x_shape))
+            d["sign_out"] = cl_to_logical(BF.fill_sign_hip(nout, mu.device, seed, sample_idx, lid,
+                                                           _lib.STREAM_SIGN_OUT), tuple(out_shape))
+        return d
+
+    # ---- ATen path (CPU tensors / autograd) -------------------------------------------------------------------
+    def _forward_aten(self, x, return_kl):
+        mu, rho = self._w()
+        op = self._op
+        eps_w_buf = getattr(self, "eps_" + self._wn)
+        has_b = self.mu_bias is not None
+        kl = None
+        if self._family == "reparam":
+            sigma_w = BF.softplus_naive(rho)
+            weight = mu + (sigma_w * eps_w_buf.data.normal_())
+            if return_kl:
+                kl = self.kl_div(mu, sigma_w, self.prior_weight_mu, self.prior_weight_sigma)
+            b = None
+            if has_b:
+                sigma_b = BF.softplus_naive(self.rho_bias)
+                b = self.mu_bias + (sigma_b * self.eps_bias.data.normal_())
+                if return_kl:
+                    kl = kl + self.kl_div(self.mu_bias, sigma_b, self.prior_bias_mu, self.prior_bias_sigma)
+            out = BF.contract_aten(x, weight, b, op)
+        elif op.nd == 0:  # LinearFlipout: eps first, then the signs
+            sigma_w = BF.softplus_naive(rho)
+            delta = sigma_w * eps_w_buf.data.normal_()
+            if return_kl:
+                kl = self.kl_div(mu, sigma_w, self.prior_weight_mu, self.prior_weight_sigma)
+            b = None
+            if has_b:
+                sigma_b = BF.softplus_naive(self.rho_bias)
+                b = sigma_b * self.eps_bias.data.normal_()
+                if return_kl:
+                    kl = kl + self.kl_div(self.mu_bias, sigma_b, self.prior_bias_mu, self.prior_bias_sigma)
+            outputs = BF.contract_aten(x, mu, self.mu_bias, op)
+            sign_in = x.clone().uniform_(-1, 1).sign()
+            sign_out = outputs.clone().uniform_(-1, 1).sign()
+            out = outputs + BF.contract_aten(x * sign_in, delta, b, op) * sign_out
+        else:  # Conv*Flipout: signs first, then eps
+            outputs = BF.contract_aten(x, mu, self.mu_bias, op)
+            sign_in = x.clone().uniform_(-1, 1).sign()
+            sign_out = outputs.clone().uniform_(-1, 1).sign()
+            sigma_w = BF.softplus_naive(rho)
+            delta = sigma_w * eps_w_buf.data.normal_()
+            if return_kl:
+                kl = self.kl_div(mu, sigma_w, self.prior_weight_mu, self.prior_weight_sigma)
+            b = None
+            if has_b:
+                sigma_b = BF.softplus_naive(self.rho_bias)
+                b = sigma_b * self.eps_bias.data.normal_()
+                if return_kl:
+                    kl = kl + self.kl_div(self.mu_bias, sigma_b, self.prior_bias_mu, self.prior_bias_sigma)
+            out = outputs + BF.contract_aten(x * sign_in, delta, b, op) * sign_out
+        if return_kl:
+            return out, kl
+        return out

@@ -1,0 +1,143 @@
+"""Drop-in surface of the Python face — CPU only.  Everything is compared with values recorded from
+the reference itself by tools/make_golden.py (signatures, state_dict keys, KL known-answers, forward outputs)."""
+import inspect
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import bayesian_torch_amd as bt
+from bayesian_torch_amd import layers as L
+from bayesian_torch_amd.models.resnet import resnet18, resnet50
+
+warnings.filterwarnings("ignore")
+
+
+def _build(meta):
+    torch.manual_seed(meta["init_seed"])
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in meta["kwargs"].items()}
+    layer = getattr(L, meta["cls"])(**kw)
+    x = torch.randn(*meta["x_shape"])
+    return layer, x
+
+
+def test_signatures_match_reference(golden):
+    for name, sig in golden["kat"]["signatures"].items():
+        assert str(inspect.signature(getattr(L, name).__init__)) == sig, name
+
+
+def test_same_seed_same_parameters_and_state_dict(golden):
+    """init_parameters draws mu_w, rho_w, mu_b, rho_b in the reference's order -> identical tensors per torch seed"""
+    for name, (meta, d) in golden["cases"].items():
+        layer, x = _build(meta)
+        assert list(layer.state_dict().keys()) == meta["state_dict_keys"], name
+        wn = "weight" if meta["cls"].startswith("Linear") else "kernel"
+        assert np.array_equal(getattr(layer, "mu_" + wn).detach().numpy(), d["mu_w"]), name
+        assert np.array_equal(getattr(layer, "rho_" + wn).detach().numpy(), d["rho_w"]), name
+        assert np.array_equal(x.numpy(), d["x"]), name
+        if "mu_b" in d:
+            assert np.array_equal(layer.mu_bias.detach().numpy(), d["mu_b"]), name
+        else:
+            assert layer.mu_bias is None and layer.rho_bias is None and layer.eps_bias is None
+        assert float(layer.kl_loss()) == meta["kl"], name
+
+
+def test_cpu_forward_is_bit_exact_vs_reference(golden):
+    """CPU tensors take the ATen op chain with the reference's torch-generator draw order (BASELINE config 0)"""
+    for name, (meta, d) in golden["cases"].items():
+        layer, x = _build(meta)
+        with torch.no_grad():
+            torch.manual_seed(meta["fwd_seed"])
+            out, kl = layer(x)
+        assert np.array_equal(out.numpy(), d["out"]), name
+        assert float(kl) == meta["kl"], name
+        wn = "weight" if meta["cls"].startswith("Linear") else "kernel"
+        # observable side effect: eps_* holds the eps of the last forward
+        assert np.array_equal(getattr(layer, "eps_" + wn).numpy(), d["eps_w"]), name
+        layer.dnn_to_bnn_flag = True
+        with torch.no_grad():
+            torch.manual_seed(meta["fwd_seed"])
+            out2 = layer(x)
+        assert torch.equal(out2, out)
+
+
+def test_attributes_and_errors():
+    l = L.Conv2dReparameterization(8, 16, 3, stride=2, padding=1)
+    assert l.posterior_mu_init == (0,) and l.posterior_rho_init == (-3.0,)  # 1-tuples, reference quirk
+    assert (l.in_channels, l.out_channels, l.kernel_size, l.stride, l.padding, l.dilation, l.groups) == \
+        (8, 16, 3, 2, 1, 1, 1)
+    assert l.bias is True and l.quant_prepare is False and l.dnn_to_bnn_flag is False
+    assert l.prior_weight_mu.shape == l.mu_kernel.shape and float(l.prior_weight_sigma[0, 0, 0, 0]) == 1.0
+    f = L.LinearFlipout(10, 4, bias=False)
+    assert f.posterior_mu_init == 0 and f.mu_weight.shape == (4, 10) and f.mu_bias is None
+    with pytest.raises(ValueError, match="invalid in_channels size"):
+        L.Conv2dReparameterization(6, 8, 3, groups=4)
+    t = L.ConvTranspose2dFlipout(8, 6, 3, stride=2, output_padding=1)
+    assert t.mu_kernel.shape == (8, 6, 3, 3) and t.output_padding == 1
+    assert isinstance(l, L.BaseVariationalLayer_)
+    # buffers are non-persistent: state_dict has only mu_* / rho_*
+    assert set(l.state_dict()) == {"mu_kernel", "rho_kernel", "mu_bias", "rho_bias"}
+
+
+def test_dnn_to_bnn_and_kl_known_answers(golden):
+    km = golden["kat"]["models"]
+    base = dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, moped_delta=0.5)
+    for key, arch, typ, moped in (("resnet18_Reparameterization", resnet18, "Reparameterization", False),
+                                  ("resnet18_Flipout", resnet18, "Flipout", False),
+                                  ("resnet18_Flipout_moped", resnet18, "Flipout", True),
+                                  ("resnet50_Flipout", resnet50, "Flipout", False)):
+        torch.manual_seed(0)
+        m = arch()
+        bt.dnn_to_bnn(m, dict(base, type=typ, moped_enable=moped))
+        bl = [(n, mod.__class__.__name__) for n, mod in m.named_modules() if hasattr(mod, "kl_loss")]
+        assert len(bl) == km[key]["n_bayes_layers"]
+        assert list(bl[0]) == km[key]["first"] and list(bl[-1]) == km[key]["last"]
+        assert all(mod.dnn_to_bnn_flag for mod in m.modules() if hasattr(mod, "kl_loss"))
+        cs = sum(float(q.double().sum()) for n, q in m.named_parameters() if ".mu_" in n or n.startswith("mu_"))
+        assert abs(cs - km[key]["checksum_mu"]) < 1e-9 * max(1.0, abs(cs)), key  # same seed -> same parameters
+        kl = float(bt.get_kl_loss(m))
+        assert abs(kl - km[key]["kl"]) <= 1e-6 * km[key]["kl"], (key, kl)
+    with pytest.raises(KeyError):
+        bt.dnn_to_bnn(resnet18(), dict(base, type="Flipout"))  # moped_enable has no default in the reference
+    assert bt.get_kl_loss(torch.nn.ReLU()) is None
+
+
+def test_get_rho(golden):
+    g = golden["kat"]["models"]["get_rho"]
+    r = bt.utils.util.get_rho(torch.tensor(g["w"]), g["delta"])
+    assert np.array_equal(r.numpy(), np.array(g["rho"], dtype=np.float32))
+
+
+def test_converted_model_runs_on_cpu_and_returns_only_out():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Flatten(),
+                            torch.nn.Linear(8 * 6 * 6, 5))
+    bt.dnn_to_bnn(m, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0,
+                          type="Flipout", moped_enable=True, moped_delta=0.5))
+    assert m[0].__class__.__name__ == "Conv2dFlipout" and m[3].__class__.__name__ == "LinearFlipout"
+    with torch.no_grad():
+        y = m(torch.randn(2, 3, 6, 6))
+    assert y.shape == (2, 5)
+    kl = bt.get_kl_loss(m)
+    assert kl.dim() == 0 and float(kl) > 0
+
+
+def test_install_alias():
+    import sys
+    bt.install_alias("bayesian_torch_alias_for_test")
+    import importlib
+    mod = importlib.import_module("bayesian_torch_alias_for_test.layers")
+    assert mod.Conv2dFlipout is L.Conv2dFlipout
+    from bayesian_torch_alias_for_test.models.dnn_to_bnn import dnn_to_bnn  # noqa: F401
+    for k in [k for k in sys.modules if k.startswith("bayesian_torch_alias_for_test")]:
+        del sys.modules[k]
+
+
+def test_cuda_path_fails_loudly_without_library(monkeypatch):
+    """a GPU tensor may never silently take another path: with libbtx.so absent the binding raises"""
+    from bayesian_torch_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "lib_path", lambda: "/nonexistent/libbtx.so")
+    with pytest.raises(_lib.BtxError, match="no fallback"):
+        _lib.lib()

@@ -1,0 +1,59 @@
+"""The C-ABI face: libbtx.so loads without a GPU and exports exactly what include/btx.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "btx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(btx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bayesian_torch_amd import _lib
+    names = _declared()
+    assert len(names) >= 11
+    assert set(names) == set(_lib.EXPORTS)
+    L = ctypes.CDLL(_lib.lib_path())
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_abi_version_and_argument_errors_without_gpu():
+    """pure host-side calls: version, strerror, shape arithmetic, argument validation (no kernel is launched)"""
+    from bayesian_torch_amd import _lib
+    L = _lib.lib()
+    assert L.btx_abi_version() == 1
+    assert b"NULL" in L.btx_strerror(-1)
+    g = _lib.Geom()
+    g.NB, g.D, g.H, g.W, g.C, g.N = 64, 1, 56, 56, 64, 128
+    g.KD, g.KH, g.KW = 1, 3, 3
+    g.sd, g.sh, g.sw = 1, 2, 2
+    g.pd, g.ph, g.pw = 0, 1, 1
+    g.dd = g.dh = g.dw = 1
+    g.groups = 1
+    d, h, w = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert L.btx_out_shape(ctypes.byref(g), 0, ctypes.byref(d), ctypes.byref(h), ctypes.byref(w)) == 0
+    assert (d.value, h.value, w.value) == (1, 28, 28)
+    assert L.btx_out_shape(ctypes.byref(g), 1, ctypes.byref(d), ctypes.byref(h), ctypes.byref(w)) == 0
+    assert (h.value, w.value) == (111, 111)
+    g.groups = 3
+    assert L.btx_out_shape(ctypes.byref(g), 0, ctypes.byref(d), ctypes.byref(h), ctypes.byref(w)) == -2
+    g.groups = 1
+    assert L.btx_contract_fwd(1, ctypes.byref(g), None, None, None, None, None, None, None, None, 0, 0, 0, None, 0,
+                              None) == -1
+    assert L.btx_kl_gauss(None, None, 10, None, None, 0.0, 1.0, None, 0, None, 0, None) == -1
+    assert L.btx_mc_packed_floats(64, 1000) == 2 * 64 * 1000 + 64 + 2
+    # split-K plan: the small-M ResNet18 layer4 shape needs a workspace, the big-M layer1 shape does not
+    g.H = g.W = 7
+    g.C = g.N = 512
+    g.sh = g.sw = 1
+    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) > 0
+    g.H = g.W = 56
+    g.C = g.N = 64
+    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) == 0
