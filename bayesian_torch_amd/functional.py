@@ -104,6 +104,20 @@ class PackedParams:
 
 _WS = {}
 
+# optional per-launch HIP-event timing of btx_contract_fwd (bench.py's roofline leg).  Events are recorded on the
+# stream the kernel is launched on (torch's current stream == the stream handed to the C-ABI).
+_LAUNCH_LOG = None
+
+
+def enable_launch_timing(on=True):
+    global _LAUNCH_LOG
+    _LAUNCH_LOG = [] if on else None
+
+
+def launch_log():
+    """[(tag, flops, start_event, end_event)] recorded since enable_launch_timing(True)."""
+    return _LAUNCH_LOG
+
 
 def _workspace(device, nbytes, stream):
     key = (device, stream)
@@ -199,6 +213,10 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
                 so = so.reshape(-1, op.out_channels)
             t = _sign_to_int8_cl(so, op)
             keep.append(t); nz.sign_out = t.data_ptr()
+    ev0 = None
+    if _LAUNCH_LOG is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(x.device))
     rc = L.btx_contract_fwd(kind, ctypes.byref(g), xp.data_ptr(), mu_p.data_ptr(), rho_p.data_ptr(),
                             mu_b.data_ptr() if mu_b is not None else None,
                             rho_b.data_ptr() if rho_b is not None else None,
@@ -206,6 +224,16 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
                             act, prec_c, flags, ws.data_ptr() if ws is not None else None,
                             ws.numel() if ws is not None else 0, stream)
     _lib.check(rc)
+    if ev0 is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream(x.device))
+        m_rows = nb * out_sp[0] * out_sp[1] * out_sp[2]
+        k_red = op.kernel[0] * op.kernel[1] * op.kernel[2] * (op.in_channels // op.groups)
+        flops = 2.0 * m_rows * op.out_channels * k_red * (2 if kind == _lib.KIND_FLIPOUT else 1)
+        tag = "%s/%s/%s k%dx%dx%d cin%d cout%d M%d" % ("flipout" if kind else "reparam", prec,
+                                                     "bf16" if act == _lib.ACT_BF16 else "f32", op.kernel[0],
+                                                     op.kernel[1], op.kernel[2], op.in_channels, op.out_channels, m_rows)
+        _LAUNCH_LOG.append((tag, flops, ev0, ev1))
     return restore(out, out_sp)
 
 

@@ -70,4 +70,9 @@ def get_kl_loss(m):
         return None
     if len(terms) == 1:
         return terms[0]
+    if not terms[0].is_cuda:  # CPU: the reference's sequential += chain, bit for bit
+        kl = terms[0]
+        for t in terms[1:]:
+            kl = kl + t
+        return kl
     return torch.stack(terms).sum()

@@ -145,3 +145,24 @@ class RefVariationalLinear(torch.nn.Module):
         s_in = x.clone().uniform_(-1, 1).sign()
         s_out = out.clone().uniform_(-1, 1).sign()
         return out + F.linear(x * s_in, delta, bias) * s_out
+
+
+def convert_for_baseline(model):
+    """Replace every variational layer of a CPU model (duck-typed: has mu_kernel/rho_kernel or mu_weight/rho_weight
+    and a `_family`) by the Ref* module above, in place.  Used by bench.py's cpu_baseline leg only."""
+    for name, child in list(model._modules.items()):
+        if child is None:
+            continue
+        if hasattr(child, "mu_kernel") and hasattr(child, "rho_kernel"):
+            kind = "Flipout" if getattr(child, "_family", "") == "flipout" else "Reparameterization"
+            if child.mu_bias is not None or child.groups != 1 or child.dilation not in (1, (1, 1)):
+                raise NotImplementedError("baseline converter covers the bias-free ResNet convs")
+            setattr(model, name, RefVariationalConv2d(child.mu_kernel.detach(), child.rho_kernel.detach(), child.stride,
+                                                      child.padding, kind))
+        elif hasattr(child, "mu_weight") and hasattr(child, "rho_weight"):
+            kind = "Flipout" if getattr(child, "_family", "") == "flipout" else "Reparameterization"
+            setattr(model, name, RefVariationalLinear(child.mu_weight.detach(), child.rho_weight.detach(),
+                                                      child.mu_bias.detach(), child.rho_bias.detach(), kind))
+        else:
+            convert_for_baseline(child)
+    return model

@@ -1,0 +1,203 @@
+"""GPU parity tests of the fused sample-and-contract kernels (btx_contract_fwd), all through the C-ABI.
+
+Tolerances (rel-L2 over the output tensor):
+  f32 MFMA path  vs reference outputs / f64-accumulating oracle : 1e-5   (north_star bar: 1e-4)
+  bf16 MFMA path vs the oracle run on bf16-rounded operands      : 5e-4   (f32 vs f64 accumulation + a few weights
+                                                                           whose bf16 rounding flips on the ~1e-6
+                                                                           difference of the fast transcendentals)
+  bf16 MFMA path vs the f32 reference                             : 1e-2   (8-bit mantissas; stated, not 1e-4)
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import case_geometry, oracle_forward, rel_l2
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore")
+
+TOL_F32, TOL_BF16_ORACLE, TOL_BF16_REF = 1e-5, 5e-4, 1e-2
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _layer_from_meta(meta, dev):
+    from bayesian_torch_amd import layers as L
+    torch.manual_seed(meta["init_seed"])
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in meta["kwargs"].items()}
+    return getattr(L, meta["cls"])(**kw).to(dev)
+
+
+def _noise_from(d, dev):
+    nz = {"eps_w": torch.from_numpy(d["eps_w"]).to(dev)}
+    if "eps_b" in d:
+        nz["eps_b"] = torch.from_numpy(d["eps_b"]).to(dev)
+    if "sign_in" in d:
+        nz["sign_in"] = torch.from_numpy(d["sign_in"]).to(dev)
+        nz["sign_out"] = torch.from_numpy(d["sign_out"]).to(dev)
+    return nz
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_explicit_noise_vs_reference_outputs(golden, prec):
+    """the reference's own noise + parameters + inputs -> must reproduce the reference's own outputs"""
+    dev = _dev()
+    for name, (meta, d) in golden["cases"].items():
+        layer = _layer_from_meta(meta, dev)
+        layer.precision = prec
+        x = torch.from_numpy(d["x"]).to(dev)
+        with torch.no_grad():
+            out = layer._forward_hip(x, noise=_noise_from(d, dev), sample_idx=0).float().cpu().numpy()
+        assert out.shape == d["out"].shape, name
+        err = rel_l2(out, d["out"])
+        assert err < (TOL_F32 if prec == "f32" else TOL_BF16_REF), (name, prec, err)
+        if prec == "bf16":
+            geo = case_geometry(meta)
+            ob = oracle_forward(geo, d["x"], d["mu_w"], d["rho_w"], d.get("mu_b"), d.get("rho_b"), d["eps_w"],
+                                d.get("eps_b"), d.get("sign_in"), d.get("sign_out"), bf16=True)
+            assert rel_l2(out, ob) < TOL_BF16_ORACLE, (name, rel_l2(out, ob))
+
+
+# (class, kwargs, x shape) — channel counts that take the FAST granule kernels (C/groups % 8 == 0)
+FUSED_CASES = [
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=64, kernel_size=3, stride=1, padding=1, bias=False), (2, 64, 14, 14)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=80, kernel_size=3, stride=2, padding=1), (3, 32, 15, 13)),
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=1, stride=2, padding=0, bias=False), (2, 64, 10, 10)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=48, kernel_size=3, padding=2, dilation=2, groups=2), (2, 32, 9, 11)),
+    ("Conv2dFlipout", dict(in_channels=256, out_channels=64, kernel_size=3, padding=1, bias=False), (2, 256, 7, 7)),  # split-K
+    ("Conv2dFlipout", dict(in_channels=24, out_channels=40, kernel_size=3, padding=1), (1, 24, 20, 20)),  # C%32 != 0
+    ("Conv2dReparameterization", dict(in_channels=64, out_channels=96, kernel_size=3, stride=1, padding=1), (2, 64, 12, 12)),
+    ("Conv2dReparameterization", dict(in_channels=128, out_channels=32, kernel_size=5, stride=2, padding=2, bias=False), (1, 128, 17, 17)),
+    ("Conv1dFlipout", dict(in_channels=16, out_channels=32, kernel_size=5, stride=2, padding=2), (3, 16, 301)),
+    ("Conv1dReparameterization", dict(in_channels=8, out_channels=8, kernel_size=3, padding=1), (2, 8, 50)),
+    ("Conv3dFlipout", dict(in_channels=8, out_channels=16, kernel_size=3, stride=(1, 2, 1), padding=1), (2, 8, 5, 8, 6)),
+    ("ConvTranspose2dFlipout", dict(in_channels=16, out_channels=16, kernel_size=4, stride=2, padding=1), (2, 16, 6, 7)),
+    ("ConvTranspose2dReparameterization", dict(in_channels=16, out_channels=24, kernel_size=3, stride=2, padding=1, output_padding=1, groups=2), (2, 16, 5, 5)),
+    ("LinearFlipout", dict(in_features=784, out_features=512), (256, 784)),
+    ("LinearFlipout", dict(in_features=512, out_features=10), (256, 512)),
+    ("LinearReparameterization", dict(in_features=128, out_features=64), (32, 128)),
+    ("LinearFlipout", dict(in_features=512, out_features=1000), (64, 512)),
+    # element-wise (GEN) kernels with in-kernel noise: odd channel counts
+    ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 32, 32)),
+    ("LinearFlipout", dict(in_features=50, out_features=10), (7, 50)),
+    ("Conv2dReparameterization", dict(in_channels=5, out_channels=7, kernel_size=3, padding=1), (2, 5, 9, 9)),
+]
+
+
+def _run_fused(cls, kw, xshape, prec, act, dev, sample=3, seed_init=11):
+    from bayesian_torch_amd import layers as L
+    import bayesian_torch_amd as bt
+    bt.manual_seed(2024)
+    torch.manual_seed(seed_init)
+    layer = getattr(L, cls)(**kw).to(dev)
+    layer.precision = prec
+    x = torch.randn(*xshape).to(dev)
+    if act == "bf16":
+        x = x.to(torch.bfloat16)
+    with torch.no_grad():
+        out = layer._forward_hip(x, sample_idx=sample)
+        nz = layer.materialize_noise(sample, tuple(x.shape), tuple(out.shape))
+    wn = "weight" if cls.startswith("Linear") else "kernel"
+    geo = case_geometry(dict(cls=cls, kwargs=kw))
+    args = dict(x=x.float().cpu().numpy(), mu_w=getattr(layer, "mu_" + wn).detach().cpu().numpy(),
+                rho_w=getattr(layer, "rho_" + wn).detach().cpu().numpy(),
+                mu_b=None if layer.mu_bias is None else layer.mu_bias.detach().cpu().numpy(),
+                rho_b=None if layer.rho_bias is None else layer.rho_bias.detach().cpu().numpy(),
+                eps_w=nz["eps_w"].cpu().numpy(), eps_b=nz["eps_b"].cpu().numpy() if "eps_b" in nz else None,
+                sign_in=nz["sign_in"].cpu().numpy() if "sign_in" in nz else None,
+                sign_out=nz["sign_out"].cpu().numpy() if "sign_out" in nz else None)
+    return layer, x, out, geo, args
+
+
+@pytest.mark.parametrize("prec,act", [("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16"), ("f32", "bf16")])
+def test_fused_noise_kernels_vs_oracle(prec, act):
+    """in-kernel Philox / sign hash: the oracle regenerates nothing itself here — it is fed the noise the RNG
+    kernels materialise (pinned to the CPU restatement in test_gpu_rng_kl.py) and must reproduce the output"""
+    dev = _dev()
+    worst = 0.0
+    for cls, kw, xshape in FUSED_CASES:
+        layer, x, out, geo, a = _run_fused(cls, kw, xshape, prec, act, dev)
+        o = out.float().cpu().numpy()
+        assert np.isfinite(o).all(), (cls, kw)
+        ref = oracle_forward(geo, a["x"], a["mu_w"], a["rho_w"], a["mu_b"], a["rho_b"], a["eps_w"], a["eps_b"],
+                             a["sign_in"], a["sign_out"], bf16=(prec == "bf16"))
+        if act == "bf16":  # the kernel rounds its f32 result to bf16 on store
+            ref = torch.from_numpy(ref).to(torch.bfloat16).float().numpy()
+            tol = 3e-3
+        else:
+            tol = TOL_F32 if prec == "f32" else TOL_BF16_ORACLE
+        err = rel_l2(o, ref)
+        worst = max(worst, err)
+        assert err < tol, (cls, kw, xshape, prec, act, err)
+        if prec == "bf16" and act == "f32":
+            ref32 = oracle_forward(geo, a["x"], a["mu_w"], a["rho_w"], a["mu_b"], a["rho_b"], a["eps_w"], a["eps_b"],
+                                   a["sign_in"], a["sign_out"], bf16=False)
+            assert rel_l2(o, ref32) < TOL_BF16_REF
+    print("worst rel-L2 (%s/%s): %.3g" % (prec, act, worst))
+
+
+def test_determinism_and_sample_dependence():
+    dev = _dev()
+    from bayesian_torch_amd import layers as L
+    torch.manual_seed(0)
+    layer = L.Conv2dFlipout(64, 64, 3, padding=1, bias=False).to(dev)
+    x = torch.randn(4, 64, 20, 20, device=dev)
+    with torch.no_grad():
+        a = layer._forward_hip(x, sample_idx=5)
+        b = layer._forward_hip(x, sample_idx=5)
+        c = layer._forward_hip(x, sample_idx=6)
+        y1, y2 = layer(x), layer(x)  # auto-incrementing sample counter
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c) and not torch.equal(y1[0], y2[0])
+    # homogeneity: every rounding commutes with a power-of-two scale -> bit-exact
+    with torch.no_grad():
+        d = layer._forward_hip(2.0 * x, sample_idx=5)
+    assert torch.equal(d, 2.0 * a)
+
+
+def test_memory_formats_and_views():
+    """NCHW-contiguous, channels_last and sliced inputs give the same result"""
+    dev = _dev()
+    from bayesian_torch_amd import layers as L
+    torch.manual_seed(0)
+    layer = L.Conv2dReparameterization(32, 32, 3, padding=1).to(dev)
+    x = torch.randn(2, 32, 9, 9, device=dev)
+    big = torch.randn(2, 40, 9, 9, device=dev)
+    big[:, 4:36] = x
+    with torch.no_grad():
+        a = layer._forward_hip(x, sample_idx=1)
+        b = layer._forward_hip(x.contiguous(memory_format=torch.channels_last), sample_idx=1)
+        c = layer._forward_hip(big[:, 4:36], sample_idx=1)
+    assert a.shape == (2, 32, 9, 9) and torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_full_size_resnet18_shapes_properties(prec):
+    """BASELINE sizes (bs 64): size-independent properties instead of the (slow) CPU oracle.
+    sigma -> 0 turns Flipout into the deterministic convolution: compare with torch's own f32 conv on the GPU;
+    plus determinism and exact homogeneity."""
+    dev = _dev()
+    from bayesian_torch_amd import layers as L
+    import torch.nn.functional as F
+    shapes = [(64, 64, 56, 1, 3), (64, 128, 56, 2, 3), (64, 128, 56, 2, 1), (128, 128, 28, 1, 3), (256, 256, 14, 1, 3),
+              (256, 512, 14, 2, 3), (512, 512, 7, 1, 3)]
+    for cin, cout, hw, stride, k in shapes:
+        torch.manual_seed(1)
+        layer = L.Conv2dFlipout(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(dev)
+        layer.precision = prec
+        x = torch.randn(64, cin, hw, hw, device=dev)
+        with torch.no_grad():
+            y = layer._forward_hip(x, sample_idx=0)
+            assert torch.equal(y, layer._forward_hip(x, sample_idx=0))
+            assert torch.equal(layer._forward_hip(4.0 * x, sample_idx=0), 4.0 * y)
+            layer.rho_kernel.data.fill_(-100.0)  # sigma = 3.7e-44 -> the perturbation vanishes
+            y0 = layer._forward_hip(x, sample_idx=0)
+            ref = F.conv2d(x, layer.mu_kernel, None, stride, k // 2)
+        err = float((y0 - ref).norm() / ref.norm())
+        assert err < (1e-5 if prec == "f32" else 6e-3), (cin, cout, hw, stride, k, prec, err)
+        assert float((y - y0).norm() / y0.norm()) > 1e-2  # and with sigma > 0 it really is perturbed

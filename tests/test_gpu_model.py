@@ -1,0 +1,125 @@
+"""GPU: whole converted models through the module API (dnn_to_bnn / get_kl_loss / MC driver)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore")
+
+PRIOR = dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, moped_enable=True,
+             moped_delta=0.5)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("typ", ["Reparameterization", "Flipout"])
+def test_resnet18_every_layer_matches_aten_with_same_noise(typ):
+    """hook every variational layer of dnn_to_bnn(resnet18): its HIP output vs the reference op chain evaluated by
+    torch (f32, on the GPU) with the noise BTX-RNG v1 defines for that (layer, sample)"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.resnet import resnet18
+    from oracle import bt_ref
+    dev = _dev()
+    bt.manual_seed(77)
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(PRIOR, type=typ))
+    m = m.to(dev).eval()
+    bt.assign_layer_ids(m)
+    bt.set_precision("f32")
+    x = torch.randn(2, 3, 224, 224, device=dev)
+    records = []
+
+    def hook(mod, inp, out):
+        records.append((mod, inp[0].detach(), out.detach()))
+    hs = [mod.register_forward_hook(hook) for mod in m.modules() if hasattr(mod, "kl_loss")]
+    sample = 4
+    with torch.no_grad():
+        bt.set_sample_index(m, sample)
+        logits = m(x)
+    for h in hs:
+        h.remove()
+    assert logits.shape == (2, 1000) and torch.isfinite(logits).all()
+    assert len(records) == 21
+    worst = 0.0
+    for mod, xin, out in records:
+        nz = mod.materialize_noise(sample, tuple(xin.shape), tuple(out.shape))
+        mu, rho = mod._w()
+        if mod._op.nd == 0:
+            op = dict(kind="linear")
+        else:
+            op = dict(kind="conv", nd=2, stride=mod._op.stride[1:], padding=mod._op.padding[1:],
+                      dilation=mod._op.dilation[1:], groups=mod._op.groups)
+        with torch.no_grad():
+            if typ == "Flipout":
+                ref = bt_ref.flipout_forward(xin, mu, rho, mod.mu_bias, mod.rho_bias, nz["eps_w"], nz.get("eps_b"),
+                                             nz["sign_in"].float(), nz["sign_out"].float(), op)
+            else:
+                ref = bt_ref.reparam_forward(xin, mu, rho, mod.mu_bias, mod.rho_bias, nz["eps_w"], nz.get("eps_b"), op)
+        err = float((out - ref).norm() / ref.norm())
+        worst = max(worst, err)
+        assert err < 1e-4, (mod.__class__.__name__, tuple(xin.shape), err)  # north_star output parity bar
+    print("resnet18 %s: worst per-layer rel-L2 %.3g" % (typ, worst))
+
+
+def test_mlp_config2_and_mc_driver():
+    """BASELINE config 2: LinearFlipout MLP 784-512-512-10, batch 256, 8 MC samples; packed statistics vs a manual
+    computation from the per-sample logits"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    dev = _dev()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(784, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                              torch.nn.Linear(512, 10))
+    bt.dnn_to_bnn(net, dict(PRIOR, type="Flipout", moped_enable=False))
+    net = net.to(dev).eval()
+    bt.assign_layer_ids(net)
+    torch.manual_seed(1234)
+    x = torch.randn(256, 784, device=dev)
+    S = 8
+    packed = mc.mc_forward(net, x, S, with_kl=True)
+    probs = []
+    with torch.no_grad():
+        for s in range(S):
+            bt.set_sample_index(net, s)
+            probs.append(torch.softmax(net(x).float(), 1))
+    P = torch.stack(probs)
+    u = mc.unpack(packed, 256, 10)
+    assert float(u["samples"]) == S
+    assert torch.allclose(u["mean_prob"], P.mean(0), atol=1e-5)
+    assert torch.allclose(u["var_prob"], P.var(0, unbiased=False), atol=1e-5)
+    ent = -(P * torch.log(P + 1e-15)).sum(-1).mean(0)
+    pe = -(P.mean(0) * torch.log(P.mean(0) + 1e-15)).sum(-1)
+    assert torch.allclose(u["mutual_information"], pe - ent, atol=1e-4)
+    assert abs(float(u["kl"]) - float(bt.get_kl_loss(net))) < 1e-4
+    assert P.std(0).mean() > 1e-4  # the samples really differ
+
+
+def test_bf16_throughput_mode_close_to_f32_mode():
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.resnet import resnet18
+    dev = _dev()
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(PRIOR, type="Flipout"))
+    m = m.to(dev).eval()
+    x = torch.randn(4, 3, 224, 224, device=dev)
+    outs = {}
+    for prec in ("f32", "bf16"):
+        bt.set_precision(prec)
+        with torch.no_grad():
+            bt.set_sample_index(m, 0)
+            outs[prec] = m(x).float()
+    bt.set_precision("f32")
+    err = float((outs["bf16"] - outs["f32"]).norm() / outs["f32"].norm())
+    assert err < 3e-2, err  # 21 stacked bf16-input layers
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""GPU diagnostics: (1) parity table of the fused kernels vs the CPU oracle over many shapes/modes (never stops at the
+first failure), (2) per-layer kernel time / TFLOP/s on the ResNet18 bs64 shapes with HIP events.
+
+usage: python tools/gpu_diag.py [parity] [perf] [--prec bf16,f32] [--iters 10]
+"""
+import argparse
+import os
+import sys
+import traceback
+import warnings
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parity():
+    from helpers import load_golden, case_geometry, oracle_forward, rel_l2
+    from test_gpu_contract import FUSED_CASES, _run_fused, _layer_from_meta, _noise_from
+    dev = torch.device("cuda:0")
+    g = load_golden()
+    print("== explicit-noise (reference goldens, GEN kernels) ==")
+    for prec in ("f32", "bf16"):
+        for name, (meta, d) in g["cases"].items():
+            try:
+                layer = _layer_from_meta(meta, dev)
+                layer.precision = prec
+                x = torch.from_numpy(d["x"]).to(dev)
+                with torch.no_grad():
+                    out = layer._forward_hip(x, noise=_noise_from(d, dev), sample_idx=0).float().cpu().numpy()
+                torch.cuda.synchronize()
+                print("  %-5s %-28s rel-L2 vs reference %.3e  %s" % (prec, name, rel_l2(out, d["out"]),
+                                                                     "" if np.isfinite(out).all() else "NON-FINITE"))
+            except Exception as e:  # noqa
+                print("  %-5s %-28s EXC %s" % (prec, name, repr(e)[:200]))
+    print("== fused-noise (in-kernel Philox / hash) vs oracle fed with materialised noise ==")
+    for prec, act in (("f32", "f32"), ("bf16", "f32"), ("bf16", "bf16")):
+        for cls, kw, xshape in FUSED_CASES:
+            try:
+                layer, x, out, geo, a = _run_fused(cls, kw, xshape, prec, act, dev)
+                torch.cuda.synchronize()
+                o = out.float().cpu().numpy()
+                ref = oracle_forward(geo, a["x"], a["mu_w"], a["rho_w"], a["mu_b"], a["rho_b"], a["eps_w"], a["eps_b"],
+                                     a["sign_in"], a["sign_out"], bf16=(prec == "bf16"))
+                # split the error: mean part only (set signs/eps irrelevant) is not separable here; print max-abs too
+                print("  %-4s/%-4s %-34s x%-18s rel-L2 %.3e  maxabs %.3e / %.3e" % (
+                    prec, act, cls, str(xshape), rel_l2(o, ref), np.abs(o - ref).max(), np.abs(ref).max()))
+            except Exception as e:  # noqa
+                print("  %-4s/%-4s %-34s x%-18s EXC %s" % (prec, act, cls, str(xshape), repr(e)[:300]))
+                traceback.print_exc(limit=2)
+
+
+RN18 = [  # (Cin, Cout, H, stride, k, count in ResNet18)
+    (3, 64, 224, 2, 7, 1), (64, 64, 56, 1, 3, 4), (64, 128, 56, 2, 3, 1), (64, 128, 56, 2, 1, 1), (128, 128, 28, 1, 3, 3),
+    (128, 256, 28, 2, 3, 1), (128, 256, 28, 2, 1, 1), (256, 256, 14, 1, 3, 3), (256, 512, 14, 2, 3, 1),
+    (256, 512, 14, 2, 1, 1), (512, 512, 7, 1, 3, 3)]
+
+
+def perf(precs, iters, bs=64):
+    from bayesian_torch_amd import layers as L
+    dev = torch.device("cuda:0")
+    peak = {"bf16": 2500.0, "f32": 157.3}
+    for typ in ("Flipout", "Reparameterization"):
+        for prec in precs:
+            act = torch.bfloat16 if prec == "bf16" else torch.float32
+            tot_ms, tot_fl = 0.0, 0.0
+            print("== %s prec=%s act=%s bs=%d ==" % (typ, prec, act, bs))
+            for cin, cout, hw, stride, k, cnt in RN18:
+                torch.manual_seed(0)
+                cls = getattr(L, "Conv2d" + typ)
+                layer = cls(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(dev)
+                layer.precision = prec
+                x = torch.randn(bs, cin, hw, hw, device=dev).to(act).contiguous(memory_format=torch.channels_last)
+                with torch.no_grad():
+                    for _ in range(2):
+                        y = layer._forward_hip(x, sample_idx=0)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for i in range(iters):
+                        y = layer._forward_hip(x, sample_idx=i)
+                    e1.record()
+                    torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / iters
+                ho = y.shape[2]
+                fl = 2.0 * bs * ho * ho * cout * cin * k * k * (2 if typ == "Flipout" else 1)
+                tf = fl / (ms * 1e-3) / 1e12
+                tot_ms += ms * cnt
+                tot_fl += fl * cnt
+                print("  cin%4d cout%4d hw%4d s%d k%d  x%d : %8.1f us  %7.1f TFLOP/s  (%4.1f%% of %s peak)" % (
+                    cin, cout, hw, stride, k, cnt, ms * 1e3, tf, 100 * tf / peak[prec], prec))
+            print("  ALL 20 convs: %.3f ms / MC sample, %.1f TFLOP/s = %.1f%% of peak" % (
+                tot_ms, tot_fl / (tot_ms * 1e-3) / 1e12, 100 * tot_fl / (tot_ms * 1e-3) / 1e12 / peak[prec]))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["parity", "perf"])
+    ap.add_argument("--prec", default="bf16,f32")
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    if "parity" in a.what:
+        parity()
+    if "perf" in a.what:
+        perf(a.prec.split(","), a.iters)

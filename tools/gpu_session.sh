@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box session: everything it learns lands in gpurun_out/ (merged back by gpurun).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+{ ls /root/reference 2>&1 | head -3; rocminfo | grep -m2 gfx; nproc; lscpu | grep -m1 "Model name"; free -g | head -2; } > gpurun_out/box.txt 2>&1
+for step in "$@"; do
+  case "$step" in
+    smoke)  timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" ;;
+    parity) timeout 1200 python tools/gpu_diag.py parity > gpurun_out/diag_parity.log 2>&1; echo "parity rc=$?" ;;
+    pytest) timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" ;;
+    pytest_all) timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" ;;
+    perf)   timeout 900 python tools/gpu_diag.py perf --iters 5 > gpurun_out/diag_perf.log 2>&1; echo "perf rc=$?" ;;
+    bench)  timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log ;;
+    bench_f32) timeout 900 python bench.py --steps 5 --warmup 1 --prec f32 --no-cpu-baseline > gpurun_out/bench_f32.log 2>&1; echo "bench_f32 rc=$?"; tail -1 gpurun_out/bench_f32.log ;;
+    prof)   cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$OLDPWD" ;;
+  esac
+done
+tail -5 gpurun_out/smoke.log 2>/dev/null
