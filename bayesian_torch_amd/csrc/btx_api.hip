@@ -4,8 +4,10 @@
 #include <math.h>
 #include <string.h>
 #include "../../include/btx.h"
+#include <stdlib.h>
 #include "btx_contract.h"
 #include "btx_rng.h"
+namespace btx { constexpr int DBM = 512; }  // pixels per tile of the LDS-DMA variant (btx_contract_dma.h)
 
 using namespace btx;
 
@@ -223,7 +225,7 @@ struct Plan {
   int Do, Ho, Wo, Cg, Ng, M, K, mtiles, ntiles, ksplits, kper, nwg;
 };
 
-static int make_plan(const BtxGeom* g, int prec, uint32_t flags, Plan* pl) {
+static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* pl) {
   int rc = btx_out_shape(g, flags, &pl->Do, &pl->Ho, &pl->Wo);
   if (rc) return rc;
   if (prec != BTX_PREC_F32 && prec != BTX_PREC_BF16) return BTX_E_DTYPE;
@@ -235,7 +237,7 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, Plan* pl) {
   pl->M = (int)M;
   pl->K = (int)K;
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
-  pl->mtiles = (pl->M + BM - 1) / BM;
+  pl->mtiles = (pl->M + bm - 1) / bm;
   pl->ntiles = (pl->Ng + BN - 1) / BN;
   const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
   const int stages = (pl->K + bk - 1) / bk;
@@ -255,11 +257,28 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, Plan* pl) {
   return 0;
 }
 
-size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, int prec, uint32_t flags) {
-  (void)kind; (void)act_dtype;
-  Plan pl;
-  if (!g || make_plan(g, prec, flags, &pl)) return 0;
+// Shape-level eligibility of the LDS-DMA pipeline (btx_contract_dma.h); pointer alignment is checked at launch.
+static bool dma_shape_ok(const BtxGeom* g, int act_dtype, int prec, const Plan& pl) {
+  if ((prec == BTX_PREC_BF16) != (act_dtype == BTX_ACT_BF16)) return false;  // DMA cannot convert
+  const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
+  if (pl.Cg % bk) return false;  // a K-stage must lie inside one filter tap
+  const long long in_elems = (long long)g->NB * g->D * g->H * g->W * g->C;
+  if (in_elems >= 0x7fffffffLL || (long long)pl.M * g->N >= 0x7fffffffLL || (long long)g->N * pl.K >= 0xffffffffLL)
+    return false;  // 32-bit element offsets
+  return true;
+}
+
+static size_t plan_ws(const Plan& pl, const BtxGeom* g) {
   return pl.ksplits > 1 ? (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
+}
+
+size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, int prec, uint32_t flags) {
+  (void)kind;
+  Plan a, b;
+  if (!g || make_plan(g, prec, flags, BM, &a) || make_plan(g, prec, flags, DBM, &b)) return 0;
+  const size_t wa = plan_ws(a, g), wb = plan_ws(b, g);  // which kernel runs also depends on pointer alignment
+  (void)act_dtype;
+  return wa > wb ? wa : wb;
 }
 
 int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
@@ -270,9 +289,25 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
   if (kind != BTX_KIND_REPARAM && kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
   if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
   Plan pl;
-  int rc = make_plan(g, prec, flags, &pl);
+  int rc = make_plan(g, prec, flags, BM, &pl);
   if (rc) return rc;
-  const size_t need = pl.ksplits > 1 ? (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
+
+  // fast (granule) paths need whole 16-byte granules everywhere; otherwise the element-wise gather path
+  const int G = (prec == BTX_PREC_BF16) ? 8 : 4;
+  const uintptr_t al = (uintptr_t)x | (uintptr_t)mu_w | (uintptr_t)rho_w | (uintptr_t)out |
+                       (uintptr_t)(noise && noise->eps_w ? noise->eps_w : nullptr) |
+                       (uintptr_t)(noise && noise->sign_in ? noise->sign_in : nullptr);
+  const bool explicit_kloop = noise && (noise->eps_w || noise->sign_in);  // parity mode runs the gather kernel
+  const bool gen = (pl.Cg % G != 0) || (al & 15) || explicit_kloop;
+  // LDS-DMA pipeline when the activations already have the contraction dtype (no conversion on the way to LDS);
+  // BTX_NO_DMA=1 forces the register-staged kernel (A/B measurements).
+  static const bool no_dma = getenv("BTX_NO_DMA") != nullptr;
+  const bool dma = !gen && !no_dma && dma_shape_ok(g, act_dtype, prec, pl);
+  if (dma) {
+    rc = make_plan(g, prec, flags, DBM, &pl);
+    if (rc) return rc;
+  }
+  const size_t need = plan_ws(pl, g);
   if (need && (!ws || ws_bytes < need)) return BTX_E_WORKSPACE;
   if (need && (((uintptr_t)ws) & 15)) return BTX_E_ALIGN;
 
@@ -297,17 +332,13 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
   sign_keys(rng, BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
   sign_keys(rng, BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
 
-  // fast (granule) path needs whole 16-byte granules everywhere; otherwise the element-wise gather path
-  const int G = (prec == BTX_PREC_BF16) ? 8 : 4;
-  const uintptr_t al = (uintptr_t)x | (uintptr_t)mu_w | (uintptr_t)rho_w | (uintptr_t)out |
-                       (uintptr_t)(noise && noise->eps_w ? noise->eps_w : nullptr) |
-                       (uintptr_t)(noise && noise->sign_in ? noise->sign_in : nullptr);
-  const bool explicit_kloop = noise && (noise->eps_w || noise->sign_in);  // parity mode runs the gather kernel
-  const bool gen = (pl.Cg % G != 0) || (al & 15) || explicit_kloop;
-
   hipStream_t st = (hipStream_t)stream;
-  rc = (prec == BTX_PREC_BF16) ? launch_contract_bf16(kind, act_dtype == BTX_ACT_BF16, gen, p, pl.nwg, st)
-                               : launch_contract_f32(kind, act_dtype == BTX_ACT_BF16, gen, p, pl.nwg, st);
+  if (dma)
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_dma_bf16(kind, p, pl.nwg, st)
+                                 : launch_contract_dma_f32(kind, p, pl.nwg, st);
+  else
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_bf16(kind, act_dtype == BTX_ACT_BF16, gen, p, pl.nwg, st)
+                                 : launch_contract_f32(kind, act_dtype == BTX_ACT_BF16, gen, p, pl.nwg, st);
   if (rc) return rc;
   if (pl.ksplits > 1) {
     const long long total = (long long)pl.M * g->N;

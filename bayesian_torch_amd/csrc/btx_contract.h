@@ -590,6 +590,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // launcher used by btx_api.hip; defined per precision in btx_contract_{f32,bf16}.hip
 int launch_contract_f32(int kind, int act_bf16, bool gen, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_bf16(int kind, int act_bf16, bool gen, const ContractParams& p, int nwg, hipStream_t st);
+// LDS-DMA pipeline variants (btx_contract_dma.h): activation dtype == contraction dtype, granule-aligned shapes
+int launch_contract_dma_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_dma_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
 
 template <int PREC>
 static int launch_contract_impl(int kind, int act_bf16, bool gen, const ContractParams& p, int nwg, hipStream_t st) {

@@ -1,7 +1,11 @@
 // Instantiates the bf16-MFMA (throughput mode) variants of the fused contraction: v_mfma_f32_32x32x16_bf16.
 #include "btx_contract.h"
+#include "btx_contract_dma.h"
 namespace btx {
 int launch_contract_bf16(int kind, int act_bf16, bool gen, const ContractParams& p, int nwg, hipStream_t st) {
   return launch_contract_impl<1>(kind, act_bf16, gen, p, nwg, st);
+}
+int launch_contract_dma_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st) {
+  return launch_contract_dma_impl<1>(kind, p, nwg, st);
 }
 }  // namespace btx

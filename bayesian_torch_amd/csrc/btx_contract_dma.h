@@ -1,0 +1,449 @@
+// btx_contract_dma.h — the LDS-DMA pipeline of the fused sample-and-contract kernel (gfx950): the hot variant.
+//
+// Same math, LDS fragment image and epilogue conventions as btx_contract.h::contract_kernel, but NOTHING is staged
+// through registers, which buys the big tile:
+//
+//   * workgroup tile 512 pixels x 64 channels, 8 waves, a wave owns 64 pixels x 64 channels (2x2 MFMA 32x32
+//     tiles; Flipout: 128 accumulator registers).  One sampled weight quad now serves 512 output rows — the
+//     sampling VALU per MFMA is half that of the 256-pixel register-staged tile;
+//   * a K-stage (32 bf16 / 16 f32 consecutive k) lies inside ONE filter tap (needs C/groups % stage == 0), so a
+//     thread = one pixel does ONE bounds check, ONE 32-bit offset add (per-pixel base + wave-uniform tap offset)
+//     and ONE sign hash per stage, then fires 4 x global_load_lds_dwordx4 (16-byte granules, lane = pixel; padding
+//     lanes read a zero page) into a 3-stage activation ring, two stages ahead;
+//   * the raw f32 (mu, rho) quads ride the same DMA path into a 2-stage ring; the wave that fetched quad row w
+//     reads it back, runs softplus + Philox/Box–Muller on the raw hardware transcendentals and writes the bf16/f32
+//     MFMA weight tile;
+//   * every VMEM op in the loop is an LDS-DMA, so hipcc inserts no vmcnt of its own: one counted
+//     `s_waitcnt vmcnt(N)` + lgkmcnt(0) + raw s_barrier per stage, never vmcnt(0) in steady state
+//     (cdna_hip_programming.md §5 "Pipelining across barriers").
+//
+// Ring bookkeeping, iteration s (stage s is being multiplied):
+//   issue   raw(s+2) -> raw slot s&1 (read by P(s) during iteration s-1), then acts/sign(s+2) -> slot (s+2)%3
+//           (read by M(s-1) during iteration s-1) — both reads are behind the barrier that ended iteration s-1
+//   M(s)    acts/sign slot s%3, weight tile s&1
+//   P(s+1)  raw slot (s+1)&1 (landed + visible since the barrier of iteration s-1), writes weight tile (s+1)&1
+//   end     vmcnt(4): everything older than this iteration's 4 activation DMAs has landed = raw(s+2), acts(s+1)
+#pragma once
+#include <type_traits>
+#include "btx_contract.h"
+
+namespace btx {
+
+constexpr int DBM = 512;                    // pixels per workgroup tile (DMA variant)
+constexpr int DMA_D = 3;                    // activation + sign ring depth
+constexpr int DA_STAGE = NG * DBM * 16;     // 32768
+constexpr int DS_STAGE = DBM * 4;           // 2048 : one sign word per (pixel, stage)
+constexpr int DR_STAGE = 16384;             // mu quads at +0, rho quads at +8192
+constexpr int DW_STAGE = 2 * NG * BN * 16;  // 8192 : mu tile at +0, delta tile at +4096
+constexpr int DA_OFF = 0;
+constexpr int DS_OFF = DA_OFF + DMA_D * DA_STAGE;     // 98304
+constexpr int DR_OFF = DS_OFF + DMA_D * DS_STAGE;     // 104448
+constexpr int DW_OFF = DR_OFF + 2 * DR_STAGE;         // 137216
+constexpr int DMA_LDS_BYTES = DW_OFF + 2 * DW_STAGE;  // 153600
+
+static __device__ __attribute__((aligned(16))) unsigned int btx_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+  // LDS destination = wave-uniform base + lane*16 ; the global source address is per lane
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int PREC, int KIND>
+__global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const ContractParams p) {
+  using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
+  constexpr int G = (PREC == 1) ? 8 : 4;
+  constexpr int BK = NG * G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool upper = wave >= 4;
+
+  int logical;
+  {
+    const int nwg = gridDim.x, L = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int inner = p.ntiles * p.groups * p.ksplits;
+  const int mtile = logical / inner;
+  int rem = logical - mtile * inner;
+  const int split = rem % p.ksplits;
+  rem /= p.ksplits;
+  const int ntile = rem % p.ntiles;
+  const int group = rem / p.ntiles;
+
+  const int k_begin = split * p.kper;
+  const int k_end = min(p.K, k_begin + p.kper);
+  const int nstages = (k_end - k_begin + BK - 1) / BK;
+
+  // ---- loader role: thread = pixel `tid` of the tile; all offsets are 32-bit (host guarantees < 2^31 elements)
+  const int m = mtile * DBM + tid;
+  const bool pix_valid = m < p.M;
+  int bd, bh, bw, nbase;
+  uint32_t base_off;  // element offset of (pixel, tap 0, channel 0 of the group), wrap-around arithmetic
+  {
+    const int mm = pix_valid ? m : 0;
+    const int ow = mm % p.Wo;
+    int t = mm / p.Wo;
+    const int oh = t % p.Ho;
+    t /= p.Ho;
+    const int od = t % p.Do;
+    const int nb = t / p.Do;
+    nbase = nb * p.D;
+    if (!p.transposed) {
+      bd = od * p.sd - p.pd; bh = oh * p.sh - p.ph; bw = ow * p.sw - p.pw;
+    } else {
+      bd = od + p.pd; bh = oh + p.ph; bw = ow + p.pw;
+    }
+    base_off = (uint32_t)(((nbase + bd) * p.H + bh) * p.W + bw) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+  }
+  const ACT* __restrict__ xptr = (const ACT*)p.x;
+
+  // wave-uniform K walk: channel offset inside the tap and the tap itself
+  int s_c, s_kd, s_kh, s_kw;
+  {
+    const int tap = k_begin / p.Cg;
+    s_c = k_begin - tap * p.Cg;
+    s_kw = tap % p.KW;
+    const int t2 = tap / p.KW;
+    s_kh = t2 % p.KH;
+    s_kd = t2 / p.KH;
+  }
+
+  // ---- sampling role: wave samples quad row `w_kquad` (4 consecutive k) of channel `lane`
+  const bool w_thread = (G == 8) || (wave < 4);
+  const int w_kquad = (G == 8) ? wave : (wave & 3);
+  const int w_col = ntile * BN + lane;
+  const bool w_colok = w_col < p.Ng;
+  const uint32_t w_rowbase = (uint32_t)(group * p.Ng + (w_colok ? w_col : 0)) * (uint32_t)p.K;
+
+  int a_slot_issue = 0;  // ring slot the next issue_stage() fills
+
+  // =================== issue: all HBM -> LDS traffic of one stage (called for stages 0,1,2,... in order) =====
+  auto issue_stage = [&](int st) {
+    const int kstage = k_begin + st * BK;  // uniform; kstage < k_end because st < nstages
+    {
+      unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
+      const int kk = kstage + 4 * w_kquad;
+      const bool ok = w_colok && (kk < k_end);
+      const uint32_t li = w_rowbase + (uint32_t)kk;
+      if constexpr (G == 8) {
+        dma16(ok ? (const void*)(p.mu + li) : (const void*)btx_zero16, rs + wave * 1024);
+        dma16(ok ? (const void*)(p.rho + li) : (const void*)btx_zero16, rs + 8192 + wave * 1024);
+      } else {
+        const float* base = (wave < 4) ? p.mu : p.rho;
+        dma16(ok ? (const void*)(base + li) : (const void*)btx_zero16, rs + (wave < 4 ? 0 : 8192) + w_kquad * 1024);
+      }
+    }
+    // activations: one tap for the whole stage
+    bool ok = pix_valid;
+    uint32_t off;
+    if (!p.transposed) {
+      const int id = bd + s_kd * p.dd, ih = bh + s_kh * p.dh, iw = bw + s_kw * p.dw;
+      ok = ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const uint32_t tap_off = (uint32_t)(((s_kd * p.dd) * p.H + s_kh * p.dh) * p.W + s_kw * p.dw) * (uint32_t)p.C +
+                               (uint32_t)s_c;  // wave-uniform
+      off = base_off + tap_off;
+    } else {
+      const int td = bd - s_kd * p.dd, th = bh - s_kh * p.dh, tw = bw - s_kw * p.dw;
+      const int id = td / p.sd, ih = th / p.sh, iw = tw / p.sw;
+      ok = ok && td >= 0 && th >= 0 && tw >= 0 && (id * p.sd == td) && (ih * p.sh == th) && (iw * p.sw == tw) &&
+           id < p.D && ih < p.H && iw < p.W;
+      off = (uint32_t)(((nbase + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + s_c);
+    }
+    unsigned char* as = smem + DA_OFF + a_slot_issue * DA_STAGE + wave * 1024;
+    const ACT* src = ok ? xptr + off : (const ACT*)btx_zero16;
+    const int step = ok ? G : 0;  // the zero page is one granule
+#pragma unroll
+    for (int j = 0; j < NG; ++j) dma16((const void*)(src + j * step), as + j * DBM * 16);
+    if constexpr (KIND == 1) {
+      // one hashed word covers the 32 (bf16) / 16 (f32) channels of this pixel's stage
+      uint32_t w = btx_sign_word(off >> 5, p.kin_a, p.kin_b);
+      if constexpr (G == 4) w <<= 8 * ((off >> 4) & 1);
+      *(uint32_t*)(smem + DS_OFF + a_slot_issue * DS_STAGE + tid * 4) = ok ? w : 0u;
+    }
+    // advance the K walk by one stage
+    s_c += BK;
+    if (s_c >= p.Cg) {
+      s_c = 0;
+      if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; ++s_kd; } }
+    }
+    a_slot_issue = (a_slot_issue == DMA_D - 1) ? 0 : a_slot_issue + 1;
+  };
+
+  // =================== P: raw (mu, rho) quad -> sampled MFMA weight tile ==================================
+  auto process_stage = [&](int st) {
+    if (w_thread) {
+      const unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
+      unsigned char* ws = smem + DW_OFF + (st & 1) * DW_STAGE;
+      const f32x4 mu4 = *(const f32x4*)(rs + (w_kquad * 64 + lane) * 16);
+      const f32x4 rho4 = *(const f32x4*)(rs + 8192 + (w_kquad * 64 + lane) * 16);
+      const int k0 = k_begin + st * BK + 4 * w_kquad;
+      const bool ok = w_colok && (k0 < k_end);
+      float eps[4];
+      btx_normal4_hw((w_rowbase + (uint32_t)k0) >> 2, p.sample, p.layer, 0u, p.seed_lo, p.seed_hi, eps);
+      float wm[4], wd[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sg = btx_softplus_hw(rho4[e]);
+        if constexpr (KIND == 0) {
+          wm[e] = ok ? __builtin_fmaf(sg, eps[e], mu4[e]) : 0.f;
+          wd[e] = 0.f;
+        } else {
+          wm[e] = ok ? mu4[e] : 0.f;
+          wd[e] = ok ? sg * eps[e] : 0.f;
+        }
+      }
+      if constexpr (PREC == 1) {
+        const int wo = ((wave >> 1) * BN + lane) * 16 + (wave & 1) * 8;
+        *(u32x2*)(ws + wo) = pack_quad_bf16(wm);
+        if constexpr (KIND == 1) *(u32x2*)(ws + NG * BN * 16 + wo) = pack_quad_bf16(wd);
+      } else {
+        const int wo = (w_kquad * BN + lane) * 16;
+        *(u32x4*)(ws + wo) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
+        if constexpr (KIND == 1)
+          *(u32x4*)(ws + NG * BN * 16 + wo) = (u32x4){f2u(wd[0]), f2u(wd[1]), f2u(wd[2]), f2u(wd[3])};
+      }
+    }
+  };
+
+  // =================== M: wave = pixels [64*wave, +64) x all 64 channels ===================================
+  f32x16 accm[2][2], accd[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
+
+  auto mma_stage = [&](int st, int a_slot) {
+    const unsigned char* as = smem + DA_OFF + a_slot * DA_STAGE;
+    const unsigned char* ss = smem + DS_OFF + a_slot * DS_STAGE;
+    const unsigned char* ws = smem + DW_OFF + (st & 1) * DW_STAGE;
+    uint32_t sw[2];
+    if constexpr (KIND == 1) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) sw[mi] = *(const uint32_t*)(ss + (wave * 64 + mi * 32 + l31) * 4);
+    }
+#pragma unroll
+    for (int kk = 0; kk < NG / 2; ++kk) {
+      // Register diet (the 128-accumulator Flipout tile leaves ~120 VGPRs for everything else): the two k-halves
+      // of the stage stay apart, and the delta weights are fetched only after the mu-MFMAs have been issued.
+      __builtin_amdgcn_sched_barrier(0);
+      const int row = 2 * kk + h;
+      u32x4 a[2], wq[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = *(const u32x4*)(as + (row * DBM + wave * 64 + mi * 32 + l31) * 16);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) wq[ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
+      if constexpr (PREC == 1) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, wq[ni]), __builtin_bit_cast(bf16x8, a[mi]), accm[mi][ni], 0, 0, 0);
+        if constexpr (KIND == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            wq[ni] = *(const u32x4*)(ws + NG * BN * 16 + (row * BN + ni * 32 + l31) * 16);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const uint32_t swr = sw[mi] << (4 * row);  // this granule row's 8 sign bits at bits 15-d / 31-d
+#pragma unroll
+            for (int d = 0; d < 4; ++d) a[mi][d] ^= ((swr << d) & 0x80008000u);
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, wq[ni]), __builtin_bit_cast(bf16x8, a[mi]), accd[mi][ni], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wq[ni][e]), u2f(a[mi][e]), accm[mi][ni], 0, 0, 0);
+        if constexpr (KIND == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            wq[ni] = *(const u32x4*)(ws + NG * BN * 16 + (row * BN + ni * 32 + l31) * 16);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const uint32_t swr = sw[mi] << (2 * row);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[mi][e] ^= ((swr << ((e >> 1) + ((e & 1) ? 0 : 16))) & 0x80000000u);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wq[ni][e]), u2f(a[mi][e]), accd[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // =================== main loop ==========================================================================
+  if (nstages > 0) {
+    const int pre = nstages < DMA_D - 1 ? nstages : DMA_D - 1;
+    for (int st = 0; st < pre; ++st) issue_stage(st);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    process_stage(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // Two complete instances of the loop, one per wave half, so that neither has control-flow merges inside
+    // (merges made hipcc shuffle the 128 accumulators between register ranges and spill; spill traffic is VMEM
+    // and drags a vmcnt(0) into the DMA pipeline).  Waves 0-3: [MFMA ; sample next], waves 4-7: [sample next ; MFMA]
+    // — the two waves sharing a SIMD keep its matrix pipe and its VALU busy at the same time.
+    auto run = [&](auto upper_tag) {
+      constexpr bool UPPER = decltype(upper_tag)::value;
+      int a_slot = 0;
+      for (int s = 0; s < nstages; ++s) {
+        const bool issued = s + DMA_D - 1 < nstages;
+        if (issued) issue_stage(s + DMA_D - 1);
+        const bool more = s + 1 < nstages;
+        if constexpr (!UPPER) {
+          mma_stage(s, a_slot);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) process_stage(s + 1);
+        } else {
+          if (more) process_stage(s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_stage(s, a_slot);
+        }
+        // this iteration issued [raw ..., acts x 4]; raw(s+2) and everything older must have landed
+        if (issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        a_slot = (a_slot == DMA_D - 1) ? 0 : a_slot + 1;
+      }
+    };
+    if (upper) run(std::true_type{}); else run(std::false_type{});
+  }
+
+  // =================== epilogue ===========================================================================
+  // lane owns pixel (lane&31) of each 32-pixel tile; register r = 4q+rr holds channel 32ni + 8q + 4h + rr.
+  const bool to_partial = p.ksplits > 1;
+  const bool has_bias = (split == 0) && (p.mu_b != nullptr);
+  float* bias_lds = (float*)smem;
+  if (has_bias) {
+    if (tid < BN) {
+      const int col = ntile * BN + tid;
+      float bm = 0.f, bdl = 0.f;
+      if (col < p.Ng) {
+        const int gcol = group * p.Ng + col;
+        const float eb = p.eps_b ? p.eps_b[gcol]
+                                 : btx_normal1((unsigned long long)gcol, p.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
+        const float sb_ = btx_softplus_fast(p.rho_b[gcol]);
+        if constexpr (KIND == 0) { bm = __builtin_fmaf(sb_, eb, p.mu_b[gcol]); }
+        else { bm = p.mu_b[gcol]; bdl = sb_ * eb; }
+      }
+      bias_lds[tid] = bm;
+      bias_lds[BN + tid] = bdl;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int mo = mtile * DBM + wave * 64 + mi * 32 + l31;
+    if (mo >= p.M) continue;
+    const uint32_t orow = (uint32_t)mo * (uint32_t)p.N + (uint32_t)(group * p.Ng);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int colbase = ntile * BN + ni * 32;
+      if (colbase >= p.Ng) continue;
+      const uint32_t o0 = orow + colbase;
+      const bool word_fast = (KIND == 1) && !p.sign_out && ((o0 & 31u) == 0) && (colbase + 32 <= p.Ng);
+      uint32_t wout = 0;
+      if (word_fast) wout = btx_sign_word(o0 >> 5, p.kout_a, p.kout_b);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cl = ni * 32 + 8 * q + 4 * h;
+        const int c0 = ntile * BN + cl;
+        if (c0 >= p.Ng) continue;
+        float v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int col = c0 + rr;
+          float val = accm[mi][ni][4 * q + rr];
+          if (has_bias) val += bias_lds[cl + rr];
+          if constexpr (KIND == 1) {
+            float dl = accd[mi][ni][4 * q + rr];
+            if (has_bias) dl += bias_lds[BN + cl + rr];
+            uint32_t flip = 0;
+            if (col < p.Ng) {
+              if (p.sign_out) {
+                flip = (p.sign_out[orow + col] < 0) ? 0x80000000u : 0u;
+              } else if (word_fast) {
+                const int bp = ((rr & 1) ? 31 : 15) - 4 * q - 2 * h - (rr >> 1);
+                flip = (wout << (31 - bp)) & 0x80000000u;
+              } else {
+                const uint32_t io = orow + col;
+                const uint32_t w1 = btx_sign_word(io >> 5, p.kout_a, p.kout_b);
+                flip = (w1 << (31 - btx_sign_bitpos(io & 31u))) & 0x80000000u;
+              }
+            }
+            val += u2f(f2u(dl) ^ flip);
+          }
+          v[rr] = val;
+        }
+        const bool vec = (c0 + 3 < p.Ng) && (((orow + c0) & 3) == 0);
+        if (to_partial) {
+          float* dst = p.partial + (size_t)split * p.M * p.N + orow + c0;
+          if (vec) {
+            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
+          }
+        } else {
+          ACT* dst = (ACT*)p.out + orow + c0;
+          if (vec) {
+            if constexpr (sizeof(ACT) == 4) {
+              *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+            } else {
+              f32x4 fv = {v[0], v[1], v[2], v[3]};
+              *(bf16x4*)dst = __builtin_convertvector(fv, bf16x4);
+            }
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = (ACT)v[rr];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int PREC>
+static int launch_contract_dma_impl(int kind, const ContractParams& p, int nwg, hipStream_t st) {
+#define BTX_LAUNCH_DMA(KIND)                                                                                        \
+  do {                                                                                                              \
+    auto kfn = contract_dma_kernel<PREC, KIND>;                                                                     \
+    static bool attr_done = false;                                                                                  \
+    if (!attr_done) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES); \
+      if (e != hipSuccess) return (int)e;                                                                           \
+      attr_done = true;                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(NTHREADS), DMA_LDS_BYTES, st, p);                                       \
+  } while (0)
+  if (kind == 0) BTX_LAUNCH_DMA(0); else BTX_LAUNCH_DMA(1);
+#undef BTX_LAUNCH_DMA
+  return (int)hipGetLastError();
+}
+
+}  // namespace btx

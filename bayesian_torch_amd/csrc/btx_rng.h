@@ -90,6 +90,35 @@ __device__ __forceinline__ float btx_normal1(uint64_t idx, uint32_t sample, uint
   return l == 0 ? z[0] : (l == 1 ? z[1] : (l == 2 ? z[2] : z[3]));
 }
 
+// Same noise / softplus on the RAW hardware transcendentals (v_exp_f32, v_log_f32, v_rcp_f32, v_sqrt_f32: ~1 ulp,
+// no denormal fix-up code, no IEEE division sequence): what the MFMA kernels use in their inner loop.  Results
+// differ from the functions above by a few ulp, far inside the parity tolerances (tests/test_gpu_contract.py).
+__device__ __forceinline__ void btx_box_muller_hw(uint32_t xa, uint32_t xb, float& za, float& zb) {
+  const float u1 = btx_u01(xa);
+  const float u2 = btx_u01(xb);
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+  za = r * __builtin_amdgcn_cosf(u2);
+  zb = r * __builtin_amdgcn_sinf(u2);
+}
+__device__ __forceinline__ void btx_normal4_hw(uint32_t blk, uint32_t sample, uint32_t layer, uint32_t stream,
+                                               uint32_t k0, uint32_t k1, float z[4]) {
+  const BtxPhilox4 p = btx_philox4x32_10(blk, sample, layer, stream, k0, k1);
+  btx_box_muller_hw(p.x[0], p.x[1], z[0], z[1]);
+  btx_box_muller_hw(p.x[2], p.x[3], z[2], z[3]);
+}
+// log1p(exp(rho)) = log(u) * e / (u - 1), u = 1 + e (e == u-1 exactly unless 1+e rounded: the ratio repairs it).
+// exp underflow (rho < -87) gives e = 0 -> 0; rho > 88.7 gives +inf like the reference's naive form.
+__device__ __forceinline__ float btx_softplus_hw(float rho) {
+  const float e = __builtin_amdgcn_exp2f(rho * 1.4426950408889634f);
+  const float u = 1.0f + e;
+  const float d = u - 1.0f;
+  const float lg = __builtin_amdgcn_logf(u) * 0.6931471805599453f;
+  float sp = lg * (e * __builtin_amdgcn_rcpf(d));
+  sp = (d == 0.0f) ? e : sp;
+  sp = (e > 3.0e38f) ? e : sp;
+  return sp;
+}
+
 // softplus exactly as the reference spells it, log1p(exp(rho)) (conv_variational.py:361), on the fast
 // transcendentals.  log1p via u=1+e: log(u)*e/(u-1) (exact-rounding-compensated); rho > 88.72 -> +inf as
 // the reference's naive form does.

@@ -84,22 +84,41 @@ def pack_gemm_major(w, op):
     return t.permute(0, 2, 3, 1).contiguous()  # [g, Ng, T, Cg]
 
 
-class PackedParams:
-    """Caches the GEMM-major copies of (mu, rho) and re-packs only when a parameter changed
-    (in-place update bumps `_version`; `.data = ...` changes `data_ptr`)."""
+def gemm_major_param(shape, op):
+    """Allocate a parameter whose STORAGE is the kernel's [N][tap][Cg] layout and return the logical view the
+    reference exposes ([out,in] / [Cout,Cin/g,*k] / [Cin,Cout/g,*k]).  The HIP path then reads the parameter in
+    place — no packed copy that could go stale when user code mutates `param.data` (which does not bump
+    `_version`).  ConvTranspose with groups > 1 has no strided logical view and stays contiguous (re-packed on
+    every forward)."""
+    nd = op.nd
+    if nd == 0:
+        return torch.empty(shape)
+    k = tuple(shape[2:])
+    if not op.transposed:
+        phys = torch.empty((shape[0],) + k + (shape[1],))
+        return phys.permute((0, nd + 1) + tuple(range(1, nd + 1)))
+    if op.groups == 1:
+        phys = torch.empty((shape[1],) + k + (shape[0],))  # [Cout][*k][Cin]
+        return phys.permute((nd + 1, 0) + tuple(range(1, nd + 1)))
+    return torch.empty(shape)
 
-    def __init__(self):
-        self._key = None
-        self._mu = self._rho = None
 
-    def get(self, mu, rho, op):
-        key = (mu.data_ptr(), mu._version, rho.data_ptr(), rho._version, mu.device)
-        if key != self._key:
-            with torch.no_grad():
-                self._mu = pack_gemm_major(mu.detach().float(), op)
-                self._rho = pack_gemm_major(rho.detach().float(), op)
-            self._key = key
-        return self._mu, self._rho
+def gemm_major_view(w, op):
+    """The [N][tap][Cg]-ordered tensor of a parameter: a zero-copy view when the parameter is stored GEMM-major
+    (the default, see gemm_major_param), else a packed copy made now."""
+    nd = op.nd
+    w = w.detach()
+    if w.dtype != torch.float32:
+        raise _lib.BtxError("variational parameters must be float32 (got %s)" % w.dtype)
+    if nd == 0:
+        return w if w.is_contiguous() else w.contiguous()
+    if not op.transposed:
+        v = w.permute((0,) + tuple(range(2, 2 + nd)) + (1,))
+        return v if v.is_contiguous() else v.contiguous()
+    if op.groups == 1:
+        v = w.permute((1,) + tuple(range(2, 2 + nd)) + (0,))
+        return v if v.is_contiguous() else v.contiguous()
+    return pack_gemm_major(w, op)
 
 
 _WS = {}
@@ -307,6 +326,12 @@ def contract_aten(x, w, b, op):
     if op.transposed:
         return _CONVT[nd](x, w, b, st, pd, opd, op.groups, dl)
     return _CONV[nd](x, w, b, st, pd, dl, op.groups)
+
+
+def plain_layout(t):
+    """row-major copy with DEFAULT strides (`.contiguous()` is not enough: a [Cout,Cin,1,1] view with
+    channels-last-looking strides already counts as contiguous and would steer ATen's conv to channels_last)."""
+    return t.clone(memory_format=torch.contiguous_format)
 
 
 def softplus_naive(rho):

@@ -91,8 +91,9 @@ class _VariationalNd(BaseVariationalLayer_):
         self._op = BF.OpDesc(nd, in_ch, out_ch, ksz if nd else 1, stride if nd else 1, padding if nd else 0,
                              dilation if nd else 1, groups if nd else 1, self._transposed,
                              output_padding if (nd and self._transposed) else 0)
-        setattr(self, "mu_" + wn, Parameter(torch.Tensor(*wshape)))
-        setattr(self, "rho_" + wn, Parameter(torch.Tensor(*wshape)))
+        # storage is GEMM-major (what the MFMA kernel streams); the logical shape/values are the reference's
+        setattr(self, "mu_" + wn, Parameter(BF.gemm_major_param(wshape, self._op)))
+        setattr(self, "rho_" + wn, Parameter(BF.gemm_major_param(wshape, self._op)))
         self.register_buffer("eps_" + wn, torch.Tensor(*wshape), persistent=False)
         self.register_buffer("prior_weight_mu", torch.Tensor(*wshape), persistent=False)
         self.register_buffer("prior_weight_sigma", torch.Tensor(*wshape), persistent=False)
@@ -111,8 +112,6 @@ class _VariationalNd(BaseVariationalLayer_):
         # MI355X-side state (not part of the reference surface)
         self._btx_layer_id = _rng.next_layer_id()
         self._btx_sample = 0
-        self._btx_packed = BF.PackedParams()
-        self._btx_kl_cache = (None, None)
         self.precision = None  # None -> functional.get_precision(); or "f32" / "bf16"
         self.init_parameters()
         self._btx_prior_versions = self._prior_versions()
@@ -133,8 +132,9 @@ class _VariationalNd(BaseVariationalLayer_):
         mu0, rho0 = self._mu_rho_init()
         self.prior_weight_mu.fill_(self.prior_mean)
         self.prior_weight_sigma.fill_(self.prior_variance)
-        mu.data.normal_(mean=mu0, std=0.1)
-        rho.data.normal_(mean=rho0, std=0.1)
+        # draw into a contiguous tensor (the reference's generator order), then copy into the strided storage
+        mu.data.copy_(torch.empty(mu.shape).normal_(mean=mu0, std=0.1))
+        rho.data.copy_(torch.empty(rho.shape).normal_(mean=rho0, std=0.1))
         if self.mu_bias is not None:
             self.prior_bias_mu.fill_(self.prior_mean)
             self.prior_bias_sigma.fill_(self.prior_variance)
@@ -170,25 +170,26 @@ class _VariationalNd(BaseVariationalLayer_):
     def kl_loss(self):
         mu, rho = self._w()
         if not self._use_hip(mu):
+            mu, rho = BF.plain_layout(mu), BF.plain_layout(rho)
             kl = self.kl_div(mu, BF.softplus_naive(rho), self.prior_weight_mu, self.prior_weight_sigma)
             if self.mu_bias is not None:
                 kl = kl + self.kl_div(self.mu_bias, BF.softplus_naive(self.rho_bias), self.prior_bias_mu,
                                       self.prior_bias_sigma)
             return kl
-        key = (mu.data_ptr(), mu._version, rho.data_ptr(), rho._version, self._prior_versions(),
-               None if self.mu_bias is None else (self.mu_bias.data_ptr(), self.mu_bias._version,
-                                                  self.rho_bias.data_ptr(), self.rho_bias._version))
-        if self._btx_kl_cache[0] != key:
-            # priors are scalars unless someone (utils.util.MOPED) overwrote the full-shape buffers
-            tens = self._prior_versions() != self._btx_prior_versions
-            kl = BF.kl_hip(mu, rho, self.prior_mean, self.prior_variance,
-                           self.prior_weight_mu if tens else None, self.prior_weight_sigma if tens else None)
-            if self.mu_bias is not None:
-                BF.kl_hip(self.mu_bias, self.rho_bias, self.prior_mean, self.prior_variance,
-                          self.prior_bias_mu if tens else None, self.prior_bias_sigma if tens else None,
-                          out=kl, accumulate=True)
-            self._btx_kl_cache = (key, kl)
-        return self._btx_kl_cache[1].clone()  # callers (get_kl_loss) += into the returned tensor
+        # RNG-free and cheap (8 B/element, two launches per tensor): recomputed on every call rather than cached —
+        # `param.data` mutations do not bump `_version`, so no cache key is trustworthy.
+        tens = self._prior_versions() != self._btx_prior_versions  # MOPED-style full-shape priors
+        if tens:  # element order must match the logical prior tensors
+            kl = BF.kl_hip(mu.contiguous(), rho.contiguous(), self.prior_mean, self.prior_variance,
+                           self.prior_weight_mu, self.prior_weight_sigma)
+        else:     # a mean over elements: storage order is irrelevant
+            kl = BF.kl_hip(BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op), self.prior_mean,
+                           self.prior_variance)
+        if self.mu_bias is not None:
+            BF.kl_hip(self.mu_bias, self.rho_bias, self.prior_mean, self.prior_variance,
+                      self.prior_bias_mu if tens else None, self.prior_bias_sigma if tens else None,
+                      out=kl, accumulate=True)
+        return kl
 
     def forward(self, input, return_kl=True):
         if self.dnn_to_bnn_flag:
@@ -203,7 +204,7 @@ class _VariationalNd(BaseVariationalLayer_):
     # ---- MI355X path -----------------------------------------------------------------------------------------
     def _forward_hip(self, x, noise=None, sample_idx=None):
         mu, rho = self._w()
-        mu_p, rho_p = self._btx_packed.get(mu, rho, self._op)
+        mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
         if sample_idx is None:
             sample_idx = self._btx_sample
             self._btx_sample += 1
@@ -247,6 +248,9 @@ class _VariationalNd(BaseVariationalLayer_):
     # ---- ATen path (CPU tensors / autograd) -------------------------------------------------------------------
     def _forward_aten(self, x, return_kl):
         mu, rho = self._w()
+        # the parameters are stored GEMM-major (strided); ATen must see the reference's plain layout or conv picks
+        # channels_last outputs and the in-place uniform_() draws land on different logical elements
+        mu, rho = BF.plain_layout(mu), BF.plain_layout(rho)
         op = self._op
         eps_w_buf = getattr(self, "eps_" + self._wn)
         has_b = self.mu_bias is not None

@@ -71,6 +71,9 @@ FUSED_CASES = [
     ("Conv2dFlipout", dict(in_channels=32, out_channels=48, kernel_size=3, padding=2, dilation=2, groups=2), (2, 32, 9, 11)),
     ("Conv2dFlipout", dict(in_channels=256, out_channels=64, kernel_size=3, padding=1, bias=False), (2, 256, 7, 7)),  # split-K
     ("Conv2dFlipout", dict(in_channels=24, out_channels=40, kernel_size=3, padding=1), (1, 24, 20, 20)),  # C%32 != 0
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=96, kernel_size=3, padding=1, groups=2), (3, 64, 17, 19)),  # DMA + groups
+    ("Conv2dFlipout", dict(in_channels=128, out_channels=64, kernel_size=3, stride=2, padding=1), (5, 128, 23, 21)),  # DMA, M tail
+    ("Conv3dReparameterization", dict(in_channels=32, out_channels=32, kernel_size=3, prior_mean=0, prior_variance=1, posterior_mu_init=0, posterior_rho_init=-3.0, padding=1), (1, 32, 6, 7, 8)),
     ("Conv2dReparameterization", dict(in_channels=64, out_channels=96, kernel_size=3, stride=1, padding=1), (2, 64, 12, 12)),
     ("Conv2dReparameterization", dict(in_channels=128, out_channels=32, kernel_size=5, stride=2, padding=2, bias=False), (1, 128, 17, 17)),
     ("Conv1dFlipout", dict(in_channels=16, out_channels=32, kernel_size=5, stride=2, padding=2), (3, 16, 301)),
