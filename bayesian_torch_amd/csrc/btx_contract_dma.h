@@ -6,10 +6,13 @@
 //   * workgroup tile 512 pixels x 64 channels, 8 waves, a wave owns 64 pixels x 64 channels (2x2 MFMA 32x32
 //     tiles; Flipout: 128 accumulator registers).  One sampled weight quad now serves 512 output rows — the
 //     sampling VALU per MFMA is half that of the 256-pixel register-staged tile;
-//   * a K-stage (32 bf16 / 16 f32 consecutive k) lies inside ONE filter tap (needs C/groups % stage == 0), so a
-//     thread = one pixel does ONE bounds check, ONE 32-bit offset add (per-pixel base + wave-uniform tap offset)
-//     and ONE sign hash per stage, then fires 4 x global_load_lds_dwordx4 (16-byte granules, lane = pixel; padding
-//     lanes read a zero page) into a 3-stage activation ring, two stages ahead;
+//   * a K-stage (32 bf16 / 16 f32 consecutive k = 64 bytes of one pixel) lies inside ONE filter tap (needs
+//     C/groups % stage == 0).  One global_load_lds_dwordx4 moves 16 pixels x 64 B: the four 16-byte granules of a
+//     pixel sit in ADJACENT LANES of one instruction (measured on MI355X, tools/ubench/dma_pattern.hip: 0.90
+//     cycles per 16-B request per CU, vs 1.84 when the same bytes are split over four instructions and 4.9 for one
+//     granule per cache line).  The LDS image is pixel-major with an XOR swizzle, slot = granule ^ ((pixel>>2)&3),
+//     applied on the SOURCE side (the DMA destination is lane-linear), which makes every 16-lane group of the MFMA
+//     fragment reads (16 pixels, one granule) hit 16 distinct 16-byte bank slots;
 //   * the raw f32 (mu, rho) quads ride the same DMA path into a 2-stage ring; the wave that fetched quad row w
 //     reads it back, runs softplus + Philox/Box–Muller on the raw hardware transcendentals and writes the bf16/f32
 //     MFMA weight tile;
@@ -81,26 +84,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   const int k_end = min(p.K, k_begin + p.kper);
   const int nstages = (k_end - k_begin + BK - 1) / BK;
 
-  // ---- loader role: thread = pixel `tid` of the tile; all offsets are 32-bit (host guarantees < 2^31 elements)
-  const int m = mtile * DBM + tid;
-  const bool pix_valid = m < p.M;
-  int bd, bh, bw, nbase;
-  uint32_t base_off;  // element offset of (pixel, tap 0, channel 0 of the group), wrap-around arithmetic
-  {
-    const int mm = pix_valid ? m : 0;
-    const int ow = mm % p.Wo;
-    int t = mm / p.Wo;
+  // ---- loader role.  DMA instruction q (0..3) of wave w moves pixels 64w + 16q + (lane>>2), granule slot lane&3;
+  //      each lane therefore keeps the geometry of FOUR pixels.  All offsets are 32-bit (host guarantees < 2^31
+  //      elements); base_off = element offset of (pixel, tap 0, channel 0 of the group), wrap-around arithmetic.
+  const int g_lane = (lane & 3) ^ ((lane >> 4) & 3);  // granule this lane fetches (source-side swizzle)
+  int pb_d[4], pb_h[4], pb_w[4], pb_n[4];
+  uint32_t pb_off[4];
+  bool pb_ok[4];
+  auto decode = [&](int mm_, int& bd_, int& bh_, int& bw_, int& nbase_, uint32_t& off_) {
+    const int ow = mm_ % p.Wo;
+    int t = mm_ / p.Wo;
     const int oh = t % p.Ho;
     t /= p.Ho;
     const int od = t % p.Do;
     const int nb = t / p.Do;
-    nbase = nb * p.D;
+    nbase_ = nb * p.D;
     if (!p.transposed) {
-      bd = od * p.sd - p.pd; bh = oh * p.sh - p.ph; bw = ow * p.sw - p.pw;
+      bd_ = od * p.sd - p.pd; bh_ = oh * p.sh - p.ph; bw_ = ow * p.sw - p.pw;
     } else {
-      bd = od + p.pd; bh = oh + p.ph; bw = ow + p.pw;
+      bd_ = od + p.pd; bh_ = oh + p.ph; bw_ = ow + p.pw;
     }
-    base_off = (uint32_t)(((nbase + bd) * p.H + bh) * p.W + bw) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+    off_ = (uint32_t)(((nbase_ + bd_) * p.H + bh_) * p.W + bw_) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mq = mtile * DBM + wave * 64 + q * 16 + (lane >> 2);
+    pb_ok[q] = mq < p.M;
+    decode(pb_ok[q] ? mq : 0, pb_d[q], pb_h[q], pb_w[q], pb_n[q], pb_off[q]);
+  }
+  uint32_t sg_off;  // this thread's own pixel (tid): only the sign word needs it
+  {
+    const int m = mtile * DBM + tid;
+    int a_, b_, c_, d_;
+    decode(m < p.M ? m : 0, a_, b_, c_, d_, sg_off);
   }
   const ACT* __restrict__ xptr = (const ACT*)p.x;
 
@@ -115,10 +131,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     s_kd = t2 / p.KH;
   }
 
-  // ---- sampling role: wave samples quad row `w_kquad` (4 consecutive k) of channel `lane`
+  // ---- weight roles.  Raw (mu, rho) stage image in LDS: [channel][QPS quads][16 B] (QPS = BK/4), i.e. one
+  //      128-B (bf16) / 64-B (f32) run per channel = whole cache lines per DMA lane group.
+  //      bf16: wave w DMAs channels [8w, 8w+8) of mu and of rho (2 instructions), thread t samples (ch t>>3, quad t&7)
+  //      f32 : waves 0-3 DMA mu channels [16w, 16w+16), waves 4-7 the same of rho; threads 0..255 sample (t>>2, t&3)
+  constexpr int QPS = BK / 4;
   const bool w_thread = (G == 8) || (wave < 4);
-  const int w_kquad = (G == 8) ? wave : (wave & 3);
-  const int w_col = ntile * BN + lane;
+  const int w_ch = (G == 8) ? (tid >> 3) : ((tid & 255) >> 2);      // channel within the n-tile (DMA + sampling)
+  const int w_quad = (G == 8) ? (tid & 7) : (tid & 3);
+  const int w_col = ntile * BN + w_ch;
   const bool w_colok = w_col < p.Ng;
   const uint32_t w_rowbase = (uint32_t)(group * p.Ng + (w_colok ? w_col : 0)) * (uint32_t)p.K;
 
@@ -129,7 +150,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     const int kstage = k_begin + st * BK;  // uniform; kstage < k_end because st < nstages
     {
       unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
-      const int kk = kstage + 4 * w_kquad;
+      const int kk = kstage + 4 * w_quad;
       const bool ok = w_colok && (kk < k_end);
       const uint32_t li = w_rowbase + (uint32_t)kk;
       if constexpr (G == 8) {
@@ -137,35 +158,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
         dma16(ok ? (const void*)(p.rho + li) : (const void*)btx_zero16, rs + 8192 + wave * 1024);
       } else {
         const float* base = (wave < 4) ? p.mu : p.rho;
-        dma16(ok ? (const void*)(base + li) : (const void*)btx_zero16, rs + (wave < 4 ? 0 : 8192) + w_kquad * 1024);
+        dma16(ok ? (const void*)(base + li) : (const void*)btx_zero16, rs + (wave < 4 ? 0 : 8192) + (wave & 3) * 1024);
       }
     }
-    // activations: one tap for the whole stage
-    bool ok = pix_valid;
-    uint32_t off;
-    if (!p.transposed) {
-      const int id = bd + s_kd * p.dd, ih = bh + s_kh * p.dh, iw = bw + s_kw * p.dw;
-      ok = ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const uint32_t tap_off = (uint32_t)(((s_kd * p.dd) * p.H + s_kh * p.dh) * p.W + s_kw * p.dw) * (uint32_t)p.C +
-                               (uint32_t)s_c;  // wave-uniform
-      off = base_off + tap_off;
-    } else {
-      const int td = bd - s_kd * p.dd, th = bh - s_kh * p.dh, tw = bw - s_kw * p.dw;
-      const int id = td / p.sd, ih = th / p.sh, iw = tw / p.sw;
-      ok = ok && td >= 0 && th >= 0 && tw >= 0 && (id * p.sd == td) && (ih * p.sh == th) && (iw * p.sw == tw) &&
-           id < p.D && ih < p.H && iw < p.W;
-      off = (uint32_t)(((nbase + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + s_c);
-    }
-    unsigned char* as = smem + DA_OFF + a_slot_issue * DA_STAGE + wave * 1024;
-    const ACT* src = ok ? xptr + off : (const ACT*)btx_zero16;
-    const int step = ok ? G : 0;  // the zero page is one granule
+    // activations: one tap for the whole stage; tap_off is wave-uniform
+    uint32_t tap_off = 0;
+    if (!p.transposed)
+      tap_off = (uint32_t)(((s_kd * p.dd) * p.H + s_kh * p.dh) * p.W + s_kw * p.dw) * (uint32_t)p.C + (uint32_t)s_c;
+    unsigned char* as = smem + DA_OFF + a_slot_issue * DA_STAGE + wave * 4096;
 #pragma unroll
-    for (int j = 0; j < NG; ++j) dma16((const void*)(src + j * step), as + j * DBM * 16);
+    for (int q = 0; q < 4; ++q) {
+      bool ok = pb_ok[q];
+      uint32_t off;
+      if (!p.transposed) {
+        const int id = pb_d[q] + s_kd * p.dd, ih = pb_h[q] + s_kh * p.dh, iw = pb_w[q] + s_kw * p.dw;
+        ok = ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        off = pb_off[q] + tap_off;
+      } else {
+        const int td = pb_d[q] - s_kd * p.dd, th = pb_h[q] - s_kh * p.dh, tw = pb_w[q] - s_kw * p.dw;
+        const int id = td / p.sd, ih = th / p.sh, iw = tw / p.sw;
+        ok = ok && td >= 0 && th >= 0 && tw >= 0 && (id * p.sd == td) && (ih * p.sh == th) && (iw * p.sw == tw) &&
+             id < p.D && ih < p.H && iw < p.W;
+        off = (uint32_t)(((pb_n[q] + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + s_c);
+      }
+      dma16(ok ? (const void*)(xptr + off + G * g_lane) : (const void*)btx_zero16, as + q * 1024);
+    }
     if constexpr (KIND == 1) {
-      // one hashed word covers the 32 (bf16) / 16 (f32) channels of this pixel's stage
+      // one hashed word covers the 32 (bf16) / 16 (f32) channels of pixel `tid`'s stage.  (In the padding the
+      // activations are zero, so the word is irrelevant there.  Transposed: recompute the input offset.)
+      uint32_t off = sg_off + tap_off;
+      if (p.transposed) {
+        const int m = mtile * DBM + tid;
+        int bd_, bh_, bw_, nb_;
+        uint32_t o_;
+        decode(m < p.M ? m : 0, bd_, bh_, bw_, nb_, o_);
+        const int id = (bd_ - s_kd * p.dd) / p.sd, ih = (bh_ - s_kh * p.dh) / p.sh, iw = (bw_ - s_kw * p.dw) / p.sw;
+        off = (uint32_t)(((nb_ + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + s_c);
+      }
       uint32_t w = btx_sign_word(off >> 5, p.kin_a, p.kin_b);
       if constexpr (G == 4) w <<= 8 * ((off >> 4) & 1);
-      *(uint32_t*)(smem + DS_OFF + a_slot_issue * DS_STAGE + tid * 4) = ok ? w : 0u;
+      *(uint32_t*)(smem + DS_OFF + a_slot_issue * DS_STAGE + tid * 4) = w;
     }
     // advance the K walk by one stage
     s_c += BK;
@@ -181,9 +213,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     if (w_thread) {
       const unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
       unsigned char* ws = smem + DW_OFF + (st & 1) * DW_STAGE;
-      const f32x4 mu4 = *(const f32x4*)(rs + (w_kquad * 64 + lane) * 16);
-      const f32x4 rho4 = *(const f32x4*)(rs + 8192 + (w_kquad * 64 + lane) * 16);
-      const int k0 = k_begin + st * BK + 4 * w_kquad;
+      const int ro = (w_ch * QPS + w_quad) * 16;  // == (tid & (G == 8 ? 511 : 255)) * 16: a linear, conflict-free read
+      const f32x4 mu4 = *(const f32x4*)(rs + ro);
+      const f32x4 rho4 = *(const f32x4*)(rs + 8192 + ro);
+      const int k0 = k_begin + st * BK + 4 * w_quad;
       const bool ok = w_colok && (k0 < k_end);
       float eps[4];
       btx_normal4_hw((w_rowbase + (uint32_t)k0) >> 2, p.sample, p.layer, 0u, p.seed_lo, p.seed_hi, eps);
@@ -199,12 +232,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
           wd[e] = ok ? sg * eps[e] : 0.f;
         }
       }
+      // MFMA weight tile [granule row][channel][16 B]
       if constexpr (PREC == 1) {
-        const int wo = ((wave >> 1) * BN + lane) * 16 + (wave & 1) * 8;
+        const int wo = ((w_quad >> 1) * BN + w_ch) * 16 + (w_quad & 1) * 8;
         *(u32x2*)(ws + wo) = pack_quad_bf16(wm);
         if constexpr (KIND == 1) *(u32x2*)(ws + NG * BN * 16 + wo) = pack_quad_bf16(wd);
       } else {
-        const int wo = (w_kquad * BN + lane) * 16;
+        const int wo = (w_quad * BN + w_ch) * 16;
         *(u32x4*)(ws + wo) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
         if constexpr (KIND == 1)
           *(u32x4*)(ws + NG * BN * 16 + wo) = (u32x4){f2u(wd[0]), f2u(wd[1]), f2u(wd[2]), f2u(wd[3])};
@@ -238,7 +272,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
       const int row = 2 * kk + h;
       u32x4 a[2], wq[2];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = *(const u32x4*)(as + (row * DBM + wave * 64 + mi * 32 + l31) * 16);
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi] = *(const u32x4*)(as + (wave * 64 + mi * 32 + l31) * 64 + ((row ^ ((l31 >> 2) & 3)) * 16));
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) wq[ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
       if constexpr (PREC == 1) {
