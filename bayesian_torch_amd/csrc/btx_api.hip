@@ -241,12 +241,18 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* p
   pl->ntiles = (pl->Ng + BN - 1) / BN;
   const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
   const int stages = (pl->K + bk - 1) / bk;
+  // split-K: pick the split that minimises (grid rounds on 256 CUs) x (stages per block + fixed per-block cost);
+  // each split keeps >= 4 stages so the DMA ring fills.
   int ks = 1;
-  if (base < 192) {
-    ks = (int)((256 + base - 1) / base);
-    const int max_ks = stages / 4 > 1 ? stages / 4 : 1;  // keep >= 4 stages per split
-    if (ks > max_ks) ks = max_ks;
-    if (ks > 32) ks = 32;
+  {
+    const long long ncu = 256;
+    long long best = -1;
+    const int max_ks = stages / 4 > 1 ? (stages / 4 < 32 ? stages / 4 : 32) : 1;
+    for (int c = 1; c <= max_ks; ++c) {
+      const long long rounds = (base * c + ncu - 1) / ncu;
+      const long long cost = rounds * ((stages + c - 1) / c + 4) + (c > 1 ? 1 : 0);  // +1: the reduce pass
+      if (best < 0 || cost < best) { best = cost; ks = c; }
+    }
   }
   int per_stages = (stages + ks - 1) / ks;
   pl->kper = per_stages * bk;

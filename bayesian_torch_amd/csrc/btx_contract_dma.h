@@ -143,10 +143,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   const bool w_colok = w_col < p.Ng;
   const uint32_t w_rowbase = (uint32_t)(group * p.Ng + (w_colok ? w_col : 0)) * (uint32_t)p.K;
 
-  int a_slot_issue = 0;  // ring slot the next issue_stage() fills
+  int a_slot_issue = 0;  // ring slot the next issue_acts() fills
 
   // =================== issue: all HBM -> LDS traffic of one stage (called for stages 0,1,2,... in order) =====
-  auto issue_stage = [&](int st) {
+  auto issue_raw = [&](int st) {
     const int kstage = k_begin + st * BK;  // uniform; kstage < k_end because st < nstages
     {
       unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
@@ -161,6 +161,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
         dma16(ok ? (const void*)(base + li) : (const void*)btx_zero16, rs + (wave < 4 ? 0 : 8192) + (wave & 3) * 1024);
       }
     }
+  };
+  auto issue_acts = [&]() {  // stages in order: the K walk advances by one stage per call
     // activations: one tap for the whole stage; tap_off is wave-uniform
     uint32_t tap_off = 0;
     if (!p.transposed)
@@ -333,35 +335,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   };
 
   // =================== main loop ==========================================================================
+  // VMEM issue order per wave and iteration s:  acts(s+2) x4  ...  raw(s+3) x RAWOPS.
+  //   bf16: a wave reads back only the raw quads it fetched itself, so it refills raw slot (s+1)&1 right after its
+  //         own P(s+1) has consumed it -> every DMA has TWO iterations to land.
+  //   f32 : rho is fetched by waves 4-7 and consumed by waves 0-3; raw(s+2) is issued at the top of iteration s
+  //         (after the barrier) instead — that path is MFMA-bound (64-cycle MFMAs), latency is irrelevant there.
+  // End of iteration: everything older than the ops still allowed in flight has landed; lgkmcnt(0); raw s_barrier.
+  constexpr int RAWOPS = (G == 8) ? 2 : 1;
+  constexpr bool RAW_EARLY = (G == 8);
   if (nstages > 0) {
-    const int pre = nstages < DMA_D - 1 ? nstages : DMA_D - 1;
-    for (int st = 0; st < pre; ++st) issue_stage(st);
+    issue_raw(0);
+    if (nstages > 1) issue_raw(1);
+    issue_acts();
+    if (nstages > 1) issue_acts();
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     process_stage(0);
+    if (RAW_EARLY && nstages > 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(2); }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // Two complete instances of the loop, one per wave half, so that neither has control-flow merges inside
-    // (merges made hipcc shuffle the 128 accumulators between register ranges and spill; spill traffic is VMEM
-    // and drags a vmcnt(0) into the DMA pipeline).  Waves 0-3: [MFMA ; sample next], waves 4-7: [sample next ; MFMA]
-    // — the two waves sharing a SIMD keep its matrix pipe and its VALU busy at the same time.
     auto run = [&](auto upper_tag) {
       constexpr bool UPPER = decltype(upper_tag)::value;
       int a_slot = 0;
       for (int s = 0; s < nstages; ++s) {
-        const bool issued = s + DMA_D - 1 < nstages;
-        if (issued) issue_stage(s + DMA_D - 1);
+        const bool acts_issued = s + 2 < nstages;
+        if (acts_issued) {
+          if constexpr (!RAW_EARLY) issue_raw(s + 2);
+          issue_acts();
+        }
         const bool more = s + 1 < nstages;
+        const bool raw_issued = RAW_EARLY && (s + 3 < nstages);
         if constexpr (!UPPER) {
           mma_stage(s, a_slot);
           __builtin_amdgcn_sched_barrier(0);
           if (more) process_stage(s + 1);
+          if (raw_issued) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(s + 3); }
         } else {
           if (more) process_stage(s + 1);
+          if (raw_issued) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(s + 3); }
           __builtin_amdgcn_sched_barrier(0);
           mma_stage(s, a_slot);
         }
-        // this iteration issued [raw ..., acts x 4]; raw(s+2) and everything older must have landed
-        if (issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (RAW_EARLY) {
+          // must have landed: acts(s+1), raw(s+2).  Younger: acts(s+2) x4 [, raw(s+3) x2]
+          if (raw_issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if (acts_issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          // must have landed: raw(s+2) (this iteration, issued before the acts), acts(s+1).  Younger: acts(s+2) x4
+          if (acts_issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         a_slot = (a_slot == DMA_D - 1) ? 0 : a_slot + 1;
       }

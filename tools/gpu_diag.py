@@ -98,12 +98,31 @@ def perf(precs, iters, bs=64):
                 tot_ms, tot_fl / (tot_ms * 1e-3) / 1e12, 100 * tot_fl / (tot_ms * 1e-3) / 1e12 / peak[prec]))
 
 
+def one(prec, iters, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64):
+    """one layer shape, `iters` launches — the target of rocprofv3 runs"""
+    from bayesian_torch_amd import layers as L
+    dev = torch.device("cuda:0")
+    act = torch.bfloat16 if prec == "bf16" else torch.float32
+    torch.manual_seed(0)
+    layer = getattr(L, "Conv2d" + typ)(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(dev)
+    layer.precision = prec
+    x = torch.randn(bs, cin, hw, hw, device=dev).to(act).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for i in range(iters):
+            layer._forward_hip(x, sample_idx=i)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["parity", "perf"])
     ap.add_argument("--prec", default="bf16,f32")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--shape", default="64,64,56,1,3")
     a = ap.parse_args()
+    if "one" in a.what:
+        c = [int(v) for v in a.shape.split(",")]
+        one(a.prec.split(",")[0], a.iters, *c)
     if "parity" in a.what:
         parity()
     if "perf" in a.what:

@@ -13,6 +13,15 @@ for step in "$@"; do
     perf)   timeout 900 python tools/gpu_diag.py perf --iters 5 > gpurun_out/diag_perf.log 2>&1; echo "perf rc=$?" ;;
     bench)  timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log ;;
     bench_f32) timeout 900 python bench.py --steps 5 --warmup 1 --prec f32 --no-cpu-baseline > gpurun_out/bench_f32.log 2>&1; echo "bench_f32 rc=$?"; tail -1 gpurun_out/bench_f32.log ;;
+    counters) rocprofv3 -L > gpurun_out/counters.txt 2>&1; echo "counters rc=$?" ;;
+    pmc)    R="$PWD"; cd /tmp
+            i=0
+            for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
+                       "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" \
+                       "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TA_BUSY_avr TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum"; do
+              i=$((i+1))
+              timeout 600 rocprofv3 --pmc $set --kernel-trace -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/tools/gpu_diag.py" one --prec bf16 --iters 6 > "$R/gpurun_out/pmc$i.log" 2>&1; echo "pmc$i rc=$?"
+            done; cd "$R" ;;
     prof)   cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$OLDPWD" ;;
   esac
 done
