@@ -276,10 +276,20 @@ def kl_hip(mu, rho, prior_mu, prior_sigma, prior_mu_t=None, prior_sigma_t=None, 
     return out
 
 
-def fill_eps_hip(shape_like, seed, sample_idx, layer_id, rng_stream):
-    """BTX-RNG v1 eps for a flat index space of shape_like.numel() elements, as a flat f32 CUDA tensor."""
+def pad_channels(x, op, extra):
+    """zero-pad the channel axis of a logical [N,C,*sp] (or [*,C]) tensor by `extra`, result channels-last"""
+    nd = op.nd
+    if nd == 0:
+        return F.pad(x, (0, extra))
+    perm = (0,) + tuple(range(2, 2 + nd)) + (1,)
+    xp = F.pad(x.permute(perm), (0, extra))  # contiguous [N,*sp,C+extra]
+    return xp.permute((0, nd + 1) + tuple(range(1, nd + 1)))
+
+
+def fill_eps_hip(n, device, seed, sample_idx, layer_id, rng_stream):
+    """BTX-RNG v1 eps for a flat index space of n elements, as a flat f32 CUDA tensor."""
     L = _lib.lib()
-    out = torch.empty(shape_like.numel(), dtype=torch.float32, device=shape_like.device)
+    out = torch.empty(int(n), dtype=torch.float32, device=device)
     r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
     _lib.check(L.btx_fill_eps(out.data_ptr(), out.numel(), ctypes.byref(r), rng_stream,
                               torch.cuda.current_stream(out.device).cuda_stream))

@@ -109,6 +109,17 @@ class _VariationalNd(BaseVariationalLayer_):
             self.register_buffer("eps_bias", None, persistent=False)
             self.register_buffer("prior_bias_mu", None, persistent=False)
             self.register_buffer("prior_bias_sigma", None, persistent=False)
+        # Channel padding for the MFMA kernels: layers whose C/groups is not a multiple of 8 (the RGB stem, odd Linear
+        # sizes) are executed on inputs / parameters zero-padded to the next multiple of 8 so they take the fast
+        # granule kernels instead of the element-wise gather kernel.  Every real element still appears exactly once,
+        # so the Flipout sign semantics are unchanged; BTX-RNG indices of such a layer refer to the padded layout
+        # (materialize_noise maps them back).  groups == 1 only.
+        self._btx_cpad = None
+        if (groups if nd else 1) == 1 and in_ch % 8 != 0:
+            self._btx_cpad = (in_ch + 7) // 8 * 8
+            self._op_pad = BF.OpDesc(nd, self._btx_cpad, out_ch, ksz if nd else 1, stride if nd else 1,
+                                     padding if nd else 0, dilation if nd else 1, 1, self._transposed,
+                                     output_padding if (nd and self._transposed) else 0)
         # MI355X-side state (not part of the reference surface)
         self._btx_layer_id = _rng.next_layer_id()
         self._btx_sample = 0
@@ -211,7 +222,14 @@ class _VariationalNd(BaseVariationalLayer_):
         kind = _lib.KIND_FLIPOUT if self._family == "flipout" else _lib.KIND_REPARAM
         mb = self.mu_bias.detach() if self.mu_bias is not None else None
         rb = self.rho_bias.detach() if self.rho_bias is not None else None
-        return BF.contract_hip(kind, x, mu_p, rho_p, mb, rb, self._op, _rng.seed(), sample_idx,
+        op = self._op
+        if self._btx_cpad is not None and noise is None:  # explicit noise (parity mode) stays unpadded -> gather kernel
+            extra = self._btx_cpad - op.in_channels
+            x = BF.pad_channels(x, op, extra)
+            mu_p = torch.nn.functional.pad(mu_p, (0, extra))   # zero weights meet zero activations
+            rho_p = torch.nn.functional.pad(rho_p, (0, extra))
+            op = self._op_pad
+        return BF.contract_hip(kind, x, mu_p, rho_p, mb, rb, op, _rng.seed(), sample_idx,
                                self._btx_layer_id, prec=self.precision, noise=noise)
 
     def materialize_noise(self, sample_idx, x_shape=None, out_shape=None):
@@ -220,11 +238,16 @@ class _VariationalNd(BaseVariationalLayer_):
         observable side effect, conv_variational.py:362)."""
         mu, _ = self._w()
         op, seed, lid = self._op, _rng.seed(), self._btx_layer_id
-        flat = BF.fill_eps_hip(mu, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+        cin, cpad = op.in_channels, self._btx_cpad
+        if cpad is None:
+            flat = BF.fill_eps_hip(mu.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+        else:  # indices run over the zero-padded [N][tap][cpad] layout
+            flat = BF.fill_eps_hip(mu.numel() // cin * cpad, mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+            flat = flat.reshape(-1, cpad)[:, :cin].reshape(-1)
         d = {"eps_w": BF.unpack_gemm_major(flat, tuple(mu.shape), op)}
         getattr(self, "eps_" + self._wn).copy_(d["eps_w"])
         if self.mu_bias is not None:
-            d["eps_b"] = BF.fill_eps_hip(self.mu_bias, seed, sample_idx, lid, _lib.STREAM_EPS_B)
+            d["eps_b"] = BF.fill_eps_hip(self.mu_bias.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_B)
             self.eps_bias.copy_(d["eps_b"])
         if self._family == "flipout" and x_shape is not None:
             def cl_to_logical(flat8, shape):
@@ -239,8 +262,12 @@ class _VariationalNd(BaseVariationalLayer_):
             nout = 1
             for v in out_shape:
                 nout *= v
-            d["sign_in"] = cl_to_logical(BF.fill_sign_hip(nin, mu.device, seed, sample_idx, lid,
-                                                          _lib.STREAM_SIGN_IN), tuple(x_shape))
+            if cpad is None:
+                d["sign_in"] = cl_to_logical(BF.fill_sign_hip(nin, mu.device, seed, sample_idx, lid,
+                                                              _lib.STREAM_SIGN_IN), tuple(x_shape))
+            else:
+                sp = BF.fill_sign_hip(nin // cin * cpad, mu.device, seed, sample_idx, lid, _lib.STREAM_SIGN_IN)
+                d["sign_in"] = cl_to_logical(sp.reshape(-1, cpad)[:, :cin].reshape(-1), tuple(x_shape))
             d["sign_out"] = cl_to_logical(BF.fill_sign_hip(nout, mu.device, seed, sample_idx, lid,
                                                            _lib.STREAM_SIGN_OUT), tuple(out_shape))
         return d

@@ -19,7 +19,7 @@ def test_fill_eps_matches_cpu_restatement():
     from oracle import bt_oracle as o
     dev = _dev()
     for (n, seed, sample, layer, stream) in ((100003, 1234, 0, 1, 0), (4096, 2 ** 40 + 17, 7, 3, 1), (5, 9, 123456, 99, 0)):
-        g = BF.fill_eps_hip(torch.empty(n, device=dev), seed, sample, layer, stream).cpu().numpy()
+        g = BF.fill_eps_hip(n, dev, seed, sample, layer, stream).cpu().numpy()
         c = o.eps(n, seed, sample, layer, stream)
         assert np.isfinite(g).all()
         assert np.abs(g - c).max() < 2e-5, (n, np.abs(g - c).max())
