@@ -269,8 +269,10 @@ static bool dma_shape_ok(const BtxGeom* g, int act_dtype, int prec, const Plan& 
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   if (pl.Cg % bk) return false;  // a K-stage must lie inside one filter tap
   const long long in_elems = (long long)g->NB * g->D * g->H * g->W * g->C;
-  if (in_elems >= 0x7fffffffLL || (long long)pl.M * g->N >= 0x7fffffffLL || (long long)g->N * pl.K >= 0xffffffffLL)
-    return false;  // 32-bit element offsets
+  const long long esz = (act_dtype == BTX_ACT_BF16) ? 2 : 4;
+  if (in_elems * esz >= 0xfff00000LL || (long long)pl.M * g->N >= 0x7fffffffLL ||
+      (long long)g->N * pl.K * 4 >= 0xfff00000LL)
+    return false;  // 32-bit byte offsets inside the buffer descriptors
   return true;
 }
 
@@ -337,6 +339,12 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
   p.sample = rng->sample_idx; p.layer = rng->layer_id;
   sign_keys(rng, BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
   sign_keys(rng, BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
+  {
+    const long long in_elems = (long long)g->NB * g->D * g->H * g->W * g->C;
+    const long long xb = in_elems * (act_dtype == BTX_ACT_BF16 ? 2 : 4), wb = (long long)g->N * pl.K * 4;
+    p.x_bytes = xb < 0xffffffffLL ? (uint32_t)xb : 0xffffffffu;
+    p.w_bytes = wb < 0xffffffffLL ? (uint32_t)wb : 0xffffffffu;
+  }
 
   hipStream_t st = (hipStream_t)stream;
   if (dma)

@@ -77,6 +77,7 @@ struct ContractParams {
   int transposed;
   uint32_t seed_lo, seed_hi, sample, layer;
   uint32_t kin_a, kin_b, kout_a, kout_b;
+  uint32_t x_bytes, w_bytes;  // sizes of x and of mu/rho in bytes (buffer descriptors of the DMA variant)
 };
 
 // ---- small helpers -------------------------------------------------------------------------------------

@@ -44,12 +44,14 @@ constexpr int DR_OFF = DS_OFF + DMA_D * DS_STAGE;     // 104448
 constexpr int DW_OFF = DR_OFF + 2 * DR_STAGE;         // 137216
 constexpr int DMA_LDS_BYTES = DW_OFF + 2 * DW_STAGE;  // 153600
 
-static __device__ __attribute__((aligned(16))) unsigned int btx_zero16[4] = {0u, 0u, 0u, 0u};
+constexpr uint32_t DMA_OOB = 0xfffffff0u;  // byte offset beyond every descriptor: the hardware returns zeros
 
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
-  // LDS destination = wave-uniform base + lane*16 ; the global source address is per lane
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// buffer_load_dwordx4 ... offen lds: descriptor base in SGPRs, one 32-bit byte offset per lane (out-of-range lanes are
+// zero-filled by the hardware: that is the conv padding and every tile tail), LDS destination = wave-uniform base +
+// lane*16.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off,
+                                           0, 0, 0);
 }
 
 template <int PREC, int KIND>
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   int pb_d[4], pb_h[4], pb_w[4], pb_n[4];
   uint32_t pb_off[4];
   bool pb_ok[4];
-  auto decode = [&](int mm_, int& bd_, int& bh_, int& bw_, int& nbase_, uint32_t& off_) {
+  auto decode = [&](int mm_, int& bd_, int& bh_, int& bw_, int& nbase_, uint32_t& off_) __attribute__((always_inline)) {
     const int ow = mm_ % p.Wo;
     int t = mm_ / p.Wo;
     const int oh = t % p.Ho;
@@ -112,18 +114,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     pb_ok[q] = mq < p.M;
     decode(pb_ok[q] ? mq : 0, pb_d[q], pb_h[q], pb_w[q], pb_n[q], pb_off[q]);
   }
+  // tap-validity bitmasks (one bit per filter tap, computed once per workgroup) when the filter has <= 32 taps
+  const int ntaps = p.KD * p.KH * p.KW;
+  const bool use_mask = (ntaps <= 32) && !p.transposed;  // uniform
+  uint32_t vmask0 = 0u, vmask1 = 0u, vmask2 = 0u, vmask3 = 0u;
+  if (use_mask) {
+    int t = 0;
+    for (int kd = 0; kd < p.KD; ++kd)
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw, ++t) {
+          // written out per pixel (no array indexing inside a runtime loop: keeps everything in registers)
+#define BTX_TAP_OK(q)                                                                                             \
+  ((pb_ok[q] && (unsigned)(pb_d[q] + kd * p.dd) < (unsigned)p.D && (unsigned)(pb_h[q] + kh * p.dh) < (unsigned)p.H && \
+    (unsigned)(pb_w[q] + kw * p.dw) < (unsigned)p.W) ? (1u << t) : 0u)
+          vmask0 |= BTX_TAP_OK(0);
+          vmask1 |= BTX_TAP_OK(1);
+          vmask2 |= BTX_TAP_OK(2);
+          vmask3 |= BTX_TAP_OK(3);
+#undef BTX_TAP_OK
+        }
+  }
+  const uint32_t vmask[4] = {vmask0, vmask1, vmask2, vmask3};
+  // byte offset of this lane's granule inside its pixel, folded into the per-pixel base
+  uint32_t pb_boff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pb_boff[q] = (pb_off[q] + (uint32_t)(G * g_lane)) * (uint32_t)sizeof(ACT);
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mu_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.mu, 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rho_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.rho, 0, p.w_bytes, 0x00020000);
   uint32_t sg_off;  // this thread's own pixel (tid): only the sign word needs it
   {
     const int m = mtile * DBM + tid;
     int a_, b_, c_, d_;
     decode(m < p.M ? m : 0, a_, b_, c_, d_, sg_off);
   }
-  const ACT* __restrict__ xptr = (const ACT*)p.x;
 
   // wave-uniform K walk: channel offset inside the tap and the tap itself
-  int s_c, s_kd, s_kh, s_kw;
+  int s_c, s_kd, s_kh, s_kw, s_tap;
   {
     const int tap = k_begin / p.Cg;
+    s_tap = tap;
     s_c = k_begin - tap * p.Cg;
     s_kw = tap % p.KW;
     const int t2 = tap / p.KW;
@@ -146,44 +176,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   int a_slot_issue = 0;  // ring slot the next issue_acts() fills
 
   // =================== issue: all HBM -> LDS traffic of one stage (called for stages 0,1,2,... in order) =====
-  auto issue_raw = [&](int st) {
+  auto issue_raw = [&](int st) __attribute__((always_inline)) {
     const int kstage = k_begin + st * BK;  // uniform; kstage < k_end because st < nstages
-    {
-      unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
-      const int kk = kstage + 4 * w_quad;
-      const bool ok = w_colok && (kk < k_end);
-      const uint32_t li = w_rowbase + (uint32_t)kk;
-      if constexpr (G == 8) {
-        dma16(ok ? (const void*)(p.mu + li) : (const void*)btx_zero16, rs + wave * 1024);
-        dma16(ok ? (const void*)(p.rho + li) : (const void*)btx_zero16, rs + 8192 + wave * 1024);
-      } else {
-        const float* base = (wave < 4) ? p.mu : p.rho;
-        dma16(ok ? (const void*)(base + li) : (const void*)btx_zero16, rs + (wave < 4 ? 0 : 8192) + (wave & 3) * 1024);
-      }
+    unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
+    const int kk = kstage + 4 * w_quad;
+    const bool ok = w_colok && (kk < k_end);
+    const uint32_t bo = ok ? (w_rowbase + (uint32_t)kk) * 4u : DMA_OOB;
+    if constexpr (G == 8) {
+      dma16(mu_rsrc, bo, rs + wave * 1024);
+      dma16(rho_rsrc, bo, rs + 8192 + wave * 1024);
+    } else {
+      if (wave < 4) dma16(mu_rsrc, bo, rs + wave * 1024);
+      else dma16(rho_rsrc, bo, rs + 8192 + (wave & 3) * 1024);
     }
   };
-  auto issue_acts = [&]() {  // stages in order: the K walk advances by one stage per call
+  auto issue_acts = [&]() __attribute__((always_inline)) {  // stages in order: the K walk advances by one stage per call
     // activations: one tap for the whole stage; tap_off is wave-uniform
     uint32_t tap_off = 0;
     if (!p.transposed)
       tap_off = (uint32_t)(((s_kd * p.dd) * p.H + s_kh * p.dh) * p.W + s_kw * p.dw) * (uint32_t)p.C + (uint32_t)s_c;
+    const uint32_t tap_boff = tap_off * (uint32_t)sizeof(ACT);
     unsigned char* as = smem + DA_OFF + a_slot_issue * DA_STAGE + wave * 4096;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      bool ok = pb_ok[q];
-      uint32_t off;
-      if (!p.transposed) {
+      bool ok;
+      uint32_t bo;
+      if (use_mask) {
+        ok = (vmask[q] >> s_tap) & 1u;
+        bo = pb_boff[q] + tap_boff;
+      } else if (!p.transposed) {
         const int id = pb_d[q] + s_kd * p.dd, ih = pb_h[q] + s_kh * p.dh, iw = pb_w[q] + s_kw * p.dw;
-        ok = ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        off = pb_off[q] + tap_off;
+        ok = pb_ok[q] && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        bo = pb_boff[q] + tap_boff;
       } else {
         const int td = pb_d[q] - s_kd * p.dd, th = pb_h[q] - s_kh * p.dh, tw = pb_w[q] - s_kw * p.dw;
         const int id = td / p.sd, ih = th / p.sh, iw = tw / p.sw;
-        ok = ok && td >= 0 && th >= 0 && tw >= 0 && (id * p.sd == td) && (ih * p.sh == th) && (iw * p.sw == tw) &&
-             id < p.D && ih < p.H && iw < p.W;
-        off = (uint32_t)(((pb_n[q] + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + s_c);
+        ok = pb_ok[q] && td >= 0 && th >= 0 && tw >= 0 && (id * p.sd == td) && (ih * p.sh == th) &&
+             (iw * p.sw == tw) && id < p.D && ih < p.H && iw < p.W;
+        bo = ((uint32_t)(((pb_n[q] + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C +
+              (uint32_t)(group * p.Cg + s_c + G * g_lane)) * (uint32_t)sizeof(ACT);
       }
-      dma16(ok ? (const void*)(xptr + off + G * g_lane) : (const void*)btx_zero16, as + q * 1024);
+      dma16(x_rsrc, ok ? bo : DMA_OOB, as + q * 1024);
     }
     if constexpr (KIND == 1) {
       // one hashed word covers the 32 (bf16) / 16 (f32) channels of pixel `tid`'s stage.  (In the padding the
@@ -205,13 +238,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     s_c += BK;
     if (s_c >= p.Cg) {
       s_c = 0;
+      ++s_tap;
       if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; ++s_kd; } }
     }
     a_slot_issue = (a_slot_issue == DMA_D - 1) ? 0 : a_slot_issue + 1;
   };
 
   // =================== P: raw (mu, rho) quad -> sampled MFMA weight tile ==================================
-  auto process_stage = [&](int st) {
+  auto process_stage = [&](int st) __attribute__((always_inline)) {
     if (w_thread) {
       const unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
       unsigned char* ws = smem + DW_OFF + (st & 1) * DW_STAGE;
@@ -257,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
 
-  auto mma_stage = [&](int st, int a_slot) {
+  auto mma_stage = [&](int st, int a_slot) __attribute__((always_inline)) {
     const unsigned char* as = smem + DA_OFF + a_slot * DA_STAGE;
     const unsigned char* ss = smem + DS_OFF + a_slot * DS_STAGE;
     const unsigned char* ws = smem + DW_OFF + (st & 1) * DW_STAGE;
@@ -352,7 +386,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     process_stage(0);
     if (RAW_EARLY && nstages > 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(2); }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    auto run = [&](auto upper_tag) {
+    auto run = [&](auto upper_tag) __attribute__((always_inline)) {
       constexpr bool UPPER = decltype(upper_tag)::value;
       int a_slot = 0;
       for (int s = 0; s < nstages; ++s) {
