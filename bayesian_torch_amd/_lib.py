@@ -9,7 +9,8 @@ _LIB = None
 KIND_REPARAM, KIND_FLIPOUT = 0, 1
 ACT_F32, ACT_BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
-FLAG_TRANSPOSED, FLAG_KL_ACCUM = 1, 2
+FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE = 1, 2, 4
+E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
 ABI_VERSION = 1
 
@@ -39,7 +40,8 @@ EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_
 
 
 def lib_path():
-    return os.path.join(_HERE, "libbtx.so")
+    # BTX_LIB: alternative build of the same ABI (A/B measurements of kernel variants)
+    return os.environ.get("BTX_LIB") or os.path.join(_HERE, "libbtx.so")
 
 
 def lib():

@@ -310,7 +310,19 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
   // LDS-DMA pipeline when the activations already have the contraction dtype (no conversion on the way to LDS);
   // BTX_NO_DMA=1 forces the register-staged kernel (A/B measurements).
   static const bool no_dma = getenv("BTX_NO_DMA") != nullptr;
-  const bool dma = !gen && !no_dma && dma_shape_ok(g, act_dtype, prec, pl);
+  const bool rowfuse = (flags & BTX_FLAG_ROWFUSE) != 0;
+  bool dma = !gen && !no_dma && dma_shape_ok(g, act_dtype, prec, pl);
+  if (rowfuse) {
+    // one K-stage = one kernel row: the K walk sees KW*C "channels" per tap and a single tap per row
+    const int esz = (act_dtype == BTX_ACT_BF16) ? 2 : 4;
+    const int bk = NG * G;
+    const bool ok = !(al & 15) && !explicit_kloop && !no_dma && (prec == BTX_PREC_BF16) == (act_dtype == BTX_ACT_BF16) &&
+                    g->groups == 1 && g->dw == 1 && g->pw == 0 && !(flags & BTX_FLAG_TRANSPOSED) &&
+                    ((g->KW * g->C) % bk == 0) && ((g->sw * g->C * esz) % 16 == 0) && ((g->W * g->C * esz) % 16 == 0) &&
+                    (g->C % G == 0 || G % g->C == 0);
+    if (!ok) return BTX_E_UNSUPPORTED;
+    dma = true;
+  }
   if (dma) {
     rc = make_plan(g, prec, flags, DBM, &pl);
     if (rc) return rc;
@@ -335,6 +347,11 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
   p.M = pl.M; p.K = pl.K;
   p.mtiles = pl.mtiles; p.ntiles = pl.ntiles; p.groups = g->groups; p.ksplits = pl.ksplits; p.kper = pl.kper;
   p.transposed = (flags & BTX_FLAG_TRANSPOSED) ? 1 : 0;
+  if (rowfuse) {  // K = KH*(KW*C) unchanged; the pixel stride p.C stays C
+    p.Cg = g->KW * g->C;
+    p.KW = 1;
+    p.sign_unaligned = 1;
+  }
   p.seed_lo = (uint32_t)rng->seed; p.seed_hi = (uint32_t)(rng->seed >> 32);
   p.sample = rng->sample_idx; p.layer = rng->layer_id;
   sign_keys(rng, BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
@@ -346,6 +363,8 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
     p.w_bytes = wb < 0xffffffffLL ? (uint32_t)wb : 0xffffffffu;
   }
 
+  static const char* dbg_env = getenv("BTX_DBG");
+  p.dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
   hipStream_t st = (hipStream_t)stream;
   if (dma)
     rc = (prec == BTX_PREC_BF16) ? launch_contract_dma_bf16(kind, p, pl.nwg, st)

@@ -28,6 +28,16 @@
 //   end     vmcnt(4): everything older than this iteration's 4 activation DMAs has landed = raw(s+2), acts(s+1)
 #pragma once
 #include <type_traits>
+// Measurement-only switches (never defined in the product build):
+//   BTX_ABLATE           honour ContractParams::dbg bits (skip sampling / MFMA / sign hash / activation DMA)
+//   BTX_MP_BARRIER       keep a sched_barrier between the MFMA block and the sampling block
+//   BTX_NO_KK_BARRIER    drop the sched_barrier between the two k-halves of a stage
+//   BTX_NO_STAGGER       all waves issue their activation DMAs at the top of the iteration
+#ifdef BTX_ABLATE
+#define BTX_DBG(bit) (p.dbg & (bit))
+#else
+#define BTX_DBG(bit) false
+#endif
 #include "btx_contract.h"
 
 namespace btx {
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
         bo = ((uint32_t)(((pb_n[q] + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C +
               (uint32_t)(group * p.Cg + s_c + G * g_lane)) * (uint32_t)sizeof(ACT);
       }
-      dma16(x_rsrc, ok ? bo : DMA_OOB, as + q * 1024);
+      if (!BTX_DBG(8u)) dma16(x_rsrc, ok ? bo : DMA_OOB, as + q * 1024);
     }
     if constexpr (KIND == 1) {
       // one hashed word covers the 32 (bf16) / 16 (f32) channels of pixel `tid`'s stage.  (In the padding the
@@ -230,8 +240,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
         const int id = (bd_ - s_kd * p.dd) / p.sd, ih = (bh_ - s_kh * p.dh) / p.sh, iw = (bw_ - s_kw * p.dw) / p.sw;
         off = (uint32_t)(((nb_ + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + s_c);
       }
-      uint32_t w = btx_sign_word(off >> 5, p.kin_a, p.kin_b);
-      if constexpr (G == 4) w <<= 8 * ((off >> 4) & 1);
+      // sign layout: element pair e>>1 sits at bit 15-(e>>1) (even e) / 31-(e>>1) (odd e) of its word, so a stage that
+      // starts at element offset e0 inside the word needs the word shifted left by e0>>1 within each 16-bit half
+      uint32_t w = BTX_DBG(4u) ? off : btx_sign_word(off >> 5, p.kin_a, p.kin_b);
+      if (p.sign_unaligned) {  // uniform: the stage may run into the next word (row-fused stems)
+        const uint32_t w1 = btx_sign_word((off >> 5) + 1u, p.kin_a, p.kin_b);
+        const uint32_t k = (off & 31u) >> 1;
+        const uint32_t lo = ((w & 0xffffu) << 16) | (w1 & 0xffffu);
+        const uint32_t hi = (w & 0xffff0000u) | (w1 >> 16);
+        w = ((lo << k) >> 16) | ((hi << k) & 0xffff0000u);
+      } else if constexpr (G == 4) {
+        w <<= 8 * ((off >> 4) & 1);
+      }
       *(uint32_t*)(smem + DS_OFF + a_slot_issue * DS_STAGE + tid * 4) = w;
     }
     // advance the K walk by one stage
@@ -254,12 +274,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
       const f32x4 rho4 = *(const f32x4*)(rs + 8192 + ro);
       const int k0 = k_begin + st * BK + 4 * w_quad;
       const bool ok = w_colok && (k0 < k_end);
-      float eps[4];
-      btx_normal4_hw((w_rowbase + (uint32_t)k0) >> 2, p.sample, p.layer, 0u, p.seed_lo, p.seed_hi, eps);
+      float eps[4] = {1.f, -1.f, 0.5f, -0.5f};
+      if (!BTX_DBG(1u)) btx_normal4_hw((w_rowbase + (uint32_t)k0) >> 2, p.sample, p.layer, 0u, p.seed_lo, p.seed_hi, eps);
       float wm[4], wd[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float sg = btx_softplus_hw(rho4[e]);
+        const float sg = BTX_DBG(1u) ? rho4[e] : btx_softplus_hw(rho4[e]);
         if constexpr (KIND == 0) {
           wm[e] = ok ? __builtin_fmaf(sg, eps[e], mu4[e]) : 0.f;
           wd[e] = 0.f;
@@ -304,7 +324,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     for (int kk = 0; kk < NG / 2; ++kk) {
       // Register diet (the 128-accumulator Flipout tile leaves ~120 VGPRs for everything else): the two k-halves
       // of the stage stay apart, and the delta weights are fetched only after the mu-MFMAs have been issued.
+#ifndef BTX_NO_KK_BARRIER
       __builtin_amdgcn_sched_barrier(0);
+#endif
       const int row = 2 * kk + h;
       u32x4 a[2], wq[2];
 #pragma unroll
@@ -391,26 +413,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
       int a_slot = 0;
       for (int s = 0; s < nstages; ++s) {
         const bool acts_issued = s + 2 < nstages;
-        if (acts_issued) {
-          if constexpr (!RAW_EARLY) issue_raw(s + 2);
-          issue_acts();
-        }
         const bool more = s + 1 < nstages;
         const bool raw_issued = RAW_EARLY && (s + 3 < nstages);
+        // The DMA instructions block at issue while the memory pipeline is full.  Waves 0-3 issue their activation
+        // DMAs at the top of the iteration, waves 4-7 after their MFMA block, so that of the two waves sharing a SIMD
+        // one is always free to compute while the other is stuck issuing (measured: memory 82 us + compute 52 us
+        // serialised to 134 us when every wave issued at the same point).
         if constexpr (!UPPER) {
-          mma_stage(s, a_slot);
+          if (acts_issued) {
+            if constexpr (!RAW_EARLY) issue_raw(s + 2);
+            issue_acts();
+          }
+          if (!BTX_DBG(2u)) mma_stage(s, a_slot);
+#ifdef BTX_MP_BARRIER
           __builtin_amdgcn_sched_barrier(0);
-          if (more) process_stage(s + 1);
+#endif
+          if (more && !BTX_DBG(16u)) process_stage(s + 1);
           if (raw_issued) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(s + 3); }
         } else {
-          if (more) process_stage(s + 1);
+          if constexpr (!RAW_EARLY) { if (acts_issued) issue_raw(s + 2); }
+#ifdef BTX_NO_STAGGER
+          if (acts_issued) issue_acts();
+#endif
+          if (more && !BTX_DBG(16u)) process_stage(s + 1);
           if (raw_issued) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(s + 3); }
+#ifdef BTX_MP_BARRIER
           __builtin_amdgcn_sched_barrier(0);
-          mma_stage(s, a_slot);
+#endif
+#ifdef BTX_NO_STAGGER
+          if (!BTX_DBG(2u)) mma_stage(s, a_slot);
+#else
+          if (!BTX_DBG(2u)) mma_stage(s, a_slot);
+          if (acts_issued) issue_acts();
+#endif
         }
         if constexpr (RAW_EARLY) {
           // must have landed: acts(s+1), raw(s+2).  Younger: acts(s+2) x4 [, raw(s+3) x2]
-          if (raw_issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          if (BTX_DBG(8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (raw_issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
           else if (acts_issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {

@@ -181,7 +181,8 @@ def _sign_to_int8_cl(s, op):
     return phys
 
 
-def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_id, prec=None, noise=None):
+def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_id, prec=None, noise=None,
+                 extra_flags=0):
     """One fused sample-and-contract forward on the GPU (btx_contract_fwd).  `mu_p`/`rho_p` are GEMM-major packed.
     `noise` (parity mode) = dict with optional eps_w (logical weight layout), eps_b, sign_in, sign_out."""
     L = _lib.lib()
@@ -207,7 +208,7 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     g.dd, g.dh, g.dw = op.dilation
     g.od, g.oh, g.ow = op.output_padding
     g.groups = op.groups
-    flags = _lib.FLAG_TRANSPOSED if op.transposed else 0
+    flags = (_lib.FLAG_TRANSPOSED if op.transposed else 0) | extra_flags
     out = _alloc_out(op, nb, out_sp, x.dtype, x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     need = L.btx_contract_workspace_bytes(ctypes.byref(g), kind, act, prec_c, flags)
@@ -274,6 +275,46 @@ def kl_hip(mu, rho, prior_mu, prior_sigma, prior_mu_t=None, prior_sigma_t=None, 
                         out.data_ptr(), _lib.FLAG_KL_ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), stream)
     _lib.check(rc)
     return out
+
+
+def rowfuse_plan(op, x_shape, prec, x_dtype):
+    """Geometry of the row-fused execution of a small-C 2-D stem conv (BTX_FLAG_ROWFUSE), or None.
+    The input is zero-padded to NHWC4 with the conv padding materialised, the kernel row is padded to 8 taps:
+    one K-stage of the DMA kernel = one kernel row = 8 pixels x 4 channels = 64 contiguous bytes (bf16)."""
+    if op.nd != 2 or op.transposed or op.groups != 1 or op.in_channels > 4 or op.dilation != (1, 1, 1):
+        return None
+    kh, kw = op.kernel[1], op.kernel[2]
+    sh, sw = op.stride[1], op.stride[2]
+    bf16 = x_dtype == torch.bfloat16
+    if (prec == "bf16") != bf16 or kw > 8 or (bf16 and sw % 2):
+        return None
+    ph, pw = op.padding[1], op.padding[2]
+    H, W = x_shape[2], x_shape[3]
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    Wp = (Wo - 1) * sw + 8
+    Wp += Wp % 2                                # row pitch (Wp*4 elements) must be a multiple of 16 bytes
+    Wp = max(Wp, W + 2 * pw)
+    Wp += Wp % 2
+    Hp = H + 2 * ph
+    fop = OpDesc(2, 4, op.out_channels, (kh, 8), (sh, sw), 0, 1, 1)
+    return dict(op=fop, Hp=Hp, Wp=Wp, ph=ph, pw=pw, Ho=Ho, Wo=Wo, kw=kw, cin=op.in_channels)
+
+
+def rowfuse_input(x, plan):
+    """logical [N,C,H,W] -> zero-padded logical [N,4,Hp,Wp] stored channels-last (NHWC4)"""
+    n, c, h, w = x.shape
+    xp = F.pad(x.permute(0, 2, 3, 1), (0, 4 - c, plan["pw"], plan["Wp"] - w - plan["pw"], plan["ph"],
+                                       plan["Hp"] - h - plan["ph"]))
+    return xp.permute(0, 3, 1, 2)
+
+
+def rowfuse_weights(mu_p, rho_p, plan):
+    """GEMM-major [Cout,KH,KW,C] -> [Cout,KH,8,4]; the padded taps meet real pixels, so they must contribute
+    exactly nothing: mu = 0 and rho = -1e30 (softplus -> 0)."""
+    kw, c = plan["kw"], plan["cin"]
+    mu_f = F.pad(mu_p, (0, 4 - c, 0, 8 - kw))
+    rho_f = F.pad(rho_p, (0, 4 - c, 0, 8 - kw), value=-1e30)
+    return mu_f, rho_f
 
 
 def pad_channels(x, op, extra):

@@ -223,6 +223,12 @@ class _VariationalNd(BaseVariationalLayer_):
         mb = self.mu_bias.detach() if self.mu_bias is not None else None
         rb = self.rho_bias.detach() if self.rho_bias is not None else None
         op = self._op
+        plan = self._rowfuse_plan(x) if noise is None else None
+        if plan is not None:  # small-C stem: one kernel row per K-stage on the LDS-DMA kernel
+            mu_f, rho_f = BF.rowfuse_weights(mu_p, rho_p, plan)
+            out = BF.contract_hip(kind, BF.rowfuse_input(x, plan), mu_f, rho_f, mb, rb, plan["op"], _rng.seed(),
+                                  sample_idx, self._btx_layer_id, prec=self.precision, extra_flags=_lib.FLAG_ROWFUSE)
+            return out[:, :, :plan["Ho"], :plan["Wo"]]
         if self._btx_cpad is not None and noise is None:  # explicit noise (parity mode) stays unpadded -> gather kernel
             extra = self._btx_cpad - op.in_channels
             x = BF.pad_channels(x, op, extra)
@@ -232,13 +238,41 @@ class _VariationalNd(BaseVariationalLayer_):
         return BF.contract_hip(kind, x, mu_p, rho_p, mb, rb, op, _rng.seed(), sample_idx,
                                self._btx_layer_id, prec=self.precision, noise=noise)
 
-    def materialize_noise(self, sample_idx, x_shape=None, out_shape=None):
+    def _rowfuse_plan(self, x):
+        if self._op.nd != 2 or self._op.in_channels > 4 or not x.is_cuda:
+            return None
+        return BF.rowfuse_plan(self._op, tuple(x.shape), self.precision or BF.get_precision(), x.dtype)
+
+    def materialize_noise(self, sample_idx, x_shape=None, out_shape=None, x_dtype=None):
         """The noise BTX-RNG v1 defines for MC sample `sample_idx` of this layer, in the reference's logical
         layouts: dict(eps_w, eps_b[, sign_in, sign_out]).  Also refreshes the eps_* buffers (the reference's
         observable side effect, conv_variational.py:362)."""
         mu, _ = self._w()
         op, seed, lid = self._op, _rng.seed(), self._btx_layer_id
         cin, cpad = op.in_channels, self._btx_cpad
+        plan = None
+        if x_shape is not None and x_dtype is not None and op.nd == 2 and cin <= 4:
+            plan = BF.rowfuse_plan(op, tuple(x_shape), self.precision or BF.get_precision(), x_dtype)
+        if plan is not None:  # indices run over the row-fused layouts: weights [Cout][KH][8][4], input [N][Hp][Wp][4]
+            kh, kw = op.kernel[1], plan["kw"]
+            flat = BF.fill_eps_hip(mu.shape[0] * kh * 32, mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+            e = flat.reshape(mu.shape[0], kh, 8, 4)[:, :, :kw, :cin].permute(0, 3, 1, 2).contiguous()
+            d = {"eps_w": e}
+            getattr(self, "eps_" + self._wn).copy_(e)
+            if self.mu_bias is not None:
+                d["eps_b"] = BF.fill_eps_hip(self.mu_bias.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_B)
+                self.eps_bias.copy_(d["eps_b"])
+            if self._family == "flipout":
+                n, _, h, w = x_shape
+                sp = BF.fill_sign_hip(n * plan["Hp"] * plan["Wp"] * 4, mu.device, seed, sample_idx, lid,
+                                      _lib.STREAM_SIGN_IN).reshape(n, plan["Hp"], plan["Wp"], 4)
+                d["sign_in"] = sp[:, plan["ph"]:plan["ph"] + h, plan["pw"]:plan["pw"] + w, :cin].permute(0, 3, 1, 2)
+                # the kernel's output tensor is [N][Ho'][Wo'][Cout] with Wo' possibly wider than Wo
+                fo = plan["op"].out_spatial((1, plan["Hp"], plan["Wp"]))
+                so = BF.fill_sign_hip(n * fo[1] * fo[2] * op.out_channels, mu.device, seed, sample_idx, lid,
+                                      _lib.STREAM_SIGN_OUT).reshape(n, fo[1], fo[2], op.out_channels)
+                d["sign_out"] = so[:, :plan["Ho"], :plan["Wo"], :].permute(0, 3, 1, 2)
+            return d
         if cpad is None:
             flat = BF.fill_eps_hip(mu.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
         else:  # indices run over the zero-padded [N][tap][cpad] layout

@@ -88,6 +88,10 @@ FUSED_CASES = [
     # element-wise (GEN) kernels with in-kernel noise: odd channel counts
     ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 32, 32)),
     ("LinearFlipout", dict(in_features=50, out_features=10), (7, 50)),
+    # small-C stems: row-fused DMA path (bf16/bf16 with even stride, f32/f32 any stride), channel padding otherwise
+    ("Conv2dFlipout", dict(in_channels=3, out_channels=32, kernel_size=3, stride=2, padding=1), (3, 3, 21, 18)),
+    ("Conv2dFlipout", dict(in_channels=1, out_channels=16, kernel_size=5, stride=1, padding=2), (2, 1, 12, 12)),
+    ("Conv2dReparameterization", dict(in_channels=4, out_channels=64, kernel_size=(5, 7), stride=(1, 2), padding=(2, 3)), (2, 4, 9, 30)),
     ("Conv2dReparameterization", dict(in_channels=5, out_channels=7, kernel_size=3, padding=1), (2, 5, 9, 9)),
 ]
 
@@ -104,7 +108,7 @@ def _run_fused(cls, kw, xshape, prec, act, dev, sample=3, seed_init=11):
         x = x.to(torch.bfloat16)
     with torch.no_grad():
         out = layer._forward_hip(x, sample_idx=sample)
-        nz = layer.materialize_noise(sample, tuple(x.shape), tuple(out.shape))
+        nz = layer.materialize_noise(sample, tuple(x.shape), tuple(out.shape), x.dtype)
     wn = "weight" if cls.startswith("Linear") else "kernel"
     geo = case_geometry(dict(cls=cls, kwargs=kw))
     args = dict(x=x.float().cpu().numpy(), mu_w=getattr(layer, "mu_" + wn).detach().cpu().numpy(),

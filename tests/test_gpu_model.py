@@ -48,7 +48,7 @@ def test_resnet18_every_layer_matches_aten_with_same_noise(typ):
     assert len(records) == 21
     worst = 0.0
     for mod, xin, out in records:
-        nz = mod.materialize_noise(sample, tuple(xin.shape), tuple(out.shape))
+        nz = mod.materialize_noise(sample, tuple(xin.shape), tuple(out.shape), xin.dtype)
         mu, rho = mod._w()
         if mod._op.nd == 0:
             op = dict(kind="linear")

@@ -108,9 +108,15 @@ def one(prec, iters, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64
     layer.precision = prec
     x = torch.randn(bs, cin, hw, hw, device=dev).to(act).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
+        layer._forward_hip(x, sample_idx=0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for i in range(iters):
             layer._forward_hip(x, sample_idx=i)
+        e1.record()
     torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
 
 
 if __name__ == "__main__":
@@ -120,9 +126,11 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shape", default="64,64,56,1,3")
     a = ap.parse_args()
-    if "one" in a.what:
+    if "one" in a.what or "timeone" in a.what:
         c = [int(v) for v in a.shape.split(",")]
-        one(a.prec.split(",")[0], a.iters, *c)
+        us = one(a.prec.split(",")[0], a.iters, *c)
+        if "timeone" in a.what:
+            print("shape %s: %.1f us / launch" % (a.shape, us))
     if "parity" in a.what:
         parity()
     if "perf" in a.what:

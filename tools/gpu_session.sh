@@ -22,6 +22,8 @@ for step in "$@"; do
               i=$((i+1))
               timeout 600 rocprofv3 --pmc $set --kernel-trace -d "$R/gpurun_out/pmc$i" -o pmc -- python "$R/tools/gpu_diag.py" one --prec bf16 --iters 6 > "$R/gpurun_out/pmc$i.log" 2>&1; echo "pmc$i rc=$?"
             done; cd "$R" ;;
+    ablate) for d in 0 1 2 4 8 16 17 18 19 27 31; do echo "== BTX_DBG=$d"; BTX_DBG=$d timeout 300 python tools/gpu_diag.py timeone --prec bf16 --iters 20; done > gpurun_out/ablate.log 2>&1; echo "ablate rc=$?" ;;
+    variants) for f in build_variants/libbtx_*.so; do for sh in 64,64,56,1,3 256,256,14,1,3; do echo -n "$(basename $f) "; BTX_LIB=$PWD/$f timeout 300 python tools/gpu_diag.py timeone --prec bf16 --iters 30 --shape $sh 2>&1 | grep shape; done; done > gpurun_out/variants.log 2>&1; echo "variants rc=$?" ;;
     prof)   cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$OLDPWD" ;;
   esac
 done
