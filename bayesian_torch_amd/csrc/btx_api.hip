@@ -327,6 +327,11 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
     rc = make_plan(g, prec, flags, DBM, &pl);
     if (rc) return rc;
   }
+  int out_bf16 = (act_dtype == BTX_ACT_BF16) ? 1 : 0;
+  if (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_OUT_BF16)) {
+    if (!dma) return BTX_E_UNSUPPORTED;
+    out_bf16 = (flags & BTX_FLAG_OUT_BF16) ? 1 : 0;
+  }
   const size_t need = plan_ws(pl, g);
   if (need && (!ws || ws_bytes < need)) return BTX_E_WORKSPACE;
   if (need && (((uintptr_t)ws) & 15)) return BTX_E_ALIGN;
@@ -347,6 +352,7 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
   p.M = pl.M; p.K = pl.K;
   p.mtiles = pl.mtiles; p.ntiles = pl.ntiles; p.groups = g->groups; p.ksplits = pl.ksplits; p.kper = pl.kper;
   p.transposed = (flags & BTX_FLAG_TRANSPOSED) ? 1 : 0;
+  p.out_bf16 = out_bf16;
   if (rowfuse) {  // K = KH*(KW*C) unchanged; the pixel stride p.C stays C
     p.Cg = g->KW * g->C;
     p.KW = 1;
@@ -378,7 +384,7 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
     long long blocks = (total / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (act_dtype == BTX_ACT_BF16)
+    if (out_bf16)
       hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, (const float*)ws,
                          (__bf16*)out, total, pl.ksplits);
     else

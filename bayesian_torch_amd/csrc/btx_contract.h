@@ -77,6 +77,7 @@ struct ContractParams {
   int transposed;
   uint32_t seed_lo, seed_hi, sample, layer;
   uint32_t kin_a, kin_b, kout_a, kout_b;
+  int out_bf16;        // output element type: 1 bf16, 0 f32 (DMA variant; the others store the activation dtype)
   int sign_unaligned;  // DMA variant: a stage's elements may straddle two 32-sign words (row-fused stems)
   uint32_t dbg;  // BTX_DBG ablation bits (measurement only; 0 in production)
   uint32_t x_bytes, w_bytes;  // sizes of x and of mu/rho in bytes (buffer descriptors of the DMA variant)

@@ -540,18 +540,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
           }
-        } else {
-          ACT* dst = (ACT*)p.out + orow + c0;
+        } else if (p.out_bf16) {
+          __bf16* dst = (__bf16*)p.out + orow + c0;
           if (vec) {
-            if constexpr (sizeof(ACT) == 4) {
-              *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-            } else {
-              f32x4 fv = {v[0], v[1], v[2], v[3]};
-              *(bf16x4*)dst = __builtin_convertvector(fv, bf16x4);
-            }
+            f32x4 fv = {v[0], v[1], v[2], v[3]};
+            *(bf16x4*)dst = __builtin_convertvector(fv, bf16x4);
           } else {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = (ACT)v[rr];
+            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = (__bf16)v[rr];
+          }
+        } else {
+          float* dst = (float*)p.out + orow + c0;
+          if (vec) {
+            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
           }
         }
       }

@@ -182,7 +182,7 @@ def _sign_to_int8_cl(s, op):
 
 
 def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_id, prec=None, noise=None,
-                 extra_flags=0):
+                 extra_flags=0, out_dtype=None):
     """One fused sample-and-contract forward on the GPU (btx_contract_fwd).  `mu_p`/`rho_p` are GEMM-major packed.
     `noise` (parity mode) = dict with optional eps_w (logical weight layout), eps_b, sign_in, sign_out."""
     L = _lib.lib()
@@ -209,7 +209,9 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     g.od, g.oh, g.ow = op.output_padding
     g.groups = op.groups
     flags = (_lib.FLAG_TRANSPOSED if op.transposed else 0) | extra_flags
-    out = _alloc_out(op, nb, out_sp, x.dtype, x.device)
+    if out_dtype is not None and out_dtype != x.dtype:
+        flags |= _lib.FLAG_OUT_BF16 if out_dtype == torch.bfloat16 else _lib.FLAG_OUT_F32
+    out = _alloc_out(op, nb, out_sp, out_dtype or x.dtype, x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     need = L.btx_contract_workspace_bytes(ctypes.byref(g), kind, act, prec_c, flags)
     ws = _workspace(x.device, need, stream) if need else None
@@ -277,43 +279,46 @@ def kl_hip(mu, rho, prior_mu, prior_sigma, prior_mu_t=None, prior_sigma_t=None, 
     return out
 
 
-def rowfuse_plan(op, x_shape, prec, x_dtype):
-    """Geometry of the row-fused execution of a small-C 2-D stem conv (BTX_FLAG_ROWFUSE), or None.
-    The input is zero-padded to NHWC4 with the conv padding materialised, the kernel row is padded to 8 taps:
-    one K-stage of the DMA kernel = one kernel row = 8 pixels x 4 channels = 64 contiguous bytes (bf16)."""
+def rowfuse_plan(op, x_shape):
+    """Geometry of the row-fused execution of a small-C 2-D stem conv (BTX_FLAG_ROWFUSE), or None.  Decided by the
+    layer geometry ONLY (never by dtypes), because the BTX-RNG index space of the layer follows this layout.
+    The input is zero-padded to [N][Hp][Wp][cp] with the conv padding materialised and the kernel row padded to kwp
+    taps; one kernel row = kwp*cp contiguous elements = a whole number of K-stages of the LDS-DMA kernel.
+    Even stride_w: cp=4 (8-byte pixels stay 16-byte aligned), else cp=8."""
     if op.nd != 2 or op.transposed or op.groups != 1 or op.in_channels > 4 or op.dilation != (1, 1, 1):
         return None
     kh, kw = op.kernel[1], op.kernel[2]
     sh, sw = op.stride[1], op.stride[2]
-    bf16 = x_dtype == torch.bfloat16
-    if (prec == "bf16") != bf16 or kw > 8 or (bf16 and sw % 2):
+    if kw > 8:
         return None
+    if sw % 2 == 0:
+        cp, kwp = 4, 8
+    else:
+        cp, kwp = 8, (4 if kw <= 4 else 8)
     ph, pw = op.padding[1], op.padding[2]
     H, W = x_shape[2], x_shape[3]
     Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
-    Wp = (Wo - 1) * sw + 8
-    Wp += Wp % 2                                # row pitch (Wp*4 elements) must be a multiple of 16 bytes
-    Wp = max(Wp, W + 2 * pw)
-    Wp += Wp % 2
+    Wp = max((Wo - 1) * sw + kwp, W + 2 * pw)
+    Wp += Wp % 2          # row pitch a multiple of 16 bytes for cp=4 bf16
     Hp = H + 2 * ph
-    fop = OpDesc(2, 4, op.out_channels, (kh, 8), (sh, sw), 0, 1, 1)
-    return dict(op=fop, Hp=Hp, Wp=Wp, ph=ph, pw=pw, Ho=Ho, Wo=Wo, kw=kw, cin=op.in_channels)
+    fop = OpDesc(2, cp, op.out_channels, (kh, kwp), (sh, sw), 0, 1, 1)
+    return dict(op=fop, Hp=Hp, Wp=Wp, ph=ph, pw=pw, Ho=Ho, Wo=Wo, kw=kw, kwp=kwp, cp=cp, cin=op.in_channels)
 
 
 def rowfuse_input(x, plan):
-    """logical [N,C,H,W] -> zero-padded logical [N,4,Hp,Wp] stored channels-last (NHWC4)"""
+    """logical [N,C,H,W] -> zero-padded logical [N,cp,Hp,Wp] stored channels-last"""
     n, c, h, w = x.shape
-    xp = F.pad(x.permute(0, 2, 3, 1), (0, 4 - c, plan["pw"], plan["Wp"] - w - plan["pw"], plan["ph"],
+    xp = F.pad(x.permute(0, 2, 3, 1), (0, plan["cp"] - c, plan["pw"], plan["Wp"] - w - plan["pw"], plan["ph"],
                                        plan["Hp"] - h - plan["ph"]))
     return xp.permute(0, 3, 1, 2)
 
 
 def rowfuse_weights(mu_p, rho_p, plan):
-    """GEMM-major [Cout,KH,KW,C] -> [Cout,KH,8,4]; the padded taps meet real pixels, so they must contribute
+    """GEMM-major [Cout,KH,KW,C] -> [Cout,KH,kwp,cp]; the padded taps meet real pixels, so they must contribute
     exactly nothing: mu = 0 and rho = -1e30 (softplus -> 0)."""
     kw, c = plan["kw"], plan["cin"]
-    mu_f = F.pad(mu_p, (0, 4 - c, 0, 8 - kw))
-    rho_f = F.pad(rho_p, (0, 4 - c, 0, 8 - kw), value=-1e30)
+    mu_f = F.pad(mu_p, (0, plan["cp"] - c, 0, plan["kwp"] - kw))
+    rho_f = F.pad(rho_p, (0, plan["cp"] - c, 0, plan["kwp"] - kw), value=-1e30)
     return mu_f, rho_f
 
 

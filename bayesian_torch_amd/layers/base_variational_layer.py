@@ -226,8 +226,12 @@ class _VariationalNd(BaseVariationalLayer_):
         plan = self._rowfuse_plan(x) if noise is None else None
         if plan is not None:  # small-C stem: one kernel row per K-stage on the LDS-DMA kernel
             mu_f, rho_f = BF.rowfuse_weights(mu_p, rho_p, plan)
-            out = BF.contract_hip(kind, BF.rowfuse_input(x, plan), mu_f, rho_f, mb, rb, plan["op"], _rng.seed(),
-                                  sample_idx, self._btx_layer_id, prec=self.precision, extra_flags=_lib.FLAG_ROWFUSE)
+            prec = self.precision or BF.get_precision()
+            # the padded copy is made in the MFMA dtype (the rounding a staging kernel would apply anyway); the
+            # output keeps the caller's activation dtype
+            xin = BF.rowfuse_input(x, plan).to(torch.bfloat16 if prec == "bf16" else torch.float32)
+            out = BF.contract_hip(kind, xin, mu_f, rho_f, mb, rb, plan["op"], _rng.seed(), sample_idx,
+                                  self._btx_layer_id, prec=prec, extra_flags=_lib.FLAG_ROWFUSE, out_dtype=x.dtype)
             return out[:, :, :plan["Ho"], :plan["Wo"]]
         if self._btx_cpad is not None and noise is None:  # explicit noise (parity mode) stays unpadded -> gather kernel
             extra = self._btx_cpad - op.in_channels
@@ -241,7 +245,7 @@ class _VariationalNd(BaseVariationalLayer_):
     def _rowfuse_plan(self, x):
         if self._op.nd != 2 or self._op.in_channels > 4 or not x.is_cuda:
             return None
-        return BF.rowfuse_plan(self._op, tuple(x.shape), self.precision or BF.get_precision(), x.dtype)
+        return BF.rowfuse_plan(self._op, tuple(x.shape))
 
     def materialize_noise(self, sample_idx, x_shape=None, out_shape=None, x_dtype=None):
         """The noise BTX-RNG v1 defines for MC sample `sample_idx` of this layer, in the reference's logical
@@ -251,12 +255,12 @@ class _VariationalNd(BaseVariationalLayer_):
         op, seed, lid = self._op, _rng.seed(), self._btx_layer_id
         cin, cpad = op.in_channels, self._btx_cpad
         plan = None
-        if x_shape is not None and x_dtype is not None and op.nd == 2 and cin <= 4:
-            plan = BF.rowfuse_plan(op, tuple(x_shape), self.precision or BF.get_precision(), x_dtype)
-        if plan is not None:  # indices run over the row-fused layouts: weights [Cout][KH][8][4], input [N][Hp][Wp][4]
-            kh, kw = op.kernel[1], plan["kw"]
-            flat = BF.fill_eps_hip(mu.shape[0] * kh * 32, mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
-            e = flat.reshape(mu.shape[0], kh, 8, 4)[:, :, :kw, :cin].permute(0, 3, 1, 2).contiguous()
+        if x_shape is not None and op.nd == 2 and cin <= 4:
+            plan = BF.rowfuse_plan(op, tuple(x_shape))
+        if plan is not None:  # indices run over the row-fused layouts: weights [Cout][KH][kwp][cp], input [N][Hp][Wp][cp]
+            kh, kw, kwp, cp = op.kernel[1], plan["kw"], plan["kwp"], plan["cp"]
+            flat = BF.fill_eps_hip(mu.shape[0] * kh * kwp * cp, mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+            e = flat.reshape(mu.shape[0], kh, kwp, cp)[:, :, :kw, :cin].permute(0, 3, 1, 2).contiguous()
             d = {"eps_w": e}
             getattr(self, "eps_" + self._wn).copy_(e)
             if self.mu_bias is not None:
@@ -264,8 +268,8 @@ class _VariationalNd(BaseVariationalLayer_):
                 self.eps_bias.copy_(d["eps_b"])
             if self._family == "flipout":
                 n, _, h, w = x_shape
-                sp = BF.fill_sign_hip(n * plan["Hp"] * plan["Wp"] * 4, mu.device, seed, sample_idx, lid,
-                                      _lib.STREAM_SIGN_IN).reshape(n, plan["Hp"], plan["Wp"], 4)
+                sp = BF.fill_sign_hip(n * plan["Hp"] * plan["Wp"] * cp, mu.device, seed, sample_idx, lid,
+                                      _lib.STREAM_SIGN_IN).reshape(n, plan["Hp"], plan["Wp"], cp)
                 d["sign_in"] = sp[:, plan["ph"]:plan["ph"] + h, plan["pw"]:plan["pw"] + w, :cin].permute(0, 3, 1, 2)
                 # the kernel's output tensor is [N][Ho'][Wo'][Cout] with Wo' possibly wider than Wo
                 fo = plan["op"].out_spatial((1, plan["Hp"], plan["Wp"]))

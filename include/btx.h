@@ -65,6 +65,8 @@ extern "C" {
                                      groups=1, dil_w=1, pad_w=0 (padding materialised by the caller), C*KW a multiple
                                      of the stage (32 bf16 / 16 f32 elements), activation dtype == precision dtype;
                                      returns BTX_E_UNSUPPORTED otherwise. */
+#define BTX_FLAG_OUT_F32      8u  /* store the output as f32 / bf16 regardless of act_dtype (LDS-DMA kernels only: lets */
+#define BTX_FLAG_OUT_BF16    16u  /* a caller that had to copy the input anyway keep "f32 in/out, bf16 MFMA" semantics) */
 
 /* RNG streams of BTX-RNG v1 */
 #define BTX_STREAM_EPS_W    0u
