@@ -29,13 +29,18 @@ class Rng(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("sample_idx", ctypes.c_uint32), ("layer_id", ctypes.c_uint32)]
 
 
+class Epilogue(ctypes.Structure):
+    _fields_ = [("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("residual", ctypes.c_void_p),
+                ("relu", ctypes.c_int32)]
+
+
 class Noise(ctypes.Structure):
     _fields_ = [("eps_w", ctypes.c_void_p), ("eps_b", ctypes.c_void_p),
                 ("sign_in", ctypes.c_void_p), ("sign_out", ctypes.c_void_p)]
 
 
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss",
-           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
+           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
            "btx_mc_packed_floats", "btx_mc_accumulate")
 
 
@@ -68,6 +73,8 @@ def lib():
     L.btx_contract_fwd.restype = i32
     L.btx_contract_fwd.argtypes = [i32, ctypes.POINTER(Geom), vp, vp, vp, vp, vp, vp, ctypes.POINTER(Rng),
                                    ctypes.POINTER(Noise), i32, i32, u32, vp, sz, vp]
+    L.btx_contract_fwd_ex.restype = i32
+    L.btx_contract_fwd_ex.argtypes = L.btx_contract_fwd.argtypes + [ctypes.POINTER(Epilogue)]
     L.btx_out_shape.restype = i32
     L.btx_out_shape.argtypes = [ctypes.POINTER(Geom), u32] + [ctypes.POINTER(ctypes.c_int32)] * 3
     L.btx_fill_eps.restype = i32

@@ -292,6 +292,14 @@ size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, i
 int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
                      const float* mu_b, const float* rho_b, void* out, const BtxRng* rng, const BtxNoise* noise,
                      int act_dtype, int prec, uint32_t flags, void* ws, size_t ws_bytes, void* stream) {
+  return btx_contract_fwd_ex(kind, g, x, mu_w, rho_w, mu_b, rho_b, out, rng, noise, act_dtype, prec, flags, ws,
+                             ws_bytes, stream, nullptr);
+}
+
+int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
+                        const float* mu_b, const float* rho_b, void* out, const BtxRng* rng, const BtxNoise* noise,
+                        int act_dtype, int prec, uint32_t flags, void* ws, size_t ws_bytes, void* stream,
+                        const BtxEpilogue* ep) {
   if (!g || !x || !mu_w || !rho_w || !out || !rng) return BTX_E_NULL;
   if ((mu_b == nullptr) != (rho_b == nullptr)) return BTX_E_NULL;
   if (kind != BTX_KIND_REPARAM && kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
@@ -353,6 +361,7 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
   p.mtiles = pl.mtiles; p.ntiles = pl.ntiles; p.groups = g->groups; p.ksplits = pl.ksplits; p.kper = pl.kper;
   p.transposed = (flags & BTX_FLAG_TRANSPOSED) ? 1 : 0;
   p.out_bf16 = out_bf16;
+  if (ep) { p.ep_scale = ep->scale; p.ep_shift = ep->shift; p.ep_res = ep->residual; p.ep_relu = ep->relu; }
   if (rowfuse) {  // K = KH*(KW*C) unchanged; the pixel stride p.C stays C
     p.Cg = g->KW * g->C;
     p.KW = 1;
@@ -386,10 +395,12 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
     if (blocks < 1) blocks = 1;
     if (out_bf16)
       hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, (const float*)ws,
-                         (__bf16*)out, total, pl.ksplits);
+                         (__bf16*)out, total, pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const __bf16*)p.ep_res,
+                         p.ep_relu);
     else
       hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)ws,
-                         (float*)out, total, pl.ksplits);
+                         (float*)out, total, pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const float*)p.ep_res,
+                         p.ep_relu);
     rc = (int)hipGetLastError();
   }
   return rc;

@@ -77,6 +77,10 @@ struct ContractParams {
   int transposed;
   uint32_t seed_lo, seed_hi, sample, layer;
   uint32_t kin_a, kin_b, kout_a, kout_b;
+  const float* ep_scale;  // fused epilogue (BtxEpilogue), all nullable
+  const float* ep_shift;
+  const void* ep_res;
+  int ep_relu;
   int out_bf16;        // output element type: 1 bf16, 0 f32 (DMA variant; the others store the activation dtype)
   int sign_unaligned;  // DMA variant: a stage's elements may straddle two 32-sign words (row-fused stems)
   uint32_t dbg;  // BTX_DBG ablation bits (measurement only; 0 in production)
@@ -141,6 +145,26 @@ struct RawAct<__bf16, 4> {
     for (int i = 0; i < 2; ++i) { f[2 * i] = u2f(a[i] << 16); f[2 * i + 1] = u2f(a[i] & 0xffff0000u); }
   }
 };
+
+// fused epilogue on 4 consecutive channels starting at (row offset `o`, channel-in-tile `cl`); `aff` = LDS copy of
+// scale (at [0..BN)) and shift (at [BN..2BN)) for this n-tile, or nullptr
+template <typename OUT>
+__device__ __forceinline__ void apply_epilogue4(float* v, const ContractParams& p, const float* aff, int cl, long long o,
+                                                int nvalid) {
+  if (aff) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], aff[cl + r], aff[64 + cl + r]);
+  }
+  if (p.ep_res) {
+    const OUT* rp = (const OUT*)p.ep_res + o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (r < nvalid) v[r] += (float)rp[r];
+  }
+  if (p.ep_relu) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+  }
+}
 
 // position of granule-local element e in the pre-shifted sign word (see btx_rng.h)
 __device__ __forceinline__ int ws_bit(int e) { return ((e & 1) ? 31 : 15) - (e >> 1); }
@@ -499,6 +523,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
     }
     __syncthreads();
   }
+  const bool has_aff = (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
+  float* aff_lds = bias_lds + 2 * BN;
+  if (has_aff) {
+    if (tid < BN) {
+      const int col = ntile * BN + tid;
+      const int gcol = group * p.Ng + (col < p.Ng ? col : 0);
+      aff_lds[tid] = p.ep_scale ? p.ep_scale[gcol] : 1.f;
+      aff_lds[BN + tid] = p.ep_shift ? p.ep_shift[gcol] : 0.f;
+    }
+    __syncthreads();
+  }
   const int colbase = ntile * BN + wv_n * 32;  // within the group
   if (colbase < p.Ng) {
 #pragma unroll
@@ -552,6 +587,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
             for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
           }
         } else {
+          apply_epilogue4<ACT>(v, p, has_aff ? aff_lds : nullptr, cl, orow + c0, p.Ng - c0);
           ACT* dst = (ACT*)p.out + orow + c0;
           if (vec) {
             if constexpr (sizeof(ACT) == 4) {
@@ -570,23 +606,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
   }
 }
 
-// Second pass of split-K: out[i] = sum_s partial[s][i], converted to the activation dtype.
+// Second pass of split-K: out[i] = epilogue(sum_s partial[s][i]), converted to the output dtype.
 template <typename ACT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, ACT* __restrict__ out,
-                                                           long long total, int ksplits) {
+                                                           long long total, int ksplits, int N,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const ACT* __restrict__ res, int relu) {
   const long long stride = (long long)gridDim.x * blockDim.x * 4;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += stride) {
-    if (i + 3 < total) {
+    const int nv = (int)((total - i) < 4 ? (total - i) : 4);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nv == 4) {
       f32x4 acc = *(const f32x4*)(partial + i);
       for (int s = 1; s < ksplits; ++s) acc += *(const f32x4*)(partial + (long long)s * total + i);
-      if constexpr (sizeof(ACT) == 4) *(f32x4*)(out + i) = acc;
-      else *(bf16x4*)(out + i) = __builtin_convertvector(acc, bf16x4);
+      a[0] = acc[0]; a[1] = acc[1]; a[2] = acc[2]; a[3] = acc[3];
     } else {
-      for (long long j = i; j < total; ++j) {
-        float a = partial[j];
-        for (int s = 1; s < ksplits; ++s) a += partial[(long long)s * total + j];
-        out[j] = (ACT)a;
-      }
+      for (int r = 0; r < nv; ++r)
+        for (int s = 0; s < ksplits; ++s) a[r] += partial[(long long)s * total + i + r];
+    }
+    for (int r = 0; r < nv; ++r) {
+      const int col = (int)((i + r) % N);
+      float v = a[r];
+      v = __builtin_fmaf(v, scale ? scale[col] : 1.f, shift ? shift[col] : 0.f);
+      if (res) v += (float)res[i + r];
+      if (relu) v = v > 0.f ? v : 0.f;
+      a[r] = v;
+    }
+    if (nv == 4) {
+      if constexpr (sizeof(ACT) == 4) *(f32x4*)(out + i) = (f32x4){a[0], a[1], a[2], a[3]};
+      else *(bf16x4*)(out + i) = __builtin_convertvector((f32x4){a[0], a[1], a[2], a[3]}, bf16x4);
+    } else {
+      for (int r = 0; r < nv; ++r) out[i + r] = (ACT)a[r];
     }
   }
 }

@@ -487,6 +487,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     }
     __syncthreads();
   }
+  const bool has_aff = (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
+  float* aff_lds = bias_lds + 2 * BN;
+  if (has_aff) {
+    if (tid < BN) {
+      const int col = ntile * BN + tid;
+      const int gcol = group * p.Ng + (col < p.Ng ? col : 0);
+      aff_lds[tid] = p.ep_scale ? p.ep_scale[gcol] : 1.f;
+      aff_lds[BN + tid] = p.ep_shift ? p.ep_shift[gcol] : 0.f;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const int mo = mtile * DBM + wave * 64 + mi * 32 + l31;
@@ -541,6 +552,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
             for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
           }
         } else if (p.out_bf16) {
+          apply_epilogue4<__bf16>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0);
           __bf16* dst = (__bf16*)p.out + orow + c0;
           if (vec) {
             f32x4 fv = {v[0], v[1], v[2], v[3]};
@@ -550,6 +562,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
             for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = (__bf16)v[rr];
           }
         } else {
+          apply_epilogue4<float>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0);
           float* dst = (float*)p.out + orow + c0;
           if (vec) {
             *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};

@@ -182,7 +182,7 @@ def _sign_to_int8_cl(s, op):
 
 
 def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_id, prec=None, noise=None,
-                 extra_flags=0, out_dtype=None):
+                 extra_flags=0, out_dtype=None, epilogue=None):
     """One fused sample-and-contract forward on the GPU (btx_contract_fwd).  `mu_p`/`rho_p` are GEMM-major packed.
     `noise` (parity mode) = dict with optional eps_w (logical weight layout), eps_b, sign_in, sign_out."""
     L = _lib.lib()
@@ -239,12 +239,33 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     if _LAUNCH_LOG is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record(torch.cuda.current_stream(x.device))
-    rc = L.btx_contract_fwd(kind, ctypes.byref(g), xp.data_ptr(), mu_p.data_ptr(), rho_p.data_ptr(),
-                            mu_b.data_ptr() if mu_b is not None else None,
-                            rho_b.data_ptr() if rho_b is not None else None,
-                            out.data_ptr(), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None,
-                            act, prec_c, flags, ws.data_ptr() if ws is not None else None,
-                            ws.numel() if ws is not None else 0, stream)
+    ep = None
+    if epilogue is not None:  # dict(scale, shift, residual, relu): eval-BN / residual / ReLU folded into the store
+        ep = _lib.Epilogue()
+        for name in ("scale", "shift"):
+            t = epilogue.get(name)
+            if t is not None:
+                if t.dtype != torch.float32 or t.numel() != op.out_channels or not t.is_contiguous():
+                    raise ValueError("epilogue %s must be a contiguous float32 [out_channels] tensor" % name)
+                keep.append(t)
+                setattr(ep, name, t.data_ptr())
+        res = epilogue.get("residual")
+        if res is not None:
+            if op.nd == 0:
+                res = res.reshape(-1, op.out_channels)
+            rp, _, _, _ = _to_channels_last(res, OpDesc(op.nd, op.out_channels, op.out_channels))
+            if rp.dtype != out.dtype or rp.numel() != out.numel():
+                raise ValueError("epilogue residual must match the output shape and dtype")
+            keep.append(rp)
+            ep.residual = rp.data_ptr()
+        ep.relu = 1 if epilogue.get("relu") else 0
+    rc = L.btx_contract_fwd_ex(kind, ctypes.byref(g), xp.data_ptr(), mu_p.data_ptr(), rho_p.data_ptr(),
+                               mu_b.data_ptr() if mu_b is not None else None,
+                               rho_b.data_ptr() if rho_b is not None else None,
+                               out.data_ptr(), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None,
+                               act, prec_c, flags, ws.data_ptr() if ws is not None else None,
+                               ws.numel() if ws is not None else 0, stream,
+                               ctypes.byref(ep) if ep is not None else None)
     _lib.check(rc)
     if ev0 is not None:
         ev1 = torch.cuda.Event(enable_timing=True)

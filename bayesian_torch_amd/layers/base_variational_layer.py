@@ -213,7 +213,7 @@ class _VariationalNd(BaseVariationalLayer_):
         return self._forward_aten(input, return_kl)
 
     # ---- MI355X path -----------------------------------------------------------------------------------------
-    def _forward_hip(self, x, noise=None, sample_idx=None):
+    def _forward_hip(self, x, noise=None, sample_idx=None, epilogue=None):
         mu, rho = self._w()
         mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
         if sample_idx is None:
@@ -230,8 +230,12 @@ class _VariationalNd(BaseVariationalLayer_):
             # the padded copy is made in the MFMA dtype (the rounding a staging kernel would apply anyway); the
             # output keeps the caller's activation dtype
             xin = BF.rowfuse_input(x, plan).to(torch.bfloat16 if prec == "bf16" else torch.float32)
+            fo = plan["op"].out_spatial((1, plan["Hp"], plan["Wp"]))
+            if epilogue is not None and epilogue.get("residual") is not None and fo[2] != plan["Wo"]:
+                raise _lib.BtxError("residual epilogue is not available for this row-fused stem geometry")
             out = BF.contract_hip(kind, xin, mu_f, rho_f, mb, rb, plan["op"], _rng.seed(), sample_idx,
-                                  self._btx_layer_id, prec=prec, extra_flags=_lib.FLAG_ROWFUSE, out_dtype=x.dtype)
+                                  self._btx_layer_id, prec=prec, extra_flags=_lib.FLAG_ROWFUSE, out_dtype=x.dtype,
+                                  epilogue=epilogue)
             return out[:, :, :plan["Ho"], :plan["Wo"]]
         if self._btx_cpad is not None and noise is None:  # explicit noise (parity mode) stays unpadded -> gather kernel
             extra = self._btx_cpad - op.in_channels
@@ -240,7 +244,23 @@ class _VariationalNd(BaseVariationalLayer_):
             rho_p = torch.nn.functional.pad(rho_p, (0, extra))
             op = self._op_pad
         return BF.contract_hip(kind, x, mu_p, rho_p, mb, rb, op, _rng.seed(), sample_idx,
-                               self._btx_layer_id, prec=self.precision, noise=noise)
+                               self._btx_layer_id, prec=self.precision, noise=noise, epilogue=epilogue)
+
+    def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False):
+        """`relu?(forward(x) * scale[c] + shift[c] (+ residual))` with the affine / residual / ReLU
+        folded into the store of the HIP contraction (eval-mode BatchNorm folds into scale/shift).  Returns `out` only.
+        CPU tensors / autograd evaluate the same expression with ATen ops."""
+        if self._use_hip(x):
+            return self._forward_hip(x, epilogue=dict(scale=scale, shift=shift, residual=residual, relu=relu))
+        out = self._forward_aten(x, False)
+        shape = (1, -1) + (1,) * self._op.nd if self._op.nd else (1, -1)
+        if scale is not None:
+            out = out * scale.view(shape).to(out.dtype)
+        if shift is not None:
+            out = out + shift.view(shape).to(out.dtype)
+        if residual is not None:
+            out = out + residual
+        return torch.relu(out) if relu else out
 
     def _rowfuse_plan(self, x):
         if self._op.nd != 2 or self._op.in_channels > 4 or not x.is_cuda:

@@ -1,0 +1,90 @@
+"""Eval-mode BatchNorm (+ residual, + ReLU) folded into the variational convolutions of a ResNet — SURVEY §8(f)-3,
+"the step either side of the path" (reference block structure: models/deterministic/resnet_large.py:46-62, 85-105,
+156-171).  `fuse_resnet(model)` rewrites, in place, every block that looks like a torchvision BasicBlock / Bottleneck
+(conv1,bn1,conv2,bn2[,conv3,bn3],downsample) whose convs are variational layers, and the stem (conv1,bn1,relu).
+BatchNorm statistics are folded ONCE into (scale, shift) buffers: call again after changing BN parameters.  Only for
+inference (`model.eval()`); the unfused model is the parity reference (tests/test_gpu_model.py).
+"""
+import types
+
+import torch
+import torch.nn as nn
+
+
+def fold_bn(bn):
+    """eval-mode BatchNorm as y = x*scale + shift (f32)"""
+    with torch.no_grad():
+        w = bn.weight.float() if bn.weight is not None else torch.ones_like(bn.running_var, dtype=torch.float32)
+        b = bn.bias.float() if bn.bias is not None else torch.zeros_like(bn.running_var, dtype=torch.float32)
+        scale = w / torch.sqrt(bn.running_var.float() + bn.eps)
+        shift = b - bn.running_mean.float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _is_var(m):
+    return hasattr(m, "forward_fused")
+
+
+class _Folded(nn.Module):
+    """conv (variational) + folded BN; keeps the BN module for state_dict compatibility but never calls it"""
+
+    def __init__(self, conv, bn):
+        super().__init__()
+        self.conv, self.bn = conv, bn
+        s, b = fold_bn(bn)
+        self.register_buffer("scale", s, persistent=False)
+        self.register_buffer("shift", b, persistent=False)
+
+    def forward(self, x, residual=None, relu=False):
+        return self.conv.forward_fused(x, self.scale, self.shift, residual, relu)
+
+
+def _basic_forward(self, x):
+    idt = x if self.downsample is None else self.downsample(x)
+    y = self._f1(x, None, True)
+    return self._f2(y, idt, True)
+
+
+def _bottleneck_forward(self, x):
+    idt = x if self.downsample is None else self.downsample(x)
+    y = self._f1(x, None, True)
+    y = self._f2(y, None, True)
+    return self._f3(y, idt, True)
+
+
+class _FoldedDownsample(nn.Module):
+    def __init__(self, seq):
+        super().__init__()
+        self.f = _Folded(seq[0], seq[1])
+
+    def forward(self, x):
+        return self.f(x)
+
+
+def fuse_resnet(model):
+    n = 0
+    for m in model.modules():
+        names = [k for k in ("conv1", "bn1", "conv2", "bn2") if hasattr(m, k)]
+        if len(names) == 4 and hasattr(m, "downsample") and _is_var(m.conv1) and _is_var(m.conv2):
+            m._f1, m._f2 = _Folded(m.conv1, m.bn1), _Folded(m.conv2, m.bn2)
+            if hasattr(m, "conv3") and _is_var(m.conv3):
+                m._f3 = _Folded(m.conv3, m.bn3)
+                m.forward = types.MethodType(_bottleneck_forward, m)
+            else:
+                m.forward = types.MethodType(_basic_forward, m)
+            ds = m.downsample
+            if isinstance(ds, nn.Sequential) and len(ds) == 2 and _is_var(ds[0]) and isinstance(ds[1], nn.BatchNorm2d):
+                m.downsample = _FoldedDownsample(ds)
+            n += 1
+    # stem: conv1 -> bn1 -> relu -> maxpool
+    if hasattr(model, "conv1") and hasattr(model, "bn1") and hasattr(model, "maxpool") and _is_var(model.conv1):
+        model._stem = _Folded(model.conv1, model.bn1)
+
+        def fwd(self, x):
+            x = self.maxpool(self._stem(x, None, True))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            x = self.avgpool(x)
+            return self.fc(x.flatten(1))
+        model.forward = types.MethodType(fwd, model)
+        n += 1
+    return n

@@ -34,7 +34,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/M
 KL_KNOWN = 55.67487335205078  # reference get_kl_loss(dnn_to_bnn(resnet18)), default init, seed 0
 
 
-def build_model(typ, device, act_dtype):
+def build_model(typ, device, act_dtype, fuse=True):
     import bayesian_torch_amd as bt
     from bayesian_torch_amd.models.resnet import resnet18
     torch.manual_seed(0)
@@ -49,6 +49,10 @@ def build_model(typ, device, act_dtype):
             if isinstance(mod, torch.nn.BatchNorm2d):
                 mod.to(torch.bfloat16)
     bt.assign_layer_ids(m)
+    if fuse:
+        # eval-mode BN (+ residual + ReLU) folded into the store of the contraction kernels
+        from bayesian_torch_amd.models.fuse import fuse_resnet
+        fuse_resnet(m)
     return m
 
 
@@ -93,6 +97,7 @@ def main():
     ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--act", default=None, choices=["bf16", "f32"], help="activation dtype (default = --prec)")
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/residual as separate torch ops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     args = ap.parse_args()
@@ -115,7 +120,7 @@ def main():
     bt.manual_seed(2024)
     bt.set_precision(args.prec)
     act_dtype = torch.bfloat16 if act == "bf16" else torch.float32
-    model = build_model(args.type, dev, act_dtype)
+    model = build_model(args.type, dev, act_dtype, fuse=not args.no_fuse)
     torch.manual_seed(1234)
     x = torch.randn(args.batch, 3, 224, 224).to(dev).to(act_dtype)
 
@@ -196,7 +201,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "dnn_to_bnn(ResNet18) %s, 224x224, batch %d, %d MC samples per GPU, default init "
-                                   "(seed 0), activations %s" % (args.type, args.batch, args.steps, act),
+                                   "(seed 0), activations %s, eval-BN/ReLU/residual %s" % (
+                                       args.type, args.batch, args.steps, act,
+                                       "as torch ops" if args.no_fuse else "folded into the kernel epilogue"),
                        "global_batch": args.batch * world, "parallelism": "mc-sample-shard x%d" % world},
             "image_samples_per_s": args.batch * args.steps * world / elapsed,
             "kl": kl, "kl_rel_err": abs(kl - KL_KNOWN) / KL_KNOWN,

@@ -140,6 +140,25 @@ int btx_contract_fwd(int kind, const BtxGeom* g,
                      int act_dtype, int prec, uint32_t flags,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* §8(f)-3, the step either side of the path: eval-mode BatchNorm (+ residual add, + ReLU) folded into the store of the
+ * contraction (reference models/deterministic/resnet_large.py:49-60: out = relu(bn(conv(x)) [+ identity])).
+ *   y = conv_out * scale[n] + shift[n]  (+ residual[same index as out])  ;  y = max(y, 0) if relu
+ * scale/shift: f32 [N] (NULL => 1 / 0); residual: same layout and dtype as `out` (NULL => none). */
+typedef struct BtxEpilogue {
+  const float* scale;
+  const float* shift;
+  const void*  residual;
+  int32_t      relu;
+} BtxEpilogue;
+int btx_contract_fwd_ex(int kind, const BtxGeom* g,
+                        const void* x, const float* mu_w, const float* rho_w,
+                        const float* mu_b, const float* rho_b,
+                        void* out,
+                        const BtxRng* rng, const BtxNoise* noise /* nullable */,
+                        int act_dtype, int prec, uint32_t flags,
+                        void* ws, size_t ws_bytes, void* stream,
+                        const BtxEpilogue* epilogue /* nullable */);
+
 /* Output spatial extent for a geometry (same arithmetic as torch's conv / conv_transpose). */
 int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, int32_t* Wo);
 

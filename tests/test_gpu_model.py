@@ -120,6 +120,69 @@ def test_bf16_throughput_mode_close_to_f32_mode():
     assert err < 3e-2, err  # 21 stacked bf16-input layers
 
 
+@pytest.mark.parametrize("prec,act,tol", [("f32", torch.float32, 2e-6), ("bf16", torch.bfloat16, 6e-3)])
+def test_fused_epilogue_matches_unfused_layer(prec, act, tol):
+    """scale/shift/residual/ReLU folded into the store == the same ops applied by torch afterwards
+    (same MC sample -> same noise); covers the DMA kernel, the split-K reduce pass, the register kernel and a stem"""
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    cases = [(L.Conv2dFlipout, dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=False), (4, 64, 28, 28)),
+             (L.Conv2dFlipout, dict(in_channels=256, out_channels=96, kernel_size=3, padding=1), (2, 256, 7, 7)),      # split-K
+             (L.Conv2dReparameterization, dict(in_channels=24, out_channels=40, kernel_size=3, padding=1), (2, 24, 10, 10)),
+             (L.Conv2dFlipout, dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 64, 64)),
+             (L.LinearFlipout, dict(in_features=512, out_features=100), (32, 512))]
+    for cls, kw, xs in cases:
+        torch.manual_seed(3)
+        layer = cls(**kw).to(dev)
+        layer.precision = prec
+        x = torch.randn(*xs, device=dev).to(act)
+        nout = kw.get("out_channels", kw.get("out_features"))
+        scale = (torch.rand(nout, device=dev) + 0.5).contiguous()
+        shift = torch.randn(nout, device=dev).contiguous()
+        with torch.no_grad():
+            layer._btx_sample = 7
+            plain = layer(x)[0].float()
+            res = torch.randn_like(plain).to(act)
+            is_stem = kw.get("in_channels", 99) <= 4
+            shape = (1, -1) + (1,) * (plain.dim() - 2)
+            ref = plain * scale.view(shape) + shift.view(shape)
+            if not is_stem:
+                ref = ref + res.float()
+            ref = torch.relu(ref)
+            layer._btx_sample = 7
+            got = layer.forward_fused(x, scale, shift, None if is_stem else res, True).float()
+        err = float((got - ref).norm() / ref.norm())
+        assert err < tol, (cls.__name__, xs, prec, err)
+        assert (got >= 0).all()
+
+
+def test_fused_resnet18_matches_unfused():
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.resnet import resnet18
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    dev = _dev()
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(PRIOR, type="Flipout"))
+    for b in m.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.running_mean.normal_(0, 0.1)
+            b.running_var.uniform_(0.5, 1.5)
+            b.weight.data.uniform_(0.5, 1.5)
+            b.bias.data.normal_(0, 0.1)
+    m = m.to(dev).eval()
+    bt.set_precision("f32")
+    x = torch.randn(2, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        bt.set_sample_index(m, 3)
+        a = m(x)
+        assert fuse_resnet(m) == 9
+        bt.set_sample_index(m, 3)
+        b = m(x)
+    err = float((a - b).norm() / a.norm())
+    assert err < 1e-4, err
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
