@@ -150,15 +150,27 @@ struct RawAct<__bf16, 4> {
 // scale (at [0..BN)) and shift (at [BN..2BN)) for this n-tile, or nullptr
 template <typename OUT>
 __device__ __forceinline__ void apply_epilogue4(float* v, const ContractParams& p, const float* aff, int cl, long long o,
-                                                int nvalid) {
+                                                int nvalid, bool vec) {
   if (aff) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(v[r], aff[cl + r], aff[64 + cl + r]);
   }
   if (p.ep_res) {
     const OUT* rp = (const OUT*)p.ep_res + o;
+    if (vec) {  // same 4-channel run, same alignment as the store: one 8-byte (bf16) / 16-byte (f32) load
+      if constexpr (sizeof(OUT) == 4) {
+        const f32x4 rv = *(const f32x4*)rp;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (r < nvalid) v[r] += (float)rp[r];
+        for (int r = 0; r < 4; ++r) v[r] += rv[r];
+      } else {
+        const u32x2 rv = *(const u32x2*)rp;
+        v[0] += u2f(rv[0] << 16); v[1] += u2f(rv[0] & 0xffff0000u);
+        v[2] += u2f(rv[1] << 16); v[3] += u2f(rv[1] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (r < nvalid) v[r] += (float)rp[r];
+    }
   }
   if (p.ep_relu) {
 #pragma unroll
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
             for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
           }
         } else {
-          apply_epilogue4<ACT>(v, p, has_aff ? aff_lds : nullptr, cl, orow + c0, p.Ng - c0);
+          apply_epilogue4<ACT>(v, p, has_aff ? aff_lds : nullptr, cl, orow + c0, p.Ng - c0, vec);
           ACT* dst = (ACT*)p.out + orow + c0;
           if (vec) {
             if constexpr (sizeof(ACT) == 4) {

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
             for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
           }
         } else if (p.out_bf16) {
-          apply_epilogue4<__bf16>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0);
+          apply_epilogue4<__bf16>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0, vec);
           __bf16* dst = (__bf16*)p.out + orow + c0;
           if (vec) {
             f32x4 fv = {v[0], v[1], v[2], v[3]};
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
             for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = (__bf16)v[rr];
           }
         } else {
-          apply_epilogue4<float>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0);
+          apply_epilogue4<float>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0, vec);
           float* dst = (float*)p.out + orow + c0;
           if (vec) {
             *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};

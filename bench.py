@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PREWARM_STEPS = 12
 KL_KNOWN = 55.67487335205078  # reference get_kl_loss(dnn_to_bnn(resnet18)), default init, seed 0
 
 
@@ -100,6 +101,7 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/residual as separate torch ops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
+    ap.add_argument("--per-step", action="store_true", help="diagnostic: print host time of every timed step to stderr")
     args = ap.parse_args()
     act = args.act or args.prec
 
@@ -140,6 +142,10 @@ def main():
         torch.cuda.synchronize(dev)
 
     with torch.no_grad():
+        # Initialisation, untimed and in addition to --warmup: the HIP runtime grows an internal pool once after
+        # ~500 kernel launches (a single 40-60 ms host stall, measured with --per-step); run past it.
+        for w in range(PREWARM_STEPS):
+            step(20_000_000 + w * world + rank)
         for w in range(args.warmup):
             step(10_000_000 + w * world + rank)
         if world > 1:
@@ -150,7 +156,10 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
+            ts = time.perf_counter()
             step(k * world + rank)
+            if args.per_step:
+                print("step %d: host %.3f ms (launch only, no sync)" % (k, 1e3 * (time.perf_counter() - ts)), file=sys.stderr)
         if world > 1:
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)
         barrier()

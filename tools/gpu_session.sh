@@ -13,6 +13,7 @@ for step in "$@"; do
     perf)   timeout 900 python tools/gpu_diag.py perf --iters 5 > gpurun_out/diag_perf.log 2>&1; echo "perf rc=$?" ;;
     bench)  timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log ;;
     bench_nofuse) timeout 900 python bench.py --steps 10 --warmup 2 --no-fuse --no-cpu-baseline > gpurun_out/bench_nofuse.log 2>&1; echo "bench_nofuse rc=$?"; tail -1 gpurun_out/bench_nofuse.log ;;
+    bench_diag) timeout 900 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --per-step > gpurun_out/bench_diag1.log 2>&1; timeout 900 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --per-step --no-launch-timing > gpurun_out/bench_diag2.log 2>&1; timeout 900 python bench.py --steps 12 --warmup 6 --no-cpu-baseline --per-step > gpurun_out/bench_diag3.log 2>&1; echo "bench_diag rc=$?" ;;
     bench_f32) timeout 900 python bench.py --steps 5 --warmup 1 --prec f32 --no-cpu-baseline > gpurun_out/bench_f32.log 2>&1; echo "bench_f32 rc=$?"; tail -1 gpurun_out/bench_f32.log ;;
     counters) rocprofv3 -L > gpurun_out/counters.txt 2>&1; echo "counters rc=$?" ;;
     pmc)    R="$PWD"; cd /tmp
