@@ -276,17 +276,94 @@ static bool dma_shape_ok(const BtxGeom* g, int act_dtype, int prec, const Plan& 
   return true;
 }
 
+// Tile plan of the patch variant (btx_contract_patch.h): stride-1 2-D convolutions with more than one tap whose
+// activations already have the contraction dtype.  Returns false when the shape is not eligible.
+struct PatchPlan {
+  int G, R, Rp, Wp, PP, NI, rtiles;
+};
+static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, Plan* pl, PatchPlan* pt) {
+  if (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_ROWFUSE)) return false;
+  if (make_plan(g, prec, flags, DBM, pl)) return false;
+  if (!dma_shape_ok(g, act_dtype, prec, *pl)) return false;
+  if (g->D != 1 || g->KD != 1 || pl->Do != 1 || g->sh != 1 || g->sw != 1) return false;
+  const int T = g->KH * g->KW;
+  if (T < 2 || T > 64) return false;
+  const int Ho = pl->Ho, Wo = pl->Wo;
+  const int Wp = Wo + (g->KW - 1) * g->dw, halo_r = (g->KH - 1) * g->dh;
+  if (Wo > DBM || Wp * (1 + halo_r) > PT_PPMAX) return false;
+  int G = 1, R;
+  if (Ho * Wo <= DBM / 2) {
+    R = Ho;
+    const int Rp = R + halo_r;
+    if (Rp * Wp > PT_PPMAX) return false;
+    G = DBM / (Ho * Wo);
+    if (G > PT_PPMAX / (Rp * Wp)) G = PT_PPMAX / (Rp * Wp);
+    if (G > g->NB) G = g->NB;
+    if (G < 1) return false;
+  } else {
+    int rmax = DBM / Wo;
+    const int rfit = PT_PPMAX / Wp - halo_r;
+    if (rfit < rmax) rmax = rfit;
+    if (rmax > Ho) rmax = Ho;
+    if (rmax < 1) return false;
+    const int nrt = (Ho + rmax - 1) / rmax;
+    R = (Ho + nrt - 1) / nrt;
+  }
+  pt->G = G; pt->R = R; pt->Rp = R + halo_r; pt->Wp = Wp; pt->PP = G * pt->Rp * Wp;
+  pt->NI = ((pt->PP + 15) / 16 + 7) / 8;
+  pt->rtiles = (Ho + R - 1) / R;
+  if (pt->PP > PT_PPMAX || pt->NI > PT_MAXNI || G * R * Wo > DBM) return false;
+  // grid: m-tiles are (image group, row tile); split-K over the channel blocks
+  const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
+  const int ncb = pl->Cg / bk;
+  pl->mtiles = ((g->NB + G - 1) / G) * pt->rtiles;
+  const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
+  int ks = 1;
+  {
+    const long long ncu = 256;
+    long long best = -1;
+    for (int c = 1; c <= ncb && c <= 32; ++c) {
+      const int per = (ncb + c - 1) / c;
+      if (c > 1 && per * T < 4) break;
+      const long long rounds = (base * c + ncu - 1) / ncu;
+      const long long cost = rounds * (per * T + 4) + (c > 1 ? 1 : 0);
+      if (best < 0 || cost < best) { best = cost; ks = c; }
+    }
+  }
+  const int per = (ncb + ks - 1) / ks;
+  pl->kper = per * bk;
+  pl->ksplits = (ncb + per - 1) / per;
+  const long long nwg = base * pl->ksplits;
+  if (nwg > 0x7fffffffLL) return false;
+  pl->nwg = (int)nwg;
+  return true;
+}
+
+// workspace of the patch variant: split-K partials (256-byte padded), then the pre-sampled weight tiles
+static size_t patch_wt_bytes(const Plan& pl, const BtxGeom* g, int kind, int prec, size_t* one) {
+  const size_t arr = (size_t)g->groups * pl.ntiles * 64 * (size_t)pl.K * (prec == BTX_PREC_BF16 ? 2 : 4);
+  if (one) *one = arr;
+  return arr * (kind == BTX_KIND_FLIPOUT ? 2 : 1);
+}
+static size_t pad256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 static size_t plan_ws(const Plan& pl, const BtxGeom* g) {
   return pl.ksplits > 1 ? (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
 }
 
 size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, int prec, uint32_t flags) {
-  (void)kind;
   Plan a, b;
   if (!g || make_plan(g, prec, flags, BM, &a) || make_plan(g, prec, flags, DBM, &b)) return 0;
-  const size_t wa = plan_ws(a, g), wb = plan_ws(b, g);  // which kernel runs also depends on pointer alignment
-  (void)act_dtype;
-  return wa > wb ? wa : wb;
+  (void)kind;
+  size_t wa = plan_ws(a, g), wb = plan_ws(b, g);  // which kernel runs also depends on pointer alignment
+  if (wb > wa) wa = wb;
+  Plan c;
+  PatchPlan pt;
+  if (make_patch_plan(g, act_dtype, prec, flags, &c, &pt)) {
+    const size_t wc = pad256(plan_ws(c, g)) + patch_wt_bytes(c, g, BTX_KIND_FLIPOUT, prec, nullptr);
+    if (wc > wa) wa = wc;
+  }
+  return wa;
 }
 
 int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
@@ -335,19 +412,39 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     rc = make_plan(g, prec, flags, DBM, &pl);
     if (rc) return rc;
   }
+  // patch variant: stride-1 2-D convolutions keep the halo'd input patch of the tile in LDS (BTX_NO_PATCH=1 disables)
+  static const bool no_patch = getenv("BTX_NO_PATCH") != nullptr;
+  PatchPlan pt;
+  bool patch = false;
+  if (dma && !rowfuse && !no_patch) {
+    Plan pp;
+    if (make_patch_plan(g, act_dtype, prec, flags, &pp, &pt)) { pl = pp; patch = true; }
+  }
   int out_bf16 = (act_dtype == BTX_ACT_BF16) ? 1 : 0;
   if (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_OUT_BF16)) {
     if (!dma) return BTX_E_UNSUPPORTED;
     out_bf16 = (flags & BTX_FLAG_OUT_BF16) ? 1 : 0;
   }
-  const size_t need = plan_ws(pl, g);
+  size_t need = plan_ws(pl, g);
+  size_t wt_off = 0, wt_one = 0, wt_all = 0;
+  if (patch) {
+    wt_off = pad256(need);
+    wt_all = patch_wt_bytes(pl, g, kind, prec, &wt_one);
+    if (wt_off + wt_all >= 0xfff00000ULL) patch = false;  // 32-bit offsets inside the descriptor
+    else need = wt_off + wt_all;
+  }
+  if (dma && !patch && pl.mtiles != (pl.M + DBM - 1) / DBM) {  // fell back after planning for the patch variant
+    rc = make_plan(g, prec, flags, DBM, &pl);
+    if (rc) return rc;
+    need = plan_ws(pl, g);
+  }
   if (need && (!ws || ws_bytes < need)) return BTX_E_WORKSPACE;
   if (need && (((uintptr_t)ws) & 15)) return BTX_E_ALIGN;
 
   ContractParams p;
   memset(&p, 0, sizeof(p));
   p.x = x; p.mu = mu_w; p.rho = rho_w; p.mu_b = mu_b; p.rho_b = rho_b; p.out = out;
-  p.partial = need ? (float*)ws : nullptr;
+  p.partial = pl.ksplits > 1 ? (float*)ws : nullptr;
   if (noise) {
     p.eps_w = noise->eps_w; p.eps_b = noise->eps_b;
     p.sign_in = noise->sign_in; p.sign_out = noise->sign_out;
@@ -381,7 +478,15 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   static const char* dbg_env = getenv("BTX_DBG");
   p.dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
   hipStream_t st = (hipStream_t)stream;
-  if (dma)
+  if (patch) {
+    p.pt_G = pt.G; p.pt_R = pt.R; p.pt_Rp = pt.Rp; p.pt_Wp = pt.Wp; p.pt_PP = pt.PP; p.pt_NI = pt.NI;
+    p.pt_rtiles = pt.rtiles;
+    p.wt = (unsigned char*)ws + wt_off;
+    p.wt_bytes = (uint32_t)wt_all;
+    p.wt_delta_off = (uint32_t)wt_one;
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg, st)
+                                 : launch_contract_patch_f32(kind, p, pl.nwg, st);
+  } else if (dma)
     rc = (prec == BTX_PREC_BF16) ? launch_contract_dma_bf16(kind, p, pl.nwg, st)
                                  : launch_contract_dma_f32(kind, p, pl.nwg, st);
   else

@@ -56,6 +56,10 @@ constexpr int WDL_OFF = WMU_OFF + NG * BN * 16;  // [NG][BN] x 16 B
 constexpr int STAGE_BYTES = WDL_OFF + NG * BN * 16;  // 28672
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // 57344
 
+// patch variant (btx_contract_patch.h)
+constexpr int PT_PPMAX = 832;  // patch pixels per LDS slot (13 x 64)
+constexpr int PT_MAXNI = 7;    // 1-KiB DMA instructions per wave per patch: ceil(832 / 16 / 8)
+
 struct ContractParams {
   const void* x;
   const float* mu;
@@ -85,6 +89,10 @@ struct ContractParams {
   int sign_unaligned;  // DMA variant: a stage's elements may straddle two 32-sign words (row-fused stems)
   uint32_t dbg;  // BTX_DBG ablation bits (measurement only; 0 in production)
   uint32_t x_bytes, w_bytes;  // sizes of x and of mu/rho in bytes (buffer descriptors of the DMA variant)
+  // patch variant (btx_contract_patch.h): tile = pt_G images x pt_R output rows x Wo; patch = pt_G x pt_Rp x pt_Wp pixels
+  int pt_G, pt_R, pt_Rp, pt_Wp, pt_PP, pt_NI, pt_rtiles;
+  void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off
+  uint32_t wt_bytes, wt_delta_off;
 };
 
 // ---- small helpers -------------------------------------------------------------------------------------
@@ -660,6 +668,8 @@ int launch_contract_bf16(int kind, int act_bf16, bool gen, const ContractParams&
 // LDS-DMA pipeline variants (btx_contract_dma.h): activation dtype == contraction dtype, granule-aligned shapes
 int launch_contract_dma_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_dma_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_patch_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_patch_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
 
 template <int PREC>
 static int launch_contract_impl(int kind, int act_bf16, bool gen, const ContractParams& p, int nwg, hipStream_t st) {

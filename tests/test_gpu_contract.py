@@ -85,6 +85,17 @@ FUSED_CASES = [
     ("LinearFlipout", dict(in_features=512, out_features=10), (256, 512)),
     ("LinearReparameterization", dict(in_features=128, out_features=64), (32, 128)),
     ("LinearFlipout", dict(in_features=512, out_features=1000), (64, 512)),
+    # patch kernel (stride-1 2-D): several row tiles per image with a ragged last tile; several images per tile with a
+    # ragged last group; asymmetric taps, dilation, no padding, groups, split over channel blocks
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=False), (2, 64, 56, 56)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=64, kernel_size=3, padding=1), (3, 32, 37, 41)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=32, kernel_size=3, padding=1), (5, 32, 14, 14)),
+    ("Conv2dFlipout", dict(in_channels=512, out_channels=128, kernel_size=3, padding=1, bias=False), (13, 512, 7, 7)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=40, kernel_size=(1, 3), padding=(0, 1)), (2, 32, 9, 30)),
+    ("Conv2dReparameterization", dict(in_channels=64, out_channels=32, kernel_size=(3, 1), padding=0), (2, 64, 19, 23)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=64, kernel_size=3, padding=0, dilation=(2, 3)), (2, 32, 25, 31)),
+    ("Conv2dReparameterization", dict(in_channels=64, out_channels=64, kernel_size=5, padding=2, groups=2), (2, 64, 30, 30)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=16, kernel_size=3, padding=1), (1, 32, 3, 200)),
     # element-wise (GEN) kernels with in-kernel noise: odd channel counts
     ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 32, 32)),
     ("LinearFlipout", dict(in_features=50, out_features=10), (7, 50)),

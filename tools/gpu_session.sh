@@ -26,6 +26,8 @@ for step in "$@"; do
             done; cd "$R" ;;
     ablate) for d in 0 1 2 4 8 16 17 18 19 27 31; do echo "== BTX_DBG=$d"; BTX_DBG=$d timeout 300 python tools/gpu_diag.py timeone --prec bf16 --iters 20; done > gpurun_out/ablate.log 2>&1; echo "ablate rc=$?" ;;
     variants) for f in build_variants/libbtx_*.so; do for sh in 64,64,56,1,3 256,256,14,1,3; do echo -n "$(basename $f) "; BTX_LIB=$PWD/$f timeout 300 python tools/gpu_diag.py timeone --prec bf16 --iters 30 --shape $sh 2>&1 | grep shape; done; done > gpurun_out/variants.log 2>&1; echo "variants rc=$?" ;;
+    patchab) for sh in 64,64,56,1,3 128,128,28,1,3 256,256,14,1,3 512,512,7,1,3; do for np in "" 1; do echo -n "NO_PATCH=$np "; env ${np:+BTX_NO_PATCH=1} timeout 120 python tools/gpu_diag.py timeone --prec bf16 --iters 30 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/patchab.log 2>&1; echo "patchab rc=$?" ;;
+    pytest_contract) timeout 900 python -m pytest tests/test_gpu_contract.py -m gpu -q -x > gpurun_out/pytest_contract.log 2>&1; echo "pytest_contract rc=$?"; tail -15 gpurun_out/pytest_contract.log ;;
     prof)   cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$OLDPWD" ;;
   esac
 done
