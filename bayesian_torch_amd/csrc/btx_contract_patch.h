@@ -27,6 +27,7 @@ namespace btx {
 
 constexpr int PT_A_STAGE = PT_PPMAX * 64;          // 53248
 constexpr int PT_S_STAGE = PT_PPMAX * 4;           // 3328
+constexpr int PT_NW = NTHREADS / 64;
 constexpr int PT_WD = 4;                           // depth of the weight-tile ring
 constexpr int PT_A_OFF = 0;                        // 2 patch slots
 constexpr int PT_S_OFF = PT_A_OFF + 2 * PT_A_STAGE;    // 106496
@@ -81,6 +82,9 @@ __global__ __launch_bounds__(256) void presample_kernel(const float* __restrict_
   }
 }
 
+#ifndef BTX_PT_ABL
+#define BTX_PT_ABL 0  // measurement-only ablation bits: 1 no MFMA, 2 no LDS fragment reads, 4 no DMA in the loop,
+#endif                // 8 no per-stage barrier, 16 no sign masks, 32 no epilogue
 #define BTX_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
   switch (n) {
@@ -189,15 +193,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
   // ---- weight loader role: wave w fetches row (w & 3) of the mu tile (w < 4) or of the delta tile (w >= 4, Flipout)
   const bool w_wave = (KIND == 1) || (wave < 4);
   const uint32_t w_base = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u + (uint32_t)lane * 16u +
-                          (wave >= 4 ? p.wt_delta_off : 0u);
+                          (wave >= 4 ? p.wt_delta_off : 0u) + (uint32_t)(wave & 3) * 1024u;
+  const int w_lds = PT_W_OFF + (wave >= 4 ? 4096 : 0) + (wave & 3) * 1024;
 
-  // stage s <-> (channel block cb_begin + s / T, tap s % T); first k of the stage = tap*Cg + cb*BK
-  auto issue_w = [&](int s) __attribute__((always_inline)) {
-    const int cbi = s / T;
-    const int tap = s - cbi * T;
-    const int k0 = tap * p.Cg + (cb_begin + cbi) * BK;
-    dma16(wt_rsrc, w_base + (uint32_t)(k0 / G + (wave & 3)) * 1024u,
-          smem + PT_W_OFF + (s & (PT_WD - 1)) * DW_STAGE + (wave >= 4 ? 4096 : 0) + (wave & 3) * 1024);
+  // Stage s <-> (channel block cb_begin + s / T, tap s % T); first k of the stage = tap*Cg + cb*BK.  Both walks over
+  // the stages (the weight fetch, three stages ahead, and the multiply) keep their position incrementally.
+  int wi_s = 0, wi_t = 0, wi_cbk = cb_begin * BK, wi_k0 = cb_begin * BK;  // next stage whose weights get fetched
+  auto issue_w_next = [&]() __attribute__((always_inline)) {
+    if (w_wave)
+      dma16(wt_rsrc, w_base + (uint32_t)(wi_k0 / G) * 1024u, smem + w_lds + (wi_s & (PT_WD - 1)) * DW_STAGE);
+    ++wi_s;
+    wi_k0 += p.Cg;
+    if (++wi_t == T) { wi_t = 0; wi_cbk += BK; wi_k0 = wi_cbk; }
   };
   // one 1-KiB piece (16 patch pixels x 64 B) of the patch of channel block `cbi` (index relative to cb_begin)
   auto issue_patch_piece = [&](int cbi, int j) __attribute__((always_inline)) {
@@ -231,57 +238,57 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
 
-  auto mma_stage = [&](int s) __attribute__((always_inline)) {
-    const int cbi = s / T;
-    const int tap = s - cbi * T;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int toff = kh * p.dh * p.pt_Wp + kw * p.dw;  // wave-uniform patch-pixel offset of the tap
+  // one K-stage: every LDS fragment of the stage is requested up front (12 x ds_read_b128 + the two sign words), the
+  // MFMAs follow in the order the data arrives
+  auto mma_stage = [&](int s, int cbi, int toff) __attribute__((always_inline)) {
     const unsigned char* as = smem + PT_A_OFF + (cbi & 1) * PT_A_STAGE;
     const unsigned char* ss = smem + PT_S_OFF + (cbi & 1) * PT_S_STAGE;
     const unsigned char* ws = smem + PT_W_OFF + (s & (PT_WD - 1)) * DW_STAGE;
-    int q[2];
+    u32x4 a[NG / 2][2], wm[NG / 2][2], wd[NG / 2][2];
     uint32_t sw[2];
+    int q[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      q[mi] = q0[mi] + toff;
-      if constexpr (KIND == 1) sw[mi] = *(const uint32_t*)(ss + q[mi] * 4);
+    for (int mi = 0; mi < 2; ++mi) q[mi] = q0[mi] + toff;
+    if constexpr (BTX_PT_ABL & 2) {
+#pragma unroll
+      for (int kk = 0; kk < NG / 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[kk][i] = (u32x4){(uint32_t)q[0], (uint32_t)kk, 3u, 4u};
+          wm[kk][i] = wd[kk][i] = (u32x4){(uint32_t)q[1], 7u, (uint32_t)s, 4u};
+        }
+      sw[0] = sw[1] = (uint32_t)s;
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < NG / 2; ++kk) {
+        const int row = 2 * kk + h;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[kk][mi] = *(const u32x4*)(as + q[mi] * 64 + ((row ^ ((q[mi] >> 2) & 3)) * 16));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) wm[kk][ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
+      }
+      if constexpr (KIND == 1) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) sw[mi] = *(const uint32_t*)(ss + q[mi] * 4);
+#pragma unroll
+        for (int kk = 0; kk < NG / 2; ++kk)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            wd[kk][ni] = *(const u32x4*)(ws + NG * BN * 16 + ((2 * kk + h) * BN + ni * 32 + l31) * 16);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < NG / 2; ++kk) {
-#ifndef BTX_NO_KK_BARRIER
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       const int row = 2 * kk + h;
-      u32x4 a[2], wq[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = *(const u32x4*)(as + q[mi] * 64 + ((row ^ ((q[mi] >> 2) & 3)) * 16));
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) wq[ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
       if constexpr (PREC == 1) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, wq[ni]), __builtin_bit_cast(bf16x8, a[mi]), accm[mi][ni], 0, 0, 0);
-        if constexpr (KIND == 1) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            wq[ni] = *(const u32x4*)(ws + NG * BN * 16 + (row * BN + ni * 32 + l31) * 16);
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            const uint32_t swr = sw[mi] << (4 * row);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) a[mi][d] ^= ((swr << d) & 0x80008000u);
+          for (int ni = 0; ni < 2; ++ni) {
+            if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(wm[kk][ni]), "v"(a[kk][mi])); accm[mi][ni][0] += 1.f; }
+            else accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, wm[kk][ni]), __builtin_bit_cast(bf16x8, a[kk][mi]), accm[mi][ni], 0, 0, 0);
           }
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                  __builtin_bit_cast(bf16x8, wq[ni]), __builtin_bit_cast(bf16x8, a[mi]), accd[mi][ni], 0, 0, 0);
-        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -289,17 +296,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-              accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wq[ni][e]), u2f(a[mi][e]), accm[mi][ni], 0, 0, 0);
-        if constexpr (KIND == 1) {
-          __builtin_amdgcn_sched_barrier(0);
+              accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wm[kk][ni][e]), u2f(a[kk][mi][e]), accm[mi][ni], 0, 0, 0);
+      }
+    }
+    if constexpr (KIND == 1) {
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            wq[ni] = *(const u32x4*)(ws + NG * BN * 16 + (row * BN + ni * 32 + l31) * 16);
+      for (int kk = 0; kk < NG / 2; ++kk) {
+        const int row = 2 * kk + h;
+        if constexpr (PREC == 1) {
+          if constexpr (!(BTX_PT_ABL & 16)) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              const uint32_t swr = sw[mi] << (4 * row);
+#pragma unroll
+              for (int d = 0; d < 4; ++d) a[kk][mi][d] ^= ((swr << d) & 0x80008000u);
+            }
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(wd[kk][ni]), "v"(a[kk][mi])); accd[mi][ni][0] += 1.f; }
+              else accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, wd[kk][ni]), __builtin_bit_cast(bf16x8, a[kk][mi]), accd[mi][ni], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
             const uint32_t swr = sw[mi] << (2 * row);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[mi][e] ^= ((swr << ((e >> 1) + ((e & 1) ? 0 : 16))) & 0x80000000u);
+            for (int e = 0; e < 4; ++e) a[kk][mi][e] ^= ((swr << ((e >> 1) + ((e & 1) ? 0 : 16))) & 0x80000000u);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -307,7 +333,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
               for (int ni = 0; ni < 2; ++ni)
-                accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wq[ni][e]), u2f(a[mi][e]), accd[mi][ni], 0, 0, 0);
+                accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wd[kk][ni][e]), u2f(a[kk][mi][e]), accd[mi][ni], 0, 0, 0);
         }
       }
     }
@@ -323,34 +349,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
     for (int j = 0; j < p.pt_NI; ++j)
       if (16 * (wave + 8 * j) < p.pt_PP) issue_patch_piece(0, j);
     write_signs(0);
-    for (int s = 0; s < PT_WD - 1 && s < nstages; ++s)
-      if (w_wave) issue_w(s);
+    for (int s = 0; s < PT_WD - 1 && s < nstages; ++s) issue_w_next();
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int nissued = 0, m1 = 0, m2 = 0, mpiece = 0;  // marks: nissued right after W(s+1), W(s+2), the last patch piece
-    int cbi = 0, t = 0;
+    int cbi = 0, t = 0, kw = 0, toff = 0, rowoff = 0;
+    const int row_step = p.dh * p.pt_Wp;
     for (int s = 0; s < nstages; ++s) {
       const bool next_cb = cbi + 1 < ncb;
       int m3 = nissued;
-      if (w_wave && s + PT_WD - 1 < nstages) { issue_w(s + PT_WD - 1); m3 = ++nissued; }
-      if (next_cb) {
+      if (!(BTX_PT_ABL & 4) && wi_s < nstages) { issue_w_next(); if (w_wave) m3 = ++nissued; }
+      if (!(BTX_PT_ABL & 4) && next_cb) {
         for (int j = t * ppst; j < (t + 1) * ppst && j < p.pt_NI; ++j)
           if (16 * (wave + 8 * j) < p.pt_PP) { issue_patch_piece(cbi + 1, j); mpiece = ++nissued; }
         if (t == 0) write_signs(cbi + 1);  // the sign slot of block cbi+1 was last read during block cbi-1
       }
-      mma_stage(s);
+      mma_stage(s, cbi, toff);
       int allowed = nissued - m1;
       if (t == T - 1 && next_cb) allowed = min(allowed, nissued - mpiece);
       wait_vmcnt(allowed);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (BTX_PT_ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       m1 = m2; m2 = m3;
-      if (++t == T) { t = 0; ++cbi; }
+      toff += p.dw;
+      if (++kw == p.KW) { kw = 0; rowoff += row_step; toff = rowoff; }
+      if (++t == T) { t = 0; ++cbi; toff = 0; rowoff = 0; }
     }
   }
+  if constexpr (BTX_PT_ABL & 32) return;
 
   // =================== epilogue ===========================================================================
+  // Stage 1: bias, Flipout combine (s_out), BN affine on the MFMA fragments; the f32 tile of the wave (64 pixels x 64
+  // channels) goes to LDS (272-byte pixel rows: conflict-free both ways).  Stage 2: every lane takes 8 consecutive
+  // channels of one pixel, adds the residual, applies ReLU, converts and stores 16 (bf16) / 32 (f32) contiguous bytes:
+  // 8 lanes cover a pixel's 64 channels, so each store instruction writes whole 128-byte lines.  (Storing straight
+  // from the fragments scatters 8-byte pieces over 64 different lines per instruction.)
+  constexpr int EP_ROW = 272;
+  constexpr int EP_WAVE = 64 * EP_ROW;  // 17408
+  static_assert(PT_NW * EP_WAVE + 1024 <= PT_LDS_BYTES, "epilogue staging does not fit");
   const bool to_partial = p.ksplits > 1;
   const bool has_bias = (split == 0) && (p.mu_b != nullptr);
-  float* bias_lds = (float*)smem;
+  float* bias_lds = (float*)(smem + PT_NW * EP_WAVE);
   if (has_bias) {
     if (tid < BN) {
       const int col = ntile * BN + tid;
@@ -366,9 +404,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
       bias_lds[tid] = bm;
       bias_lds[BN + tid] = bdl;
     }
-    __syncthreads();
   }
-  const bool has_aff = (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
+  const bool has_aff = !to_partial && ((p.ep_scale != nullptr) || (p.ep_shift != nullptr));
   float* aff_lds = bias_lds + 2 * BN;
   if (has_aff) {
     if (tid < BN) {
@@ -377,16 +414,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
       aff_lds[tid] = p.ep_scale ? p.ep_scale[gcol] : 1.f;
       aff_lds[BN + tid] = p.ep_shift ? p.ep_shift[gcol] : 0.f;
     }
-    __syncthreads();
   }
+  if (has_bias || has_aff) __syncthreads();
+  unsigned char* ep = smem + wave * EP_WAVE;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    if (out_m[mi] < 0) continue;
-    const uint32_t orow = (uint32_t)out_m[mi] * (uint32_t)p.N + (uint32_t)(group * p.Ng);
+    const uint32_t orow = (uint32_t)(out_m[mi] < 0 ? 0 : out_m[mi]) * (uint32_t)p.N + (uint32_t)(group * p.Ng);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int colbase = ntile * BN + ni * 32;
-      if (colbase >= p.Ng) continue;
       const uint32_t o0 = orow + colbase;
       const bool word_fast = (KIND == 1) && !p.sign_out && ((o0 & 31u) == 0) && (colbase + 32 <= p.Ng);
       uint32_t wout = 0;
@@ -395,7 +431,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
       for (int q = 0; q < 4; ++q) {
         const int cl = ni * 32 + 8 * q + 4 * h;
         const int c0 = ntile * BN + cl;
-        if (c0 >= p.Ng) continue;
         float v[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -406,12 +441,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
             float dl = accd[mi][ni][4 * q + rr];
             if (has_bias) dl += bias_lds[BN + cl + rr];
             uint32_t flip = 0;
-            if (col < p.Ng) {
+            if (word_fast) {
+              const int bp = ((rr & 1) ? 31 : 15) - 4 * q - 2 * h - (rr >> 1);
+              flip = (wout << (31 - bp)) & 0x80000000u;
+            } else if (col < p.Ng && out_m[mi] >= 0) {
               if (p.sign_out) {
                 flip = (p.sign_out[orow + col] < 0) ? 0x80000000u : 0u;
-              } else if (word_fast) {
-                const int bp = ((rr & 1) ? 31 : 15) - 4 * q - 2 * h - (rr >> 1);
-                flip = (wout << (31 - bp)) & 0x80000000u;
               } else {
                 const uint32_t io = orow + col;
                 const uint32_t w1 = btx_sign_word(io >> 5, p.kout_a, p.kout_b);
@@ -420,35 +455,86 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_patch_kernel(const Contr
             }
             val += u2f(f2u(dl) ^ flip);
           }
+          if (has_aff) val = __builtin_fmaf(val, aff_lds[cl + rr], aff_lds[BN + cl + rr]);
           v[rr] = val;
         }
-        const bool vec = (c0 + 3 < p.Ng) && (((orow + c0) & 3) == 0);
-        if (to_partial) {
-          float* dst = p.partial + (size_t)split * p.M * p.N + orow + c0;
-          if (vec) {
-            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-          } else {
+        *(f32x4*)(ep + (mi * 32 + l31) * EP_ROW + cl * 4) = (f32x4){v[0], v[1], v[2], v[3]};
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area is private to the wave
+  {
+    // valid pixels of the tile are a prefix of its flattened (image, row, col) order, contiguous in the output
+    const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
+    const int nvalid = nimg * nrow * p.Wo;
+    const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
+    const int cg = lane & 7;
+    const int col0 = ntile * BN + cg * 8;
+    const int nv = min(8, p.Ng - col0);
+    const bool relu = !to_partial && p.ep_relu;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
-          }
-        } else if (p.out_bf16) {
-          apply_epilogue4<__bf16>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0, vec);
-          __bf16* dst = (__bf16*)p.out + orow + c0;
-          if (vec) {
-            f32x4 fv = {v[0], v[1], v[2], v[3]};
-            *(bf16x4*)dst = __builtin_convertvector(fv, bf16x4);
-          } else {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = (__bf16)v[rr];
-          }
+    for (int r8 = 0; r8 < 8; ++r8) {
+      const int pix = r8 * 8 + (lane >> 3);
+      const int pl = wave * 64 + pix;
+      if (pl >= nvalid || nv <= 0) continue;
+      const f32x4 lo = *(const f32x4*)(ep + pix * EP_ROW + cg * 32);
+      const f32x4 hi = *(const f32x4*)(ep + pix * EP_ROW + cg * 32 + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const size_t idx = (size_t)(m0 + (uint32_t)pl) * (size_t)p.N + (size_t)(group * p.Ng + col0);
+      if (to_partial) {
+        float* dst = p.partial + (size_t)split * p.M * p.N + idx;
+        if (nv == 8 && (idx & 3) == 0) {
+          *(f32x4*)dst = lo;
+          *(f32x4*)(dst + 4) = hi;
         } else {
-          apply_epilogue4<float>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0, vec);
-          float* dst = (float*)p.out + orow + c0;
-          if (vec) {
-            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-          } else {
+          for (int j = 0; j < nv; ++j) dst[j] = v[j];
+        }
+      } else if (p.out_bf16) {
+        __bf16* dst = (__bf16*)p.out + idx;
+        const __bf16* res = p.ep_res ? (const __bf16*)p.ep_res + idx : nullptr;
+        if (nv == 8 && (idx & 7) == 0) {
+          if (res) {
+            const bf16x8 rv = *(const bf16x8*)res;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
+            for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+          }
+          if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+          const bf16x4 b0 = __builtin_convertvector(x0, bf16x4), b1 = __builtin_convertvector(x1, bf16x4);
+          u32x4 pk;
+          const u32x2 p0 = __builtin_bit_cast(u32x2, b0), p1 = __builtin_bit_cast(u32x2, b1);
+          pk[0] = p0[0]; pk[1] = p0[1]; pk[2] = p1[0]; pk[3] = p1[1];
+          *(u32x4*)dst = pk;
+        } else {
+          for (int j = 0; j < nv; ++j) {
+            float y = v[j] + (res ? (float)res[j] : 0.f);
+            if (relu) y = fmaxf(y, 0.f);
+            dst[j] = (__bf16)y;
+          }
+        }
+      } else {
+        float* dst = (float*)p.out + idx;
+        const float* res = p.ep_res ? (const float*)p.ep_res + idx : nullptr;
+        if (nv == 8 && (idx & 3) == 0) {
+          if (res) {
+            const f32x4 r0 = *(const f32x4*)res, r1 = *(const f32x4*)(res + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
+          }
+          if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+          *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        } else {
+          for (int j = 0; j < nv; ++j) {
+            float y = v[j] + (res ? res[j] : 0.f);
+            if (relu) y = fmaxf(y, 0.f);
+            dst[j] = y;
           }
         }
       }
