@@ -279,30 +279,25 @@ static bool dma_shape_ok(const BtxGeom* g, int act_dtype, int prec, const Plan& 
 // Tile plan of the patch variant (btx_contract_patch.h): stride-1 2-D convolutions with more than one tap whose
 // activations already have the contraction dtype.  Returns false when the shape is not eligible.
 struct PatchPlan {
-  int G, R, Rp, Wp, PP, NI, rtiles;
+  int G, R, Rp, Wp, PP, NI, rtiles, nw, astage, lds;
 };
-static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, Plan* pl, PatchPlan* pt) {
-  if (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_ROWFUSE)) return false;
-  if (make_plan(g, prec, flags, DBM, pl)) return false;
-  if (!dma_shape_ok(g, act_dtype, prec, *pl)) return false;
-  if (g->D != 1 || g->KD != 1 || pl->Do != 1 || g->sh != 1 || g->sw != 1) return false;
-  const int T = g->KH * g->KW;
-  if (T < 2 || T > 64) return false;
-  const int Ho = pl->Ho, Wo = pl->Wo;
+// tile of `tp` output pixels whose patch holds at most `ppcap` pixels
+static bool patch_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, PatchPlan* pt) {
+  const int Ho = pl.Ho, Wo = pl.Wo;
   const int Wp = Wo + (g->KW - 1) * g->dw, halo_r = (g->KH - 1) * g->dh;
-  if (Wo > DBM || Wp * (1 + halo_r) > PT_PPMAX) return false;
+  if (Wo > tp || Wp * (1 + halo_r) > ppcap) return false;
   int G = 1, R;
-  if (Ho * Wo <= DBM / 2) {
+  if (Ho * Wo <= tp / 2 || (Ho * Wo <= tp && (Ho + halo_r) * Wp <= ppcap)) {
     R = Ho;
     const int Rp = R + halo_r;
-    if (Rp * Wp > PT_PPMAX) return false;
-    G = DBM / (Ho * Wo);
-    if (G > PT_PPMAX / (Rp * Wp)) G = PT_PPMAX / (Rp * Wp);
+    if (Rp * Wp > ppcap) return false;
+    G = tp / (Ho * Wo);
+    if (G > ppcap / (Rp * Wp)) G = ppcap / (Rp * Wp);
     if (G > g->NB) G = g->NB;
     if (G < 1) return false;
   } else {
-    int rmax = DBM / Wo;
-    const int rfit = PT_PPMAX / Wp - halo_r;
+    int rmax = tp / Wo;
+    const int rfit = ppcap / Wp - halo_r;
     if (rfit < rmax) rmax = rfit;
     if (rmax > Ho) rmax = Ho;
     if (rmax < 1) return false;
@@ -310,22 +305,45 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
     R = (Ho + nrt - 1) / nrt;
   }
   pt->G = G; pt->R = R; pt->Rp = R + halo_r; pt->Wp = Wp; pt->PP = G * pt->Rp * Wp;
-  pt->NI = ((pt->PP + 15) / 16 + 7) / 8;
   pt->rtiles = (Ho + R - 1) / R;
-  if (pt->PP > PT_PPMAX || pt->NI > PT_MAXNI || G * R * Wo > DBM) return false;
+  return pt->PP <= ppcap && G * R * Wo <= tp;
+}
+static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, Plan* pl, PatchPlan* pt) {
+  if (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_ROWFUSE)) return false;
+  if (make_plan(g, prec, flags, DBM, pl)) return false;
+  if (!dma_shape_ok(g, act_dtype, prec, *pl)) return false;
+  if (g->D != 1 || g->KD != 1 || pl->Do != 1 || g->sh != 1 || g->sw != 1) return false;
+  const int T = g->KH * g->KW;
+  if (T < 2 || T > 64) return false;
+  // 4-wave blocks, two per CU: 2 patch slots + 2 sign slots + 4 weight tiles within 80 KiB -> 22 pieces = 352 pixels;
+  // 8-wave blocks, one per CU: 60 pieces = 960 pixels.  BTX_PATCH_NW=8 forces the latter (A/B measurements).
+  static const char* nw_env = getenv("BTX_PATCH_NW");
+  const bool force8 = nw_env && atoi(nw_env) == 8;
+  if (!force8 && patch_tile(g, *pl, 256, 352, pt)) pt->nw = 4;
+  else if (patch_tile(g, *pl, 512, 960, pt)) pt->nw = 8;
+  else return false;
+  const int pieces = (pt->PP + 15) / 16;
+  pt->NI = (pieces + pt->nw - 1) / pt->nw;
+  if (pt->NI > PT_MAXNI) return false;
+  pt->astage = pieces * 1024;
+  int lds = 2 * pt->astage + 2 * (pt->astage / 16) + PT_WD * 8192;
+  const int ep = pt->nw * PT_EP_WAVE + 1024;
+  if (lds < ep) lds = ep;
+  if (lds > (pt->nw == 4 ? 81920 : 163840)) return false;
+  pt->lds = lds;
   // grid: m-tiles are (image group, row tile); split-K over the channel blocks
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   const int ncb = pl->Cg / bk;
-  pl->mtiles = ((g->NB + G - 1) / G) * pt->rtiles;
+  pl->mtiles = ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
   const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
   int ks = 1;
   {
-    const long long ncu = 256;
+    const long long slots = pt->nw == 4 ? 512 : 256;
     long long best = -1;
     for (int c = 1; c <= ncb && c <= 32; ++c) {
       const int per = (ncb + c - 1) / c;
       if (c > 1 && per * T < 4) break;
-      const long long rounds = (base * c + ncu - 1) / ncu;
+      const long long rounds = (base * c + slots - 1) / slots;
       const long long cost = rounds * (per * T + 4) + (c > 1 ? 1 : 0);
       if (best < 0 || cost < best) { best = cost; ks = c; }
     }
@@ -355,7 +373,8 @@ size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, i
   Plan a, b;
   if (!g || make_plan(g, prec, flags, BM, &a) || make_plan(g, prec, flags, DBM, &b)) return 0;
   (void)kind;
-  size_t wa = plan_ws(a, g), wb = plan_ws(b, g);  // which kernel runs also depends on pointer alignment
+  size_t wa = plan_ws(a, g);  // which kernel runs also depends on pointer alignment
+  const size_t wb = pad256(plan_ws(b, g)) + patch_wt_bytes(b, g, BTX_KIND_FLIPOUT, prec, nullptr);
   if (wb > wa) wa = wb;
   Plan c;
   PatchPlan pt;
@@ -426,17 +445,21 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     out_bf16 = (flags & BTX_FLAG_OUT_BF16) ? 1 : 0;
   }
   size_t need = plan_ws(pl, g);
+  // LDS-DMA and patch variants: the weights are sampled once per launch into the workspace (btx_presample.h),
+  // behind the split-K partials
   size_t wt_off = 0, wt_one = 0, wt_all = 0;
-  if (patch) {
+  if (dma) {
     wt_off = pad256(need);
     wt_all = patch_wt_bytes(pl, g, kind, prec, &wt_one);
-    if (wt_off + wt_all >= 0xfff00000ULL) patch = false;  // 32-bit offsets inside the descriptor
-    else need = wt_off + wt_all;
-  }
-  if (dma && !patch && pl.mtiles != (pl.M + DBM - 1) / DBM) {  // fell back after planning for the patch variant
-    rc = make_plan(g, prec, flags, DBM, &pl);
-    if (rc) return rc;
-    need = plan_ws(pl, g);
+    if (wt_off + wt_all >= 0xfff00000ULL) {  // 32-bit offsets inside the descriptor: register-staged kernel instead
+      if (rowfuse || (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_OUT_BF16))) return BTX_E_UNSUPPORTED;
+      dma = patch = false;
+      rc = make_plan(g, prec, flags, BM, &pl);
+      if (rc) return rc;
+      need = plan_ws(pl, g);
+    } else {
+      need = wt_off + wt_all;
+    }
   }
   if (need && (!ws || ws_bytes < need)) return BTX_E_WORKSPACE;
   if (need && (((uintptr_t)ws) & 15)) return BTX_E_ALIGN;
@@ -475,15 +498,18 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.w_bytes = wb < 0xffffffffLL ? (uint32_t)wb : 0xffffffffu;
   }
 
+  if (const char* tp = getenv("BTX_TRACE_PTR")) p.trace = (void*)strtoull(tp, nullptr, 0);  // BTX_PT_TRACE builds only
+  if (dma) {
+    p.wt = (unsigned char*)ws + wt_off;
+    p.wt_bytes = (uint32_t)wt_all;
+    p.wt_delta_off = (uint32_t)wt_one;
+  }
   static const char* dbg_env = getenv("BTX_DBG");
   p.dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
   hipStream_t st = (hipStream_t)stream;
   if (patch) {
     p.pt_G = pt.G; p.pt_R = pt.R; p.pt_Rp = pt.Rp; p.pt_Wp = pt.Wp; p.pt_PP = pt.PP; p.pt_NI = pt.NI;
-    p.pt_rtiles = pt.rtiles;
-    p.wt = (unsigned char*)ws + wt_off;
-    p.wt_bytes = (uint32_t)wt_all;
-    p.wt_delta_off = (uint32_t)wt_one;
+    p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg, st)
                                  : launch_contract_patch_f32(kind, p, pl.nwg, st);
   } else if (dma)

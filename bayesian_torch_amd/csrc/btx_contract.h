@@ -57,8 +57,10 @@ constexpr int STAGE_BYTES = WDL_OFF + NG * BN * 16;  // 28672
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // 57344
 
 // patch variant (btx_contract_patch.h)
-constexpr int PT_PPMAX = 832;  // patch pixels per LDS slot (13 x 64)
-constexpr int PT_MAXNI = 7;    // 1-KiB DMA instructions per wave per patch: ceil(832 / 16 / 8)
+constexpr int PT_WD = 4;  // depth of the weight-tile ring: W(s+3) is fetched while stage s multiplies and s+1 is read
+constexpr int PT_EP_ROW = 272;
+constexpr int PT_EP_WAVE = 64 * PT_EP_ROW;  // 17408: epilogue staging per wave
+constexpr int PT_MAXNI = 8;  // 1-KiB DMA instructions per wave per patch slot (host plan keeps pieces <= NW * 8)
 
 struct ContractParams {
   const void* x;
@@ -91,6 +93,8 @@ struct ContractParams {
   uint32_t x_bytes, w_bytes;  // sizes of x and of mu/rho in bytes (buffer descriptors of the DMA variant)
   // patch variant (btx_contract_patch.h): tile = pt_G images x pt_R output rows x Wo; patch = pt_G x pt_Rp x pt_Wp pixels
   int pt_G, pt_R, pt_Rp, pt_Wp, pt_PP, pt_NI, pt_rtiles;
+  void* trace;  // BTX_PT_TRACE builds: per-wave phase timings (measurement only)
+  int pt_nw, pt_astage, pt_lds;  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off
   uint32_t wt_bytes, wt_delta_off;
 };

@@ -39,6 +39,8 @@
 #define BTX_DBG(bit) false
 #endif
 #include "btx_contract.h"
+#include "btx_epilogue.h"
+#include "btx_presample.h"
 
 namespace btx {
 
@@ -46,13 +48,13 @@ constexpr int DBM = 512;                    // pixels per workgroup tile (DMA va
 constexpr int DMA_D = 3;                    // activation + sign ring depth
 constexpr int DA_STAGE = NG * DBM * 16;     // 32768
 constexpr int DS_STAGE = DBM * 4;           // 2048 : one sign word per (pixel, stage)
-constexpr int DR_STAGE = 16384;             // mu quads at +0, rho quads at +8192
 constexpr int DW_STAGE = 2 * NG * BN * 16;  // 8192 : mu tile at +0, delta tile at +4096
 constexpr int DA_OFF = 0;
 constexpr int DS_OFF = DA_OFF + DMA_D * DA_STAGE;     // 98304
-constexpr int DR_OFF = DS_OFF + DMA_D * DS_STAGE;     // 104448
-constexpr int DW_OFF = DR_OFF + 2 * DR_STAGE;         // 137216
-constexpr int DMA_LDS_BYTES = DW_OFF + 2 * DW_STAGE;  // 153600
+constexpr int DW_OFF = DS_OFF + DMA_D * DS_STAGE;     // 104448 : PT_WD weight tiles (pre-sampled, btx_presample.h)
+constexpr int DMA_LDS_MAIN = DW_OFF + PT_WD * DW_STAGE;  // 137216
+constexpr int DMA_LDS_EP = (NTHREADS / 64) * PT_EP_WAVE + 1024;  // 140288: epilogue staging (btx_epilogue.h)
+constexpr int DMA_LDS_BYTES = DMA_LDS_MAIN > DMA_LDS_EP ? DMA_LDS_MAIN : DMA_LDS_EP;
 
 constexpr uint32_t DMA_OOB = 0xfffffff0u;  // byte offset beyond every descriptor: the hardware returns zeros
 
@@ -63,6 +65,18 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off,
                                            0, 0, 0);
 }
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant)
+#define BTX_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
+  switch (n) {
+    BTX_VMCNT_CASE(0) BTX_VMCNT_CASE(1) BTX_VMCNT_CASE(2) BTX_VMCNT_CASE(3) BTX_VMCNT_CASE(4) BTX_VMCNT_CASE(5)
+    BTX_VMCNT_CASE(6) BTX_VMCNT_CASE(7) BTX_VMCNT_CASE(8) BTX_VMCNT_CASE(9) BTX_VMCNT_CASE(10) BTX_VMCNT_CASE(11)
+    BTX_VMCNT_CASE(12) BTX_VMCNT_CASE(13) BTX_VMCNT_CASE(14) BTX_VMCNT_CASE(15) BTX_VMCNT_CASE(16)
+    default: if (n > 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+#undef BTX_VMCNT_CASE
 
 template <int PREC, int KIND>
 __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const ContractParams p) {
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   const int l31 = lane & 31;
   const int h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool upper = wave >= 4;
+  const bool upper = wave >= 4;  // waves 4-7 issue their DMAs after the MFMA block (see the main loop)
 
   int logical;
   {
@@ -150,8 +164,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
 #pragma unroll
   for (int q = 0; q < 4; ++q) pb_boff[q] = (pb_off[q] + (uint32_t)(G * g_lane)) * (uint32_t)sizeof(ACT);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t mu_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.mu, 0, p.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rho_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.rho, 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.wt_bytes, 0x00020000);
   uint32_t sg_off;  // this thread's own pixel (tid): only the sign word needs it
   {
     const int m = mtile * DBM + tid;
@@ -171,34 +184,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     s_kd = t2 / p.KH;
   }
 
-  // ---- weight roles.  Raw (mu, rho) stage image in LDS: [channel][QPS quads][16 B] (QPS = BK/4), i.e. one
-  //      128-B (bf16) / 64-B (f32) run per channel = whole cache lines per DMA lane group.
-  //      bf16: wave w DMAs channels [8w, 8w+8) of mu and of rho (2 instructions), thread t samples (ch t>>3, quad t&7)
-  //      f32 : waves 0-3 DMA mu channels [16w, 16w+16), waves 4-7 the same of rho; threads 0..255 sample (t>>2, t&3)
-  constexpr int QPS = BK / 4;
-  const bool w_thread = (G == 8) || (wave < 4);
-  const int w_ch = (G == 8) ? (tid >> 3) : ((tid & 255) >> 2);      // channel within the n-tile (DMA + sampling)
-  const int w_quad = (G == 8) ? (tid & 7) : (tid & 3);
-  const int w_col = ntile * BN + w_ch;
-  const bool w_colok = w_col < p.Ng;
-  const uint32_t w_rowbase = (uint32_t)(group * p.Ng + (w_colok ? w_col : 0)) * (uint32_t)p.K;
+  // ---- weight loader role: the stage's tile is 4 rows of mu (+ 4 rows of delta, Flipout) of 1 KiB in the pre-sampled
+  //      buffer; wave w fetches mu row w (w < 4) or delta row w-4 with one DMA instruction.
+  const bool w_wave = (KIND == 1) || (wave < 4);
+  const uint32_t w_base = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u + (uint32_t)lane * 16u +
+                          (uint32_t)(wave & 3) * 1024u + (wave >= 4 ? p.wt_delta_off : 0u) +
+                          (uint32_t)(k_begin / G) * 1024u;
+  const int w_lds = DW_OFF + (wave & 3) * 1024 + (wave >= 4 ? 4096 : 0);
 
   int a_slot_issue = 0;  // ring slot the next issue_acts() fills
 
-  // =================== issue: all HBM -> LDS traffic of one stage (called for stages 0,1,2,... in order) =====
-  auto issue_raw = [&](int st) __attribute__((always_inline)) {
-    const int kstage = k_begin + st * BK;  // uniform; kstage < k_end because st < nstages
-    unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
-    const int kk = kstage + 4 * w_quad;
-    const bool ok = w_colok && (kk < k_end);
-    const uint32_t bo = ok ? (w_rowbase + (uint32_t)kk) * 4u : DMA_OOB;
-    if constexpr (G == 8) {
-      dma16(mu_rsrc, bo, rs + wave * 1024);
-      dma16(rho_rsrc, bo, rs + 8192 + wave * 1024);
-    } else {
-      if (wave < 4) dma16(mu_rsrc, bo, rs + wave * 1024);
-      else dma16(rho_rsrc, bo, rs + 8192 + (wave & 3) * 1024);
-    }
+  // =================== issue: all L2 -> LDS traffic of one stage (called for stages 0,1,2,... in order) ======
+  auto issue_w = [&](int st) __attribute__((always_inline)) {
+    if (w_wave)
+      dma16(wt_rsrc, w_base + (uint32_t)st * (uint32_t)(BK / G) * 1024u, smem + w_lds + (st & (PT_WD - 1)) * DW_STAGE);
   };
   auto issue_acts = [&]() __attribute__((always_inline)) {  // stages in order: the K walk advances by one stage per call
     // activations: one tap for the whole stage; tap_off is wave-uniform
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
         bo = ((uint32_t)(((pb_n[q] + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C +
               (uint32_t)(group * p.Cg + s_c + G * g_lane)) * (uint32_t)sizeof(ACT);
       }
-      if (!BTX_DBG(8u)) dma16(x_rsrc, ok ? bo : DMA_OOB, as + q * 1024);
+      dma16(x_rsrc, ok ? bo : DMA_OOB, as + q * 1024);
     }
     if constexpr (KIND == 1) {
       // one hashed word covers the 32 (bf16) / 16 (f32) channels of pixel `tid`'s stage.  (In the padding the
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
       }
       // sign layout: element pair e>>1 sits at bit 15-(e>>1) (even e) / 31-(e>>1) (odd e) of its word, so a stage that
       // starts at element offset e0 inside the word needs the word shifted left by e0>>1 within each 16-bit half
-      uint32_t w = BTX_DBG(4u) ? off : btx_sign_word(off >> 5, p.kin_a, p.kin_b);
+      uint32_t w = btx_sign_word(off >> 5, p.kin_a, p.kin_b);
       if (p.sign_unaligned) {  // uniform: the stage may run into the next word (row-fused stems)
         const uint32_t w1 = btx_sign_word((off >> 5) + 1u, p.kin_a, p.kin_b);
         const uint32_t k = (off & 31u) >> 1;
@@ -264,44 +263,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     a_slot_issue = (a_slot_issue == DMA_D - 1) ? 0 : a_slot_issue + 1;
   };
 
-  // =================== P: raw (mu, rho) quad -> sampled MFMA weight tile ==================================
-  auto process_stage = [&](int st) __attribute__((always_inline)) {
-    if (w_thread) {
-      const unsigned char* rs = smem + DR_OFF + (st & 1) * DR_STAGE;
-      unsigned char* ws = smem + DW_OFF + (st & 1) * DW_STAGE;
-      const int ro = (w_ch * QPS + w_quad) * 16;  // == (tid & (G == 8 ? 511 : 255)) * 16: a linear, conflict-free read
-      const f32x4 mu4 = *(const f32x4*)(rs + ro);
-      const f32x4 rho4 = *(const f32x4*)(rs + 8192 + ro);
-      const int k0 = k_begin + st * BK + 4 * w_quad;
-      const bool ok = w_colok && (k0 < k_end);
-      float eps[4] = {1.f, -1.f, 0.5f, -0.5f};
-      if (!BTX_DBG(1u)) btx_normal4_hw((w_rowbase + (uint32_t)k0) >> 2, p.sample, p.layer, 0u, p.seed_lo, p.seed_hi, eps);
-      float wm[4], wd[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float sg = BTX_DBG(1u) ? rho4[e] : btx_softplus_hw(rho4[e]);
-        if constexpr (KIND == 0) {
-          wm[e] = ok ? __builtin_fmaf(sg, eps[e], mu4[e]) : 0.f;
-          wd[e] = 0.f;
-        } else {
-          wm[e] = ok ? mu4[e] : 0.f;
-          wd[e] = ok ? sg * eps[e] : 0.f;
-        }
-      }
-      // MFMA weight tile [granule row][channel][16 B]
-      if constexpr (PREC == 1) {
-        const int wo = ((w_quad >> 1) * BN + w_ch) * 16 + (w_quad & 1) * 8;
-        *(u32x2*)(ws + wo) = pack_quad_bf16(wm);
-        if constexpr (KIND == 1) *(u32x2*)(ws + NG * BN * 16 + wo) = pack_quad_bf16(wd);
-      } else {
-        const int wo = (w_quad * BN + w_ch) * 16;
-        *(u32x4*)(ws + wo) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
-        if constexpr (KIND == 1)
-          *(u32x4*)(ws + NG * BN * 16 + wo) = (u32x4){f2u(wd[0]), f2u(wd[1]), f2u(wd[2]), f2u(wd[3])};
-      }
-    }
-  };
-
   // =================== M: wave = pixels [64*wave, +64) x all 64 channels ===================================
   f32x16 accm[2][2], accd[2][2];
 #pragma unroll
@@ -314,7 +275,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   auto mma_stage = [&](int st, int a_slot) __attribute__((always_inline)) {
     const unsigned char* as = smem + DA_OFF + a_slot * DA_STAGE;
     const unsigned char* ss = smem + DS_OFF + a_slot * DS_STAGE;
-    const unsigned char* ws = smem + DW_OFF + (st & 1) * DW_STAGE;
+    const unsigned char* ws = smem + DW_OFF + (st & (PT_WD - 1)) * DW_STAGE;
     uint32_t sw[2];
     if constexpr (KIND == 1) {
 #pragma unroll
@@ -391,188 +352,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   };
 
   // =================== main loop ==========================================================================
-  // VMEM issue order per wave and iteration s:  acts(s+2) x4  ...  raw(s+3) x RAWOPS.
-  //   bf16: a wave reads back only the raw quads it fetched itself, so it refills raw slot (s+1)&1 right after its
-  //         own P(s+1) has consumed it -> every DMA has TWO iterations to land.
-  //   f32 : rho is fetched by waves 4-7 and consumed by waves 0-3; raw(s+2) is issued at the top of iteration s
-  //         (after the barrier) instead — that path is MFMA-bound (64-cycle MFMAs), latency is irrelevant there.
-  // End of iteration: everything older than the ops still allowed in flight has landed; lgkmcnt(0); raw s_barrier.
-  constexpr int RAWOPS = (G == 8) ? 2 : 1;
-  constexpr bool RAW_EARLY = (G == 8);
+  // Iteration s: every wave issues W(s+3) and acts(s+2), multiplies stage s, waits until everything it issued BEFORE
+  // this iteration has landed (vmcnt retires in order: at most this iteration's operations stay in flight) and meets
+  // the others at one barrier.  acts(s+1) (issued one iteration ago) and W(s+1) (two iterations ago) are then visible.
+  // The DMA instructions block at issue while the memory pipeline is full: waves 0-3 issue at the top of the
+  // iteration, waves 4-7 after their MFMA block, so that of the two waves sharing a SIMD one is free to compute while
+  // the other is stuck issuing.
   if (nstages > 0) {
-    issue_raw(0);
-    if (nstages > 1) issue_raw(1);
+    for (int s = 0; s < PT_WD - 1 && s < nstages; ++s) issue_w(s);
     issue_acts();
     if (nstages > 1) issue_acts();
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    process_stage(0);
-    if (RAW_EARLY && nstages > 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(2); }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    auto run = [&](auto upper_tag) __attribute__((always_inline)) {
-      constexpr bool UPPER = decltype(upper_tag)::value;
-      int a_slot = 0;
-      for (int s = 0; s < nstages; ++s) {
-        const bool acts_issued = s + 2 < nstages;
-        const bool more = s + 1 < nstages;
-        const bool raw_issued = RAW_EARLY && (s + 3 < nstages);
-        // The DMA instructions block at issue while the memory pipeline is full.  Waves 0-3 issue their activation
-        // DMAs at the top of the iteration, waves 4-7 after their MFMA block, so that of the two waves sharing a SIMD
-        // one is always free to compute while the other is stuck issuing (measured: memory 82 us + compute 52 us
-        // serialised to 134 us when every wave issued at the same point).
-        if constexpr (!UPPER) {
-          if (acts_issued) {
-            if constexpr (!RAW_EARLY) issue_raw(s + 2);
-            issue_acts();
-          }
-          if (!BTX_DBG(2u)) mma_stage(s, a_slot);
-#ifdef BTX_MP_BARRIER
-          __builtin_amdgcn_sched_barrier(0);
-#endif
-          if (more && !BTX_DBG(16u)) process_stage(s + 1);
-          if (raw_issued) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(s + 3); }
-        } else {
-          if constexpr (!RAW_EARLY) { if (acts_issued) issue_raw(s + 2); }
-#ifdef BTX_NO_STAGGER
-          if (acts_issued) issue_acts();
-#endif
-          if (more && !BTX_DBG(16u)) process_stage(s + 1);
-          if (raw_issued) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); issue_raw(s + 3); }
-#ifdef BTX_MP_BARRIER
-          __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef BTX_NO_STAGGER
-          if (!BTX_DBG(2u)) mma_stage(s, a_slot);
-#else
-          if (!BTX_DBG(2u)) mma_stage(s, a_slot);
-          if (acts_issued) issue_acts();
-#endif
-        }
-        if constexpr (RAW_EARLY) {
-          // must have landed: acts(s+1), raw(s+2).  Younger: acts(s+2) x4 [, raw(s+3) x2]
-          if (BTX_DBG(8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else if (raw_issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          else if (acts_issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-          // must have landed: raw(s+2) (this iteration, issued before the acts), acts(s+1).  Younger: acts(s+2) x4
-          if (acts_issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        a_slot = (a_slot == DMA_D - 1) ? 0 : a_slot + 1;
+    int a_slot = 0;
+    for (int s = 0; s < nstages; ++s) {
+      const bool acts_issued = s + 2 < nstages;
+      const bool w_issued = s + PT_WD - 1 < nstages;
+      if (!upper) {
+        if (w_issued) issue_w(s + PT_WD - 1);
+        if (acts_issued) issue_acts();
       }
-    };
-    if (upper) run(std::true_type{}); else run(std::false_type{});
+      mma_stage(s, a_slot);
+      if (upper) {
+        if (w_issued) issue_w(s + PT_WD - 1);
+        if (acts_issued) issue_acts();
+      }
+      wait_vmcnt((acts_issued ? 4 : 0) + ((w_issued && w_wave) ? 1 : 0));
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      a_slot = (a_slot == DMA_D - 1) ? 0 : a_slot + 1;
+    }
   }
 
-  // =================== epilogue ===========================================================================
-  // lane owns pixel (lane&31) of each 32-pixel tile; register r = 4q+rr holds channel 32ni + 8q + 4h + rr.
-  const bool to_partial = p.ksplits > 1;
-  const bool has_bias = (split == 0) && (p.mu_b != nullptr);
-  float* bias_lds = (float*)smem;
-  if (has_bias) {
-    if (tid < BN) {
-      const int col = ntile * BN + tid;
-      float bm = 0.f, bdl = 0.f;
-      if (col < p.Ng) {
-        const int gcol = group * p.Ng + col;
-        const float eb = p.eps_b ? p.eps_b[gcol]
-                                 : btx_normal1((unsigned long long)gcol, p.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
-        const float sb_ = btx_softplus_fast(p.rho_b[gcol]);
-        if constexpr (KIND == 0) { bm = __builtin_fmaf(sb_, eb, p.mu_b[gcol]); }
-        else { bm = p.mu_b[gcol]; bdl = sb_ * eb; }
-      }
-      bias_lds[tid] = bm;
-      bias_lds[BN + tid] = bdl;
-    }
-    __syncthreads();
-  }
-  const bool has_aff = (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
-  float* aff_lds = bias_lds + 2 * BN;
-  if (has_aff) {
-    if (tid < BN) {
-      const int col = ntile * BN + tid;
-      const int gcol = group * p.Ng + (col < p.Ng ? col : 0);
-      aff_lds[tid] = p.ep_scale ? p.ep_scale[gcol] : 1.f;
-      aff_lds[BN + tid] = p.ep_shift ? p.ep_shift[gcol] : 0.f;
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int mo = mtile * DBM + wave * 64 + mi * 32 + l31;
-    if (mo >= p.M) continue;
-    const uint32_t orow = (uint32_t)mo * (uint32_t)p.N + (uint32_t)(group * p.Ng);
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int colbase = ntile * BN + ni * 32;
-      if (colbase >= p.Ng) continue;
-      const uint32_t o0 = orow + colbase;
-      const bool word_fast = (KIND == 1) && !p.sign_out && ((o0 & 31u) == 0) && (colbase + 32 <= p.Ng);
-      uint32_t wout = 0;
-      if (word_fast) wout = btx_sign_word(o0 >> 5, p.kout_a, p.kout_b);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cl = ni * 32 + 8 * q + 4 * h;
-        const int c0 = ntile * BN + cl;
-        if (c0 >= p.Ng) continue;
-        float v[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int col = c0 + rr;
-          float val = accm[mi][ni][4 * q + rr];
-          if (has_bias) val += bias_lds[cl + rr];
-          if constexpr (KIND == 1) {
-            float dl = accd[mi][ni][4 * q + rr];
-            if (has_bias) dl += bias_lds[BN + cl + rr];
-            uint32_t flip = 0;
-            if (col < p.Ng) {
-              if (p.sign_out) {
-                flip = (p.sign_out[orow + col] < 0) ? 0x80000000u : 0u;
-              } else if (word_fast) {
-                const int bp = ((rr & 1) ? 31 : 15) - 4 * q - 2 * h - (rr >> 1);
-                flip = (wout << (31 - bp)) & 0x80000000u;
-              } else {
-                const uint32_t io = orow + col;
-                const uint32_t w1 = btx_sign_word(io >> 5, p.kout_a, p.kout_b);
-                flip = (w1 << (31 - btx_sign_bitpos(io & 31u))) & 0x80000000u;
-              }
-            }
-            val += u2f(f2u(dl) ^ flip);
-          }
-          v[rr] = val;
-        }
-        const bool vec = (c0 + 3 < p.Ng) && (((orow + c0) & 3) == 0);
-        if (to_partial) {
-          float* dst = p.partial + (size_t)split * p.M * p.N + orow + c0;
-          if (vec) {
-            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-          } else {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
-          }
-        } else if (p.out_bf16) {
-          apply_epilogue4<__bf16>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0, vec);
-          __bf16* dst = (__bf16*)p.out + orow + c0;
-          if (vec) {
-            f32x4 fv = {v[0], v[1], v[2], v[3]};
-            *(bf16x4*)dst = __builtin_convertvector(fv, bf16x4);
-          } else {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = (__bf16)v[rr];
-          }
-        } else {
-          apply_epilogue4<float>(v, p, has_aff ? aff_lds : nullptr, cl, (long long)orow + c0, p.Ng - c0, vec);
-          float* dst = (float*)p.out + orow + c0;
-          if (vec) {
-            *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-          } else {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) if (c0 + rr < p.Ng) dst[rr] = v[rr];
-          }
-        }
-      }
-    }
+  // =================== epilogue (btx_epilogue.h) ============================================================
+  {
+    const uint32_t m0 = (uint32_t)mtile * (uint32_t)DBM;
+    const int nvalid = min(DBM, p.M - (int)m0);
+    staged_epilogue<KIND, NTHREADS / 64>(p, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
   }
 }
 
@@ -589,6 +403,8 @@ static int launch_contract_dma_impl(int kind, const ContractParams& p, int nwg, 
     }                                                                                                               \
     hipLaunchKernelGGL(kfn, dim3(nwg), dim3(NTHREADS), DMA_LDS_BYTES, st, p);                                       \
   } while (0)
+  int rc = launch_presample_impl<PREC>(kind, p, st);
+  if (rc) return rc;
   if (kind == 0) BTX_LAUNCH_DMA(0); else BTX_LAUNCH_DMA(1);
 #undef BTX_LAUNCH_DMA
   return (int)hipGetLastError();

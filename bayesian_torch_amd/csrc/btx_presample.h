@@ -1,0 +1,70 @@
+// btx_presample.h — sampling pre-pass of the fused contraction kernels (gfx950).
+#pragma once
+#include "btx_contract.h"
+#include "btx_rng.h"
+
+namespace btx {
+
+// ---- sampling pre-pass --------------------------------------------------------------------------------------
+// Every workgroup of a convolution needs the same sampled weight tile: with 392 pixel tiles (ResNet18 layer1) the
+// in-kernel sampler of the other variants repeats each Philox/Box-Muller/softplus 392 times, and that — not the
+// memory pipeline — is what bounds them (A/B in DESIGN.md §5).  Here the weights are sampled ONCE per launch into
+// MFMA-ready tiles in the workspace:   wt[tile = group*ntiles + ntile][kg = k/G][ch 0..63][G elements]  (16-byte
+// granules; `mu` array, then the `delta` = sigma*eps array for Flipout; Reparameterization stores mu + sigma*eps in the
+// first array).  One K-stage of a workgroup is then 4 (+4) contiguous 1-KiB rows: one LDS-DMA instruction each.
+// Same element indices, same _hw sampling functions and the same rounding as the in-kernel sampler: the values are
+// bit-identical to what the other variants compute.
+template <int PREC, int KIND>
+__global__ __launch_bounds__(256) void presample_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
+                                                        unsigned char* __restrict__ wt, uint32_t delta_off, int Ng,
+                                                        int K, int ntiles, uint32_t nquads_total, uint32_t seed_lo,
+                                                        uint32_t seed_hi, uint32_t sample, uint32_t layer) {
+  constexpr int G = (PREC == 1) ? 8 : 4;
+  const uint32_t kq = (uint32_t)K >> 2;
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < nquads_total; t += gridDim.x * 256u) {
+    const uint32_t quad = t % kq, np = t / kq;
+    const int ch = np & 63, tile = np >> 6;
+    const int group = tile / ntiles, ntile = tile - group * ntiles;
+    const int col = ntile * BN + ch;
+    float wm[4] = {0.f, 0.f, 0.f, 0.f}, wd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < Ng) {
+      const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
+      const f32x4 mu4 = *(const f32x4*)(mu + e0);
+      const f32x4 rho4 = *(const f32x4*)(rho + e0);
+      float eps[4];
+      btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sg = btx_softplus_hw(rho4[e]);
+        if constexpr (KIND == 0) wm[e] = __builtin_fmaf(sg, eps[e], mu4[e]);
+        else { wm[e] = mu4[e]; wd[e] = sg * eps[e]; }
+      }
+    }
+    const uint32_t kg = (4u * quad) / G;
+    const uint32_t o = (((uint32_t)tile * ((uint32_t)K / G) + kg) * 64u + (uint32_t)ch) * 16u;
+    if constexpr (PREC == 1) {
+      const uint32_t oo = o + (quad & 1u) * 8u;
+      *(u32x2*)(wt + oo) = pack_quad_bf16(wm);
+      if constexpr (KIND == 1) *(u32x2*)(wt + delta_off + oo) = pack_quad_bf16(wd);
+    } else {
+      *(u32x4*)(wt + o) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
+      if constexpr (KIND == 1) *(u32x4*)(wt + delta_off + o) = (u32x4){f2u(wd[0]), f2u(wd[1]), f2u(wd[2]), f2u(wd[3])};
+    }
+  }
+}
+
+template <int PREC>
+static int launch_presample_impl(int kind, const ContractParams& p, hipStream_t st) {
+  const uint32_t nq = (uint32_t)(p.groups * p.ntiles * 64) * ((uint32_t)p.K >> 2);
+  uint32_t blocks = (nq + 255u) / 256u;
+  if (blocks > 4096u) blocks = 4096u;
+  if (kind == 0)
+    hipLaunchKernelGGL((presample_kernel<PREC, 0>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
+                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer);
+  else
+    hipLaunchKernelGGL((presample_kernel<PREC, 1>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
+                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer);
+  return (int)hipGetLastError();
+}
+
+}  // namespace btx

@@ -119,6 +119,46 @@ def one(prec, iters, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def trace(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64):
+    """per-wave phase timings of the patch kernel (needs a libbtx built with -DBTX_PT_TRACE, see BTX_LIB)"""
+    import os
+    import numpy as np
+    from bayesian_torch_amd import layers as L
+    dev = torch.device("cuda:0")
+    act = torch.bfloat16 if prec == "bf16" else torch.float32
+    torch.manual_seed(0)
+    layer = getattr(L, "Conv2d" + typ)(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(dev)
+    layer.precision = prec
+    x = torch.randn(bs, cin, hw, hw, device=dev).to(act).contiguous(memory_format=torch.channels_last)
+    buf = torch.zeros(1 << 20, dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        for i in range(3):
+            layer._forward_hip(x, sample_idx=i)
+        torch.cuda.synchronize()
+        os.environ["BTX_TRACE_PTR"] = hex(buf.data_ptr())
+        layer._forward_hip(x, sample_idx=7)
+        torch.cuda.synchronize()
+        del os.environ["BTX_TRACE_PTR"]
+    t = buf.cpu().numpy().view(np.uint32).reshape(-1, 8)
+    t = t[t[:, 5] != 0]
+    print("waves traced: %d" % len(t))
+    if not len(t):
+        return
+    names = ["prologue", "A->B issue+mma", "B->C vmcnt", "C->D barrier", "epilogue", "total"]
+    for i, n in enumerate(names):
+        c = t[:, i].astype(np.float64)
+        print("  %-16s mean %9.0f  min %9.0f  max %9.0f  (clock ticks)" % (n, c.mean(), c.min(), c.max()))
+    t0 = t[:, 6].astype(np.int64)
+    t0 = (t0 - t0.min()) & 0xffffffff
+    end = t0 + t[:, 5]
+    print("  kernel span %d ticks; start-time histogram (8 bins): %s" % (end.max(), np.histogram(t0, bins=8)[0].tolist()))
+    hw_id = t[:, 7]
+    cu = ((hw_id >> 8) & 0xf) | (((hw_id >> 13) & 0x7) << 4) | (((hw_id >> 16) & 0xf) << 7)
+    print("  distinct (se,sh,cu) ids: %d" % len(set(cu.tolist())))
+    for w in range(0, min(len(t), 16)):
+        print("   wave %3d: %s start %d" % (w, t[w, :6].tolist(), int(t0[w])))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["parity", "perf"])
@@ -131,6 +171,9 @@ if __name__ == "__main__":
         us = one(a.prec.split(",")[0], a.iters, *c)
         if "timeone" in a.what:
             print("shape %s: %.1f us / launch" % (a.shape, us))
+    if "trace" in a.what:
+        c = [int(v) for v in a.shape.split(",")]
+        trace(a.prec.split(",")[0], *c)
     if "parity" in a.what:
         parity()
     if "perf" in a.what:
