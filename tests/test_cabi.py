@@ -49,11 +49,12 @@ def test_abi_version_and_argument_errors_without_gpu():
                               None) == -1
     assert L.btx_kl_gauss(None, None, 10, None, None, 0.0, 1.0, None, 0, None, 0, None) == -1
     assert L.btx_mc_packed_floats(64, 1000) == 2 * 64 * 1000 + 64 + 2
-    # split-K plan: the small-M ResNet18 layer4 shape needs a workspace, the big-M layer1 shape does not
+    # workspace = split-K partials (small-M ResNet18 layer4 shape) + the weight tiles sampled once per launch:
+    # the big-M layer1 shape needs only the latter, 2 arrays (mu, delta) x 64 channels x K=576 x 2 bytes
     g.H = g.W = 7
     g.C = g.N = 512
     g.sh = g.sw = 1
-    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) > 0
+    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) > 2 * 512 * 4608 * 2
     g.H = g.W = 56
     g.C = g.N = 64
-    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) == 0
+    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) == 2 * 64 * 576 * 2
