@@ -12,7 +12,7 @@ PREC_F32, PREC_BF16 = 0, 1
 FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16 = 1, 2, 4, 8, 16
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class BtxError(RuntimeError):
@@ -26,7 +26,8 @@ class Geom(ctypes.Structure):
 
 
 class Rng(ctypes.Structure):
-    _fields_ = [("seed", ctypes.c_uint64), ("sample_idx", ctypes.c_uint32), ("layer_id", ctypes.c_uint32)]
+    _fields_ = [("seed", ctypes.c_uint64), ("sample_idx", ctypes.c_uint32), ("layer_id", ctypes.c_uint32),
+                ("sample_idx_dev", ctypes.c_void_p)]
 
 
 class Epilogue(ctypes.Structure):
@@ -36,12 +37,17 @@ class Epilogue(ctypes.Structure):
 
 class Noise(ctypes.Structure):
     _fields_ = [("eps_w", ctypes.c_void_p), ("eps_b", ctypes.c_void_p),
-                ("sign_in", ctypes.c_void_p), ("sign_out", ctypes.c_void_p)]
+                ("sign_in", ctypes.c_void_p), ("sign_out", ctypes.c_void_p), ("sampled_w", ctypes.c_void_p)]
+
+
+class SampleItem(ctypes.Structure):
+    _fields_ = [("geom", ctypes.POINTER(Geom)), ("mu_w", ctypes.c_void_p), ("rho_w", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("kind", ctypes.c_int32), ("layer_id", ctypes.c_uint32)]
 
 
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss",
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
-           "btx_mc_packed_floats", "btx_mc_accumulate")
+           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights")
 
 
 def lib_path():
@@ -83,6 +89,10 @@ def lib():
     L.btx_fill_sign.argtypes = [vp, sz, ctypes.POINTER(Rng), u32, vp]
     L.btx_mc_packed_floats.restype = sz
     L.btx_mc_packed_floats.argtypes = [i32, i32]
+    L.btx_sampled_w_bytes.restype = sz
+    L.btx_sampled_w_bytes.argtypes = [ctypes.POINTER(Geom), i32, i32]
+    L.btx_sample_weights.restype = i32
+    L.btx_sample_weights.argtypes = [ctypes.POINTER(SampleItem), i32, ctypes.POINTER(Rng), i32, vp]
     L.btx_mc_accumulate.restype = i32
     L.btx_mc_accumulate.argtypes = [vp, i32, i32, i32, f32, vp, vp]
     if L.btx_abi_version() != ABI_VERSION:

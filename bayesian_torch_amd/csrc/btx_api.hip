@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include "btx_contract.h"
 #include "btx_rng.h"
+#include "btx_presample.h"
 namespace btx { constexpr int DBM = 512; }  // pixels per tile of the LDS-DMA variant (btx_contract_dma.h)
 
 using namespace btx;
@@ -448,16 +449,19 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   // LDS-DMA and patch variants: the weights are sampled once per launch into the workspace (btx_presample.h),
   // behind the split-K partials
   size_t wt_off = 0, wt_one = 0, wt_all = 0;
+  const void* sampled_w = (noise && noise->sampled_w) ? noise->sampled_w : nullptr;
+  if (sampled_w && (((uintptr_t)sampled_w) & 15)) return BTX_E_ALIGN;
   if (dma) {
     wt_off = pad256(need);
     wt_all = patch_wt_bytes(pl, g, kind, prec, &wt_one);
+    if (sampled_w && wt_all < 0xfff00000ULL) wt_off = need;  // tiles live in the caller's buffer
     if (wt_off + wt_all >= 0xfff00000ULL) {  // 32-bit offsets inside the descriptor: register-staged kernel instead
       if (rowfuse || (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_OUT_BF16))) return BTX_E_UNSUPPORTED;
       dma = patch = false;
       rc = make_plan(g, prec, flags, BM, &pl);
       if (rc) return rc;
       need = plan_ws(pl, g);
-    } else {
+    } else if (!sampled_w) {
       need = wt_off + wt_all;
     }
   }
@@ -489,6 +493,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   }
   p.seed_lo = (uint32_t)rng->seed; p.seed_hi = (uint32_t)(rng->seed >> 32);
   p.sample = rng->sample_idx; p.layer = rng->layer_id;
+  p.sample_ptr = rng->sample_idx_dev;
   sign_keys(rng, BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
   sign_keys(rng, BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
   {
@@ -500,7 +505,8 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
 
   if (const char* tp = getenv("BTX_TRACE_PTR")) p.trace = (void*)strtoull(tp, nullptr, 0);  // BTX_PT_TRACE builds only
   if (dma) {
-    p.wt = (unsigned char*)ws + wt_off;
+    p.wt = sampled_w ? (void*)sampled_w : (void*)((unsigned char*)ws + wt_off);
+    p.wt_ready = sampled_w ? 1 : 0;
     p.wt_bytes = (uint32_t)wt_all;
     p.wt_delta_off = (uint32_t)wt_one;
   }
@@ -535,6 +541,55 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     rc = (int)hipGetLastError();
   }
   return rc;
+}
+
+size_t btx_sampled_w_bytes(const BtxGeom* g, int kind, int prec) {
+  Plan pl;
+  if (!g || make_plan(g, prec, 0, DBM, &pl)) return 0;
+  return patch_wt_bytes(pl, g, kind, prec, nullptr);
+}
+
+int btx_sample_weights(const BtxSampleItem* items, int n_items, const BtxRng* rng, int prec, void* stream) {
+  if (!items || !rng) return BTX_E_NULL;
+  const uint64_t seed = rng->seed;
+  const uint32_t sample_idx = rng->sample_idx;
+  if (n_items <= 0) return n_items == 0 ? 0 : BTX_E_SHAPE;
+  if (prec != BTX_PREC_F32 && prec != BTX_PREC_BF16) return BTX_E_DTYPE;
+  for (int base = 0; base < n_items; base += PRESAMPLE_MAX_ITEMS) {
+    PresampleBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = n_items - base < PRESAMPLE_MAX_ITEMS ? n_items - base : PRESAMPLE_MAX_ITEMS;
+    b.seed_lo = (uint32_t)seed; b.seed_hi = (uint32_t)(seed >> 32); b.sample = sample_idx; b.sample_ptr = rng->sample_idx_dev;
+    uint32_t blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const BtxSampleItem& s = items[base + i];
+      if (!s.geom || !s.mu_w || !s.rho_w || !s.out) return BTX_E_NULL;
+      if (s.kind != BTX_KIND_REPARAM && s.kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
+      if ((((uintptr_t)s.mu_w | (uintptr_t)s.rho_w | (uintptr_t)s.out) & 15)) return BTX_E_ALIGN;
+      Plan pl;
+      int rc = make_plan(s.geom, prec, 0, DBM, &pl);
+      if (rc) return rc;
+      if (pl.K % 4) return BTX_E_UNSUPPORTED;
+      size_t one = 0;
+      if (patch_wt_bytes(pl, s.geom, s.kind, prec, &one) >= 0xfff00000ULL) return BTX_E_UNSUPPORTED;
+      PresampleItem& it = b.it[i];
+      it.mu = s.mu_w; it.rho = s.rho_w; it.wt = (unsigned char*)s.out;
+      it.delta_off = (uint32_t)one;
+      it.nquads = (uint32_t)(s.geom->groups * pl.ntiles * 64) * ((uint32_t)pl.K >> 2);
+      it.first_block = blocks;
+      it.layer = s.layer_id;
+      it.Ng = pl.Ng; it.K = pl.K; it.ntiles = pl.ntiles; it.kind = s.kind;
+      uint32_t nb = (it.nquads + 1023u) / 1024u;  // ~4 quads per thread
+      if (nb < 1) nb = 1;
+      if (nb > 1024u) nb = 1024u;
+      blocks += nb;
+    }
+    b.total_blocks = blocks;
+    int rc = (prec == BTX_PREC_BF16) ? launch_presample_batch_bf16(b, (hipStream_t)stream)
+                                     : launch_presample_batch_f32(b, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int btx_fill_eps(float* out, size_t n, const BtxRng* rng, uint32_t rng_stream, void* stream) {

@@ -82,6 +82,7 @@ struct ContractParams {
   int mtiles, ntiles, groups, ksplits, kper;
   int transposed;
   uint32_t seed_lo, seed_hi, sample, layer;
+  const uint32_t* sample_ptr;  // non-NULL: the MC sample index is read from device memory when the kernel runs
   uint32_t kin_a, kin_b, kout_a, kout_b;
   const float* ep_scale;  // fused epilogue (BtxEpilogue), all nullable
   const float* ep_shift;
@@ -97,7 +98,29 @@ struct ContractParams {
   int pt_nw, pt_astage, pt_lds;  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off
   uint32_t wt_bytes, wt_delta_off;
+  int wt_ready;  // wt was filled by btx_sample_weights: skip the per-launch sampling pre-pass
 };
+
+// ---- the (sample index, sign keys) a launch actually uses --------------------------------------------------------
+// BtxRng.sample_idx_dev lets a captured hipGraph be replayed for successive MC samples: the index — and the Flipout
+// sign keys derived from it — are then resolved on the device at run time instead of being baked into the arguments.
+struct RngLive {
+  uint32_t sample, kin_a, kin_b, kout_a, kout_b;
+};
+template <int KIND>
+__device__ __forceinline__ RngLive rng_live(const ContractParams& p) {
+  RngLive r = {p.sample, p.kin_a, p.kin_b, p.kout_a, p.kout_b};
+  if (p.sample_ptr) {
+    r.sample = __builtin_amdgcn_readfirstlane(*p.sample_ptr);
+    if constexpr (KIND == 1) {
+      const BtxPhilox4 ki = btx_philox4x32_10(0u, r.sample, p.layer, 2u, p.seed_lo, p.seed_hi);  // BTX_STREAM_SIGN_IN
+      const BtxPhilox4 ko = btx_philox4x32_10(0u, r.sample, p.layer, 3u, p.seed_lo, p.seed_hi);  // BTX_STREAM_SIGN_OUT
+      r.kin_a = __builtin_amdgcn_readfirstlane(ki.x[0]); r.kin_b = __builtin_amdgcn_readfirstlane(ki.x[1]);
+      r.kout_a = __builtin_amdgcn_readfirstlane(ko.x[0]); r.kout_b = __builtin_amdgcn_readfirstlane(ko.x[1]);
+    }
+  }
+  return r;
+}
 
 // ---- small helpers -------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
@@ -196,6 +219,7 @@ __device__ __forceinline__ int ws_bit(int e) { return ((e & 1) ? 31 : 15) - (e >
 // =========================================================================================================
 template <int PREC, typename ACT, int KIND, bool GEN>
 __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractParams p) {
+  const RngLive rl = rng_live<KIND>(p);
   constexpr int G = (PREC == 1) ? 8 : 4;   // elements per granule
   constexpr int BK = NG * G;               // k per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -348,7 +372,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
           rawok[j & 1] = ok;
           if constexpr (KIND == 1) {
             const unsigned long long i0 = (unsigned long long)off;
-            const uint32_t w = btx_sign_word((uint32_t)(i0 >> 5), p.kin_a, p.kin_b);
+            const uint32_t w = btx_sign_word((uint32_t)(i0 >> 5), rl.kin_a, rl.kin_b);
             const int sh = (int)((i0 >> 3) & 3) * 4 + (G == 4 ? (int)((i0 >> 2) & 1) * 2 : 0);
             wsr[j & 1] = w << sh;
           }
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
                   bit = p.sign_in[i] < 0 ? 1u : 0u;
                 } else {
                   const uint32_t wi = (uint32_t)(i >> 5);
-                  if (wi != cw_i) { cw_i = wi; cw = btx_sign_word(wi, p.kin_a, p.kin_b); }
+                  if (wi != cw_i) { cw_i = wi; cw = btx_sign_word(wi, rl.kin_a, rl.kin_b); }
                   bit = (cw >> btx_sign_bitpos((uint32_t)i & 31u)) & 1u;
                 }
                 ws |= bit << ws_bit(e);
@@ -393,7 +417,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
     if (w_thread) {
       float eps[4];
       if constexpr (!GEN) {
-        btx_normal4((uint32_t)(w_idx >> 2), p.sample, p.layer, 0u, p.seed_lo, p.seed_hi, eps);
+        btx_normal4((uint32_t)(w_idx >> 2), rl.sample, p.layer, 0u, p.seed_lo, p.seed_hi, eps);
       } else {
         if (p.eps_w) {  // parity mode: explicit eps
 #pragma unroll
@@ -401,7 +425,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            eps[e] = btx_normal1((unsigned long long)(w_idx + e), p.sample, p.layer, 0u, p.seed_lo, p.seed_hi);
+            eps[e] = btx_normal1((unsigned long long)(w_idx + e), rl.sample, p.layer, 0u, p.seed_lo, p.seed_hi);
         }
       }
       float wm[4], wd[4];
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
       if (col < p.Ng) {
         const int gcol = group * p.Ng + col;
         const float eb = p.eps_b ? p.eps_b[gcol]
-                                 : btx_normal1((unsigned long long)gcol, p.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
+                                 : btx_normal1((unsigned long long)gcol, rl.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
         const float sb_ = btx_softplus_fast(p.rho_b[gcol]);
         if constexpr (KIND == 0) { bm = __builtin_fmaf(sb_, eb, p.mu_b[gcol]); }
         else { bm = p.mu_b[gcol]; bdl = sb_ * eb; }
@@ -569,7 +593,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
       const unsigned long long o0 = (unsigned long long)(orow + colbase);
       const bool word_fast = (KIND == 1) && !p.sign_out && ((o0 & 31ull) == 0) && (colbase + 32 <= p.Ng);
       uint32_t wout = 0;
-      if (word_fast) wout = btx_sign_word((uint32_t)(o0 >> 5), p.kout_a, p.kout_b);
+      if (word_fast) wout = btx_sign_word((uint32_t)(o0 >> 5), rl.kout_a, rl.kout_b);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int cl = wv_n * 32 + 8 * q + 4 * h;  // channel within the n-tile
@@ -593,7 +617,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
                 flip = (wout << (31 - bp)) & 0x80000000u;
               } else {
                 const unsigned long long io = (unsigned long long)(orow + col);
-                const uint32_t w1 = btx_sign_word((uint32_t)(io >> 5), p.kout_a, p.kout_b);
+                const uint32_t w1 = btx_sign_word((uint32_t)(io >> 5), rl.kout_a, rl.kout_b);
                 flip = (w1 << (31 - btx_sign_bitpos((uint32_t)io & 31u))) & 0x80000000u;
               }
             }
@@ -673,6 +697,9 @@ int launch_contract_bf16(int kind, int act_bf16, bool gen, const ContractParams&
 int launch_contract_dma_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_dma_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_patch_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
+struct PresampleBatch;
+int launch_presample_batch_f32(const PresampleBatch& b, hipStream_t st);
+int launch_presample_batch_bf16(const PresampleBatch& b, hipStream_t st);
 int launch_contract_patch_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
 
 template <int PREC>

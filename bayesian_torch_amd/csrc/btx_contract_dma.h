@@ -80,6 +80,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 
 template <int PREC, int KIND>
 __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const ContractParams p) {
+  const RngLive rl = rng_live<KIND>(p);
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
   constexpr int BK = NG * G;
@@ -241,9 +242,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
       }
       // sign layout: element pair e>>1 sits at bit 15-(e>>1) (even e) / 31-(e>>1) (odd e) of its word, so a stage that
       // starts at element offset e0 inside the word needs the word shifted left by e0>>1 within each 16-bit half
-      uint32_t w = btx_sign_word(off >> 5, p.kin_a, p.kin_b);
+      uint32_t w = btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
       if (p.sign_unaligned) {  // uniform: the stage may run into the next word (row-fused stems)
-        const uint32_t w1 = btx_sign_word((off >> 5) + 1u, p.kin_a, p.kin_b);
+        const uint32_t w1 = btx_sign_word((off >> 5) + 1u, rl.kin_a, rl.kin_b);
         const uint32_t k = (off & 31u) >> 1;
         const uint32_t lo = ((w & 0xffffu) << 16) | (w1 & 0xffffu);
         const uint32_t hi = (w & 0xffff0000u) | (w1 >> 16);
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   {
     const uint32_t m0 = (uint32_t)mtile * (uint32_t)DBM;
     const int nvalid = min(DBM, p.M - (int)m0);
-    staged_epilogue<KIND, NTHREADS / 64>(p, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    staged_epilogue<KIND, NTHREADS / 64>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
   }
 }
 

@@ -41,6 +41,7 @@ namespace btx {
 // tiles), wt_bytes, wt_delta_off; kper = channel blocks per split * BK.
 template <int PREC, int KIND, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const ContractParams p) {
+  const RngLive rl = rng_live<KIND>(p);
   constexpr int NT = 64 * NW;
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
       for (int j = 0; j < 2; ++j) {
         if (sg_ok[j]) {
           const uint32_t off = sg_off[j] + (uint32_t)((cb_begin + cbi) * BK);
-          uint32_t w = btx_sign_word(off >> 5, p.kin_a, p.kin_b);
+          uint32_t w = btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
           if constexpr (G == 4) w <<= 8 * ((off >> 4) & 1);
           *(uint32_t*)(ss + (tid + NT * j) * 4) = w;
         }
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
     const int nvalid = nimg * nrow * p.Wo;
     const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
-    staged_epilogue<KIND, NW>(p, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
   }
 #ifdef BTX_PT_TRACE
   if (p.trace) {

@@ -16,7 +16,7 @@
 namespace btx {
 
 template <int KIND, int NW>
-__device__ __forceinline__ void staged_epilogue(const ContractParams& p, const f32x16 (&accm)[2][2],
+__device__ __forceinline__ void staged_epilogue(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
                                                 const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int wave,
                                                 int lane, int ntile, int group, int split, uint32_t m0, int nvalid) {
   // Stage 1: bias, Flipout combine (s_out), BN affine on the MFMA fragments; the f32 tile of the wave (64 pixels x 64
@@ -37,7 +37,7 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const f
       if (col < p.Ng) {
         const int gcol = group * p.Ng + col;
         const float eb = p.eps_b ? p.eps_b[gcol]
-                                 : btx_normal1((unsigned long long)gcol, p.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
+                                 : btx_normal1((unsigned long long)gcol, rl.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
         const float sb_ = btx_softplus_fast(p.rho_b[gcol]);
         if constexpr (KIND == 0) { bm = __builtin_fmaf(sb_, eb, p.mu_b[gcol]); }
         else { bm = p.mu_b[gcol]; bdl = sb_ * eb; }
@@ -69,7 +69,7 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const f
       const uint32_t o0 = orow + colbase;
       const bool word_fast = (KIND == 1) && !p.sign_out && ((o0 & 31u) == 0) && (colbase + 32 <= p.Ng);
       uint32_t wout = 0;
-      if (word_fast) wout = btx_sign_word(o0 >> 5, p.kout_a, p.kout_b);
+      if (word_fast) wout = btx_sign_word(o0 >> 5, rl.kout_a, rl.kout_b);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int cl = ni * 32 + 8 * q + 4 * h;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const f
                 flip = (p.sign_out[orow + col] < 0) ? 0x80000000u : 0u;
               } else {
                 const uint32_t io = orow + col;
-                const uint32_t w1 = btx_sign_word(io >> 5, p.kout_a, p.kout_b);
+                const uint32_t w1 = btx_sign_word(io >> 5, rl.kout_a, rl.kout_b);
                 flip = (w1 << (31 - btx_sign_bitpos(io & 31u))) & 0x80000000u;
               }
             }

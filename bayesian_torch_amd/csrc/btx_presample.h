@@ -14,56 +14,96 @@ namespace btx {
 // first array).  One K-stage of a workgroup is then 4 (+4) contiguous 1-KiB rows: one LDS-DMA instruction each.
 // Same element indices, same _hw sampling functions and the same rounding as the in-kernel sampler: the values are
 // bit-identical to what the other variants compute.
+// one quad (4 consecutive k of one output channel) of the tile image; `t` enumerates (padded channel, quad)
+template <int PREC>
+__device__ __forceinline__ void presample_quad(int kind, const float* __restrict__ mu, const float* __restrict__ rho,
+                                               unsigned char* __restrict__ wt, uint32_t delta_off, int Ng, int K,
+                                               int ntiles, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
+                                               uint32_t sample, uint32_t layer) {
+  constexpr int G = (PREC == 1) ? 8 : 4;
+  const uint32_t kq = (uint32_t)K >> 2;
+  const uint32_t quad = t % kq, np = t / kq;
+  const int ch = np & 63, tile = np >> 6;
+  const int group = tile / ntiles, ntile = tile - group * ntiles;
+  const int col = ntile * BN + ch;
+  float wm[4] = {0.f, 0.f, 0.f, 0.f}, wd[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < Ng) {
+    const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
+    const f32x4 mu4 = *(const f32x4*)(mu + e0);
+    const f32x4 rho4 = *(const f32x4*)(rho + e0);
+    float eps[4];
+    btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float sg = btx_softplus_hw(rho4[e]);
+      if (kind == 0) wm[e] = __builtin_fmaf(sg, eps[e], mu4[e]);
+      else { wm[e] = mu4[e]; wd[e] = sg * eps[e]; }
+    }
+  }
+  const uint32_t kg = (4u * quad) / G;
+  const uint32_t o = (((uint32_t)tile * ((uint32_t)K / G) + kg) * 64u + (uint32_t)ch) * 16u;
+  if constexpr (PREC == 1) {
+    const uint32_t oo = o + (quad & 1u) * 8u;
+    *(u32x2*)(wt + oo) = pack_quad_bf16(wm);
+    if (kind == 1) *(u32x2*)(wt + delta_off + oo) = pack_quad_bf16(wd);
+  } else {
+    *(u32x4*)(wt + o) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
+    if (kind == 1) *(u32x4*)(wt + delta_off + o) = (u32x4){f2u(wd[0]), f2u(wd[1]), f2u(wd[2]), f2u(wd[3])};
+  }
+}
+
 template <int PREC, int KIND>
 __global__ __launch_bounds__(256) void presample_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
                                                         unsigned char* __restrict__ wt, uint32_t delta_off, int Ng,
                                                         int K, int ntiles, uint32_t nquads_total, uint32_t seed_lo,
-                                                        uint32_t seed_hi, uint32_t sample, uint32_t layer) {
-  constexpr int G = (PREC == 1) ? 8 : 4;
-  const uint32_t kq = (uint32_t)K >> 2;
-  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < nquads_total; t += gridDim.x * 256u) {
-    const uint32_t quad = t % kq, np = t / kq;
-    const int ch = np & 63, tile = np >> 6;
-    const int group = tile / ntiles, ntile = tile - group * ntiles;
-    const int col = ntile * BN + ch;
-    float wm[4] = {0.f, 0.f, 0.f, 0.f}, wd[4] = {0.f, 0.f, 0.f, 0.f};
-    if (col < Ng) {
-      const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
-      const f32x4 mu4 = *(const f32x4*)(mu + e0);
-      const f32x4 rho4 = *(const f32x4*)(rho + e0);
-      float eps[4];
-      btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float sg = btx_softplus_hw(rho4[e]);
-        if constexpr (KIND == 0) wm[e] = __builtin_fmaf(sg, eps[e], mu4[e]);
-        else { wm[e] = mu4[e]; wd[e] = sg * eps[e]; }
-      }
-    }
-    const uint32_t kg = (4u * quad) / G;
-    const uint32_t o = (((uint32_t)tile * ((uint32_t)K / G) + kg) * 64u + (uint32_t)ch) * 16u;
-    if constexpr (PREC == 1) {
-      const uint32_t oo = o + (quad & 1u) * 8u;
-      *(u32x2*)(wt + oo) = pack_quad_bf16(wm);
-      if constexpr (KIND == 1) *(u32x2*)(wt + delta_off + oo) = pack_quad_bf16(wd);
-    } else {
-      *(u32x4*)(wt + o) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
-      if constexpr (KIND == 1) *(u32x4*)(wt + delta_off + o) = (u32x4){f2u(wd[0]), f2u(wd[1]), f2u(wd[2]), f2u(wd[3])};
-    }
-  }
+                                                        uint32_t seed_hi, uint32_t sample, uint32_t layer,
+                                                        const uint32_t* __restrict__ sample_ptr) {
+  if (sample_ptr) sample = __builtin_amdgcn_readfirstlane(*sample_ptr);
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < nquads_total; t += gridDim.x * 256u)
+    presample_quad<PREC>(KIND, mu, rho, wt, delta_off, Ng, K, ntiles, t, seed_lo, seed_hi, sample, layer);
+}
+
+// Batched form (btx_sample_weights): the weights of up to PRESAMPLE_MAX_ITEMS layers in ONE launch — a model's
+// 21 per-layer pre-passes cost ~6.5 us each, mostly launch latency.  The item table travels in the kernel arguments.
+constexpr int PRESAMPLE_MAX_ITEMS = 32;
+struct PresampleItem {
+  const float* mu;
+  const float* rho;
+  unsigned char* wt;
+  uint32_t delta_off, nquads, first_block, layer;
+  int Ng, K, ntiles, kind;
+};
+struct PresampleBatch {
+  PresampleItem it[PRESAMPLE_MAX_ITEMS];
+  int n;
+  uint32_t seed_lo, seed_hi, sample, total_blocks;
+  const uint32_t* sample_ptr;
+};
+template <int PREC>
+__global__ __launch_bounds__(256) void presample_batch_kernel(const PresampleBatch b) {
+  int i = 0;
+  for (int j = 1; j < b.n; ++j)
+    if (blockIdx.x >= b.it[j].first_block) i = j;
+  const PresampleItem& it = b.it[i];
+  const uint32_t sample = b.sample_ptr ? __builtin_amdgcn_readfirstlane(*b.sample_ptr) : b.sample;
+  const uint32_t nblk = (i + 1 < b.n ? b.it[i + 1].first_block : b.total_blocks) - it.first_block;
+  for (uint32_t t = (blockIdx.x - it.first_block) * 256u + threadIdx.x; t < it.nquads; t += nblk * 256u)
+    presample_quad<PREC>(it.kind, it.mu, it.rho, it.wt, it.delta_off, it.Ng, it.K, it.ntiles, t, b.seed_lo, b.seed_hi,
+                         sample, it.layer);
 }
 
 template <int PREC>
 static int launch_presample_impl(int kind, const ContractParams& p, hipStream_t st) {
+  if (p.wt_ready) return 0;  // the caller sampled the weights already (btx_sample_weights)
   const uint32_t nq = (uint32_t)(p.groups * p.ntiles * 64) * ((uint32_t)p.K >> 2);
   uint32_t blocks = (nq + 255u) / 256u;
   if (blocks > 4096u) blocks = 4096u;
   if (kind == 0)
     hipLaunchKernelGGL((presample_kernel<PREC, 0>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
-                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer);
+                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer, p.sample_ptr);
   else
     hipLaunchKernelGGL((presample_kernel<PREC, 1>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
-                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer);
+                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer, p.sample_ptr);
   return (int)hipGetLastError();
 }
 

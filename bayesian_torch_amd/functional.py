@@ -181,8 +181,47 @@ def _sign_to_int8_cl(s, op):
     return phys
 
 
+def _weight_geom(op):
+    """BtxGeom carrying what the sampled-weight tile layout depends on (N, K = taps*C/groups, groups)"""
+    g = _lib.Geom()
+    g.NB, g.D, g.H, g.W = 1, max(op.kernel[0], 1), max(op.kernel[1], 1), max(op.kernel[2], 1)
+    g.C, g.N = op.in_channels, op.out_channels
+    g.KD, g.KH, g.KW = op.kernel
+    g.sd = g.sh = g.sw = 1
+    g.dd = g.dh = g.dw = 1
+    g.groups = op.groups
+    return g
+
+
+def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None):
+    """btx_sample_weights: ONE launch samples the weights of every layer in `items` for MC sample `sample_idx`.
+    items = [(kind, op, mu_p, rho_p, layer_id)] with GEMM-major f32 mu/rho as handed to contract_hip; returns the list
+    of uint8 tile buffers, to be passed as contract_hip(..., sampled_w=buf)."""
+    L = _lib.lib()
+    if not items:
+        return []
+    prec_c = _lib.PREC_BF16 if prec == "bf16" else _lib.PREC_F32
+    arr = (_lib.SampleItem * len(items))()
+    geoms, outs = [], []
+    for i, (kind, op, mu_p, rho_p, layer_id) in enumerate(items):
+        g = _weight_geom(op)
+        geoms.append(g)
+        nbytes = L.btx_sampled_w_bytes(ctypes.byref(g), kind, prec_c)
+        if nbytes == 0:
+            raise _lib.BtxError("btx_sampled_w_bytes: unsupported geometry")
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        outs.append(buf)
+        arr[i].geom = ctypes.pointer(g)
+        arr[i].mu_w, arr[i].rho_w, arr[i].out = mu_p.data_ptr(), rho_p.data_ptr(), buf.data_ptr()
+        arr[i].kind, arr[i].layer_id = kind, int(layer_id) & 0xFFFFFFFF
+    stream = torch.cuda.current_stream(device).cuda_stream
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, 0, sample_dev.data_ptr() if sample_dev is not None else None)
+    _lib.check(L.btx_sample_weights(arr, len(items), ctypes.byref(r), prec_c, stream))
+    return outs
+
+
 def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_id, prec=None, noise=None,
-                 extra_flags=0, out_dtype=None, epilogue=None):
+                 extra_flags=0, out_dtype=None, epilogue=None, sampled_w=None, sample_dev=None):
     """One fused sample-and-contract forward on the GPU (btx_contract_fwd).  `mu_p`/`rho_p` are GEMM-major packed.
     `noise` (parity mode) = dict with optional eps_w (logical weight layout), eps_b, sign_in, sign_out."""
     L = _lib.lib()
@@ -215,11 +254,16 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     stream = torch.cuda.current_stream(x.device).cuda_stream
     need = L.btx_contract_workspace_bytes(ctypes.byref(g), kind, act, prec_c, flags)
     ws = _workspace(x.device, need, stream) if need else None
-    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF,
+                 sample_dev.data_ptr() if sample_dev is not None else None)
     keep = []
     nz = None
-    if noise:
+    if sampled_w is not None:
         nz = _lib.Noise()
+        nz.sampled_w = sampled_w.data_ptr()
+        keep.append(sampled_w)
+    if noise:
+        nz = nz or _lib.Noise()
         if noise.get("eps_w") is not None:
             t = pack_gemm_major(noise["eps_w"].to(device=x.device, dtype=torch.float32), op)
             keep.append(t); nz.eps_w = t.data_ptr()

@@ -213,6 +213,46 @@ class _VariationalNd(BaseVariationalLayer_):
         return self._forward_aten(input, return_kl)
 
     # ---- MI355X path -----------------------------------------------------------------------------------------
+    def _kernel_weights(self, x_shape):
+        """(layout tag, op, mu, rho) as the HIP kernels of the in-kernel-noise path receive them for an input of
+        shape `x_shape`: GEMM-major, row-fused for small-C stems, channel-padded where C % 8 != 0"""
+        mu, rho = self._w()
+        mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
+        plan = None
+        if self._op.nd == 2 and self._op.in_channels <= 4:
+            plan = BF.rowfuse_plan(self._op, tuple(x_shape))
+        if plan is not None:
+            mu_f, rho_f = BF.rowfuse_weights(mu_p, rho_p, plan)
+            return ("rowfuse", plan["cp"], plan["kwp"]), plan["op"], mu_f, rho_f, plan
+        if self._btx_cpad is not None:
+            extra = self._btx_cpad - self._op.in_channels
+            return (("cpad", self._btx_cpad), self._op_pad, torch.nn.functional.pad(mu_p, (0, extra)),
+                    torch.nn.functional.pad(rho_p, (0, extra)), None)
+        return ("plain",), self._op, mu_p, rho_p, None
+
+    def presample_item(self, sample_idx, prec):
+        """What bayesian_torch_amd.presample() needs to sample this layer's weights ahead of its next forward (None
+        until the layer has seen an input: the stem layouts depend on the input shape)"""
+        shape = getattr(self, "_btx_last_xshape", None)
+        if shape is None:
+            return None
+        tag, op, mu_k, rho_k, _ = self._kernel_weights(shape)
+        kind = _lib.KIND_FLIPOUT if self._family == "flipout" else _lib.KIND_REPARAM
+        key = (_rng.seed(), self._sample_key(sample_idx), self._btx_layer_id, self.precision or prec, tag)
+        return key, (kind, op, mu_k, rho_k, self._btx_layer_id)
+
+    def _sample_key(self, sample_idx):
+        sdev = getattr(self, "_btx_sample_dev", None)  # graph mode (mc.GraphedMC): the index lives on the device
+        return ("dev", sdev.data_ptr()) if sdev is not None else int(sample_idx)
+
+    def _take_presampled(self, sample_idx, prec, tag):
+        """one-shot: the buffer bayesian_torch_amd.presample() left for exactly this (seed, sample, layer, prec, layout)"""
+        pre = getattr(self, "_btx_pre", None)
+        self._btx_pre = None
+        if pre is not None and pre[0] == (_rng.seed(), self._sample_key(sample_idx), self._btx_layer_id, prec, tag):
+            return pre[1]
+        return None
+
     def _forward_hip(self, x, noise=None, sample_idx=None, epilogue=None):
         mu, rho = self._w()
         mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
@@ -223,10 +263,12 @@ class _VariationalNd(BaseVariationalLayer_):
         mb = self.mu_bias.detach() if self.mu_bias is not None else None
         rb = self.rho_bias.detach() if self.rho_bias is not None else None
         op = self._op
+        self._btx_last_xshape = tuple(x.shape)
         plan = self._rowfuse_plan(x) if noise is None else None
         if plan is not None:  # small-C stem: one kernel row per K-stage on the LDS-DMA kernel
             mu_f, rho_f = BF.rowfuse_weights(mu_p, rho_p, plan)
             prec = self.precision or BF.get_precision()
+            pre = self._take_presampled(sample_idx, prec, ("rowfuse", plan["cp"], plan["kwp"]))
             # the padded copy is made in the MFMA dtype (the rounding a staging kernel would apply anyway); the
             # output keeps the caller's activation dtype
             xin = BF.rowfuse_input(x, plan).to(torch.bfloat16 if prec == "bf16" else torch.float32)
@@ -235,7 +277,7 @@ class _VariationalNd(BaseVariationalLayer_):
                 raise _lib.BtxError("residual epilogue is not available for this row-fused stem geometry")
             out = BF.contract_hip(kind, xin, mu_f, rho_f, mb, rb, plan["op"], _rng.seed(), sample_idx,
                                   self._btx_layer_id, prec=prec, extra_flags=_lib.FLAG_ROWFUSE, out_dtype=x.dtype,
-                                  epilogue=epilogue)
+                                  epilogue=epilogue, sampled_w=pre, sample_dev=getattr(self, "_btx_sample_dev", None))
             return out[:, :, :plan["Ho"], :plan["Wo"]]
         if self._btx_cpad is not None and noise is None:  # explicit noise (parity mode) stays unpadded -> gather kernel
             extra = self._btx_cpad - op.in_channels
@@ -243,8 +285,13 @@ class _VariationalNd(BaseVariationalLayer_):
             mu_p = torch.nn.functional.pad(mu_p, (0, extra))   # zero weights meet zero activations
             rho_p = torch.nn.functional.pad(rho_p, (0, extra))
             op = self._op_pad
+        pre = None
+        if noise is None:
+            tag = ("cpad", self._btx_cpad) if self._btx_cpad is not None else ("plain",)
+            pre = self._take_presampled(sample_idx, self.precision or BF.get_precision(), tag)
         return BF.contract_hip(kind, x, mu_p, rho_p, mb, rb, op, _rng.seed(), sample_idx,
-                               self._btx_layer_id, prec=self.precision, noise=noise, epilogue=epilogue)
+                               self._btx_layer_id, prec=self.precision, noise=noise, epilogue=epilogue, sampled_w=pre,
+                               sample_dev=getattr(self, "_btx_sample_dev", None))
 
     def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False):
         """`relu?(forward(x) * scale[c] + shift[c] (+ residual))` with the affine / residual / ReLU

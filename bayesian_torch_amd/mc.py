@@ -71,7 +71,7 @@ def mc_forward(model, x, num_samples, sample_offset=0, with_kl=False, group=None
     packed = None
     kl = float(get_kl_loss(model)) if with_kl else 0.0  # RNG-free: identical for every sample
     for s in range(rank, num_samples, world):
-        _rng.set_sample_index(model, sample_offset + s)
+        _rng.set_sample_index(model, sample_offset + s, presample=x.is_cuda)
         logits = model(x)
         if isinstance(logits, tuple):
             logits = logits[0]
@@ -86,3 +86,60 @@ def mc_forward(model, x, num_samples, sample_offset=0, with_kl=False, group=None
     if reduce and world > 1:
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return packed
+
+
+class GraphedMC:
+    """One Monte-Carlo sample — weight sampling, the model forward, the accumulation of the predictive statistics —
+    captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed per sample.
+
+    A converted ResNet18 step is ~50 kernel launches of 20-70 us; issued one by one from Python the host cannot keep
+    the GPU busy.  The graph removes the per-launch host work; what changes between samples — the sample index that
+    keys BTX-RNG v1 — lives in one device word (BtxRng.sample_idx_dev) that `run()` rewrites before each replay, so
+    every replay draws the noise of ITS sample index exactly as an eager forward with set_sample_index() would.
+
+        g = GraphedMC(model, x, kl=float(get_kl_loss(model)))
+        for s in my_samples: g.run(s)
+        stats = unpack(g.packed, *g.logits_shape)
+
+    The parameters must not be re-allocated while the graph is alive (in-place updates are seen by the replays)."""
+
+    def __init__(self, model, x, kl=0.0, warmup=2):
+        if not x.is_cuda:
+            raise ValueError("GraphedMC needs CUDA (ROCm) tensors")
+        self.model, self.x, self.kl = model, x, float(kl)
+        dev = x.device
+        self.sample_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._layers = [m for m in model.modules() if hasattr(m, "_btx_layer_id")]
+        for m in self._layers:
+            m._btx_sample_dev = self.sample_dev
+        self.packed = None
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup) + 1):  # 1st pass records the input shapes presample() needs
+                self._one()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self._one()
+        self.packed.zero_()
+
+    def _one(self):
+        _rng.presample(self.model, 0)
+        logits = self.model(self.x)
+        if isinstance(logits, tuple):
+            logits = logits[0]
+        if self.packed is None:
+            self.logits_shape = tuple(logits.shape)
+            self.packed = torch.zeros(packed_numel(*logits.shape), dtype=torch.float32, device=logits.device)
+        accumulate(self.packed, logits, self.kl)
+
+    def run(self, sample_idx):
+        self.sample_dev.fill_(int(sample_idx) & 0x7FFFFFFF)
+        self.graph.replay()
+
+    def close(self):
+        for m in self._layers:
+            m._btx_sample_dev = None
+            m._btx_pre = None

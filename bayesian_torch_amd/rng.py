@@ -43,8 +43,40 @@ def assign_layer_ids(model, start=1):
     return i
 
 
-def set_sample_index(model, idx):
-    """Pin the Monte-Carlo sample index used by the NEXT forward of every variational layer in `model`."""
+def set_sample_index(model, idx, presample=False):
+    """Pin the Monte-Carlo sample index used by the NEXT forward of every variational layer in `model`.
+    presample=True additionally samples the weights of all layers for that index in ONE launch (see presample())."""
     for m in model.modules():
         if hasattr(m, "_btx_layer_id"):
             m._btx_sample = int(idx)
+    if presample:
+        _presample(model, idx)
+
+
+def _presample(model, idx):
+    """Sample the weights of every variational layer of `model` for MC sample `idx` in one kernel launch
+    (btx_sample_weights) instead of one small pre-pass per layer.  The buffers are consumed by the next forward of each
+    layer if — and only if — it runs with the same (seed, sample index, layer id, precision, weight layout); call it
+    after the last parameter update before that forward.  Layers that have not seen an input yet, CPU layers and
+    explicit-noise calls simply sample in their own launch."""
+    from . import functional as BF
+    groups = {}
+    for m in model.modules():
+        if not hasattr(m, "presample_item") or not hasattr(m, "_btx_layer_id"):
+            continue
+        m._btx_pre = None
+        if not next(m.parameters()).is_cuda:
+            continue
+        it = m.presample_item(idx, BF.get_precision())
+        if it is None:
+            continue
+        key, item = it
+        groups.setdefault((key[3], next(m.parameters()).device), []).append((m, key, item))
+    for (prec, device), lst in groups.items():
+        bufs = BF.sample_weights([it for _, _, it in lst], seed(), idx, prec, device,
+                                 sample_dev=getattr(lst[0][0], "_btx_sample_dev", None))
+        for (m, key, _), buf in zip(lst, bufs):
+            m._btx_pre = (key, buf)
+
+
+presample = _presample

@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--act", default=None, choices=["bf16", "f32"], help="activation dtype (default = --prec)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/residual as separate torch ops")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every MC sample from Python instead of "
+                    "replaying one captured hipGraph per sample")
+    ap.add_argument("--no-presample", action="store_true", help="sample the weights per layer launch instead of once per MC sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: print host time of every timed step to stderr")
@@ -129,12 +132,22 @@ def main():
     with torch.no_grad():
         kl_t = bt.get_kl_loss(model)
     kl = float(kl_t)
-    packed = torch.zeros(mc.packed_numel(args.batch, 1000), dtype=torch.float32, device=dev)
+    graphed = None
+    if args.no_graph:
+        packed = torch.zeros(mc.packed_numel(args.batch, 1000), dtype=torch.float32, device=dev)
 
-    def step(s_global):
-        bt.set_sample_index(model, s_global)
-        logits = model(x)
-        mc.accumulate(packed, logits, kl)
+        def step(s_global):
+            bt.set_sample_index(model, s_global, presample=not args.no_presample)
+            logits = model(x)
+            mc.accumulate(packed, logits, kl)
+    else:
+        # one MC sample (weight sampling + 21 fused contractions + pooling + accumulation) = one hipGraph replay;
+        # the sample index is a device word the kernels read when they run (BtxRng.sample_idx_dev)
+        graphed = mc.GraphedMC(model, x, kl=kl)
+        packed = graphed.packed
+
+        def step(s_global):
+            graphed.run(s_global)
 
     def barrier():
         if world > 1:
@@ -151,7 +164,7 @@ def main():
         if world > 1:
             dist.all_reduce(packed)  # warm the communicator too
         packed.zero_()
-        if not args.no_launch_timing:
+        if not args.no_launch_timing and graphed is None:
             BF.enable_launch_timing(True)
         barrier()
         t0 = time.perf_counter()
@@ -164,6 +177,19 @@ def main():
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)
         barrier()
         elapsed = time.perf_counter() - t0
+    stats = packed.clone()
+    if graphed is not None:
+        graphed.close()
+        if not args.no_launch_timing:
+            # Kernel durations for the roofline: HIP events cannot bracket the nodes of a replayed graph, so the same
+            # launches are issued once more eagerly, with an event pair around each, right after the timed region.
+            scratch = torch.zeros_like(packed)
+            with torch.no_grad():
+                BF.enable_launch_timing(True)
+                for k in range(min(args.steps, 10)):
+                    bt.set_sample_index(model, k * world + rank, presample=not args.no_presample)
+                    mc.accumulate(scratch, model(x), kl)
+                torch.cuda.synchronize(dev)
     log = BF.launch_log() or []
     BF.enable_launch_timing(False)
 
@@ -175,6 +201,7 @@ def main():
     # roofline of the dominant kernel from the HIP events of the timed region
     roofline = None
     if log:
+        log_steps = args.steps if graphed is None else min(args.steps, 10)
         total_flops = sum(f for _, f, _, _ in log)
         total_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in log)
         achieved = total_flops / (total_ms * 1e-3) / 1e12
@@ -197,11 +224,15 @@ def main():
         roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": traffic, "kernel": "btx::contract_kernel<%s,%s,%s>" % (args.prec, act, args.type),
                     "launches": len(log), "avg_launch_us": 1e3 * total_ms / len(log),
-                    "kernel_time_frac_of_step": (total_ms * 1e-3) / elapsed,
-                    "algorithmic_gflop_per_step": total_flops / args.steps / 1e9, "top_launches": layers[:6]}
+                    "kernel_time_frac_of_step": (total_ms * 1e-3 / log_steps) / (elapsed / args.steps),
+                    "algorithmic_gflop_per_step": total_flops / log_steps / 1e9,
+                    "measured": "HIP events around every launch, " + (
+                        "timed region" if graphed is None else "eager re-issue of the same launches after the timed "
+                        "region (the timed region replays one hipGraph per MC sample)"),
+                    "top_launches": layers[:6]}
 
     if rank == 0:
-        u = mc.unpack(packed, args.batch, 1000)
+        u = mc.unpack(stats, args.batch, 1000)
         assert abs(float(u["samples"]) - args.steps * world) < 0.5, "work was skipped inside the timed region"
         assert torch.isfinite(u["mean_prob"]).all()
         out = {
@@ -210,9 +241,10 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "dnn_to_bnn(ResNet18) %s, 224x224, batch %d, %d MC samples per GPU, default init "
-                                   "(seed 0), activations %s, eval-BN/ReLU/residual %s" % (
+                                   "(seed 0), activations %s, eval-BN/ReLU/residual %s, %s" % (
                                        args.type, args.batch, args.steps, act,
-                                       "as torch ops" if args.no_fuse else "folded into the kernel epilogue"),
+                                       "as torch ops" if args.no_fuse else "folded into the kernel epilogue",
+                                       "eager launches" if graphed is None else "one hipGraph replay per MC sample"),
                        "global_batch": args.batch * world, "parallelism": "mc-sample-shard x%d" % world},
             "image_samples_per_s": args.batch * args.steps * world / elapsed,
             "kl": kl, "kl_rel_err": abs(kl - KL_KNOWN) / KL_KNOWN,

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BTX_ABI_VERSION 1
+#define BTX_ABI_VERSION 2
 
 /* argument-error codes (negative) */
 #define BTX_E_NULL        (-1)   /* required pointer is NULL */
@@ -92,6 +92,10 @@ typedef struct BtxRng {
   uint64_t seed;
   uint32_t sample_idx;           /* global Monte-Carlo sample index */
   uint32_t layer_id;
+  const uint32_t* sample_idx_dev; /* optional DEVICE pointer: when non-NULL the kernels read the sample index from it
+                                     when they run and sample_idx is ignored.  This is what lets one captured hipGraph
+                                     of a whole MC forward be replayed for successive samples (update the word, replay):
+                                     no per-launch host work in the Monte-Carlo loop. */
 } BtxRng;
 
 /* Optional explicit noise (parity mode).  Any member may be NULL => generated by BTX-RNG v1.
@@ -104,6 +108,9 @@ typedef struct BtxNoise {
   const float*  eps_b;
   const int8_t* sign_in;
   const int8_t* sign_out;
+  const void*   sampled_w;   /* weight tiles filled by btx_sample_weights for the same (seed, sample_idx, layer_id,
+                                kind, prec, geometry): the launch skips its own sampling pre-pass.  Not explicit noise:
+                                the values are BTX-RNG v1's.  Ignored by the kernels that sample in-register. */
 } BtxNoise;
 
 int         btx_abi_version(void);
@@ -158,6 +165,25 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g,
                         int act_dtype, int prec, uint32_t flags,
                         void* ws, size_t ws_bytes, void* stream,
                         const BtxEpilogue* epilogue /* nullable */);
+
+/* Sampling pre-pass, hoisted.  The LDS-DMA / patch kernels of btx_contract_fwd* first sample the layer's weights ONCE
+ * into MFMA-ready tiles (W = mu + sigma*eps for Reparameterization; mu and sigma*eps for Flipout; reference:
+ * conv_flipout.py:380-394, conv_variational.py:357-366 materialise the same tensors with ATen ops) and then contract.
+ * btx_sample_weights does that pre-pass for a whole model in one launch (per-layer launches cost more than the
+ * sampling itself); the buffers are handed to btx_contract_fwd* through BtxNoise.sampled_w.  `out` of each item must
+ * hold btx_sampled_w_bytes(geom, kind, prec) bytes (depends on N, K, groups only), 16-byte aligned; the tile layout is
+ * private to the library.  items_host is a HOST array, read before the call returns. */
+typedef struct BtxSampleItem {
+  const BtxGeom* geom;       /* host pointer */
+  const float*   mu_w;       /* device, GEMM-major, as passed to btx_contract_fwd */
+  const float*   rho_w;
+  void*          out;        /* device */
+  int32_t        kind;
+  uint32_t       layer_id;
+} BtxSampleItem;
+size_t btx_sampled_w_bytes(const BtxGeom* g, int kind, int prec);
+int btx_sample_weights(const BtxSampleItem* items_host, int n_items, const BtxRng* rng /* layer_id unused */,
+                       int prec, void* stream);
 
 /* Output spatial extent for a geometry (same arithmetic as torch's conv / conv_transpose). */
 int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, int32_t* Wo);

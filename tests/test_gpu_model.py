@@ -183,6 +183,91 @@ def test_fused_resnet18_matches_unfused():
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("prec,act", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_presample_is_bit_identical_and_one_shot(prec, act):
+    """bt.presample (one launch for the whole model) feeds the same kernels the same tiles their own pre-pass makes:
+    outputs must be bit-identical; a buffer sampled for another sample index must be ignored."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.resnet import resnet18
+    dev = _dev()
+    bt.manual_seed(5)
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(PRIOR, type="Flipout"))
+    m = m.to(dev).eval()
+    bt.assign_layer_ids(m)
+    bt.set_precision(prec)
+    try:
+        x = torch.randn(2, 3, 224, 224, device=dev).to(act)
+        if act == torch.bfloat16:
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.to(torch.bfloat16)
+        with torch.no_grad():
+            bt.set_sample_index(m, 4)
+            y4 = m(x)                                  # also records the input shapes the stem layouts depend on
+            bt.set_sample_index(m, 9)
+            y9 = m(x)
+            bt.set_sample_index(m, 9, presample=True)
+            n_pre = sum(1 for mod in m.modules() if getattr(mod, "_btx_pre", None) is not None)
+            y9p = m(x)
+            assert all(getattr(mod, "_btx_pre", None) is None for mod in m.modules())  # consumed
+            bt.presample(m, 9)                         # stale on purpose: the forward below runs sample 4
+            bt.set_sample_index(m, 4)
+            y4s = m(x)
+        assert n_pre == 21
+        assert torch.equal(y9, y9p)
+        assert torch.equal(y4, y4s)
+        assert not torch.equal(y4, y9)
+    finally:
+        bt.set_precision("f32")
+
+
+def test_graphed_mc_replays_equal_eager_samples():
+    """mc.GraphedMC: one captured hipGraph, replayed with the sample index in device memory, must reproduce the eager
+    forwards of exactly those sample indices (same kernels, same noise, same accumulation order -> bit-identical)."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd.models.resnet import resnet18
+    dev = _dev()
+    bt.manual_seed(11)
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(PRIOR, type="Flipout"))
+    m = m.to(dev).eval()
+    bt.assign_layer_ids(m)
+    bt.set_precision("bf16")
+    try:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.to(torch.bfloat16)
+        x = torch.randn(2, 3, 224, 224, device=dev).to(torch.bfloat16)
+        samples = [3, 8, 1000003]
+        eager = torch.zeros(mc.packed_numel(2, 1000), dtype=torch.float32, device=dev)
+        singles = []
+        with torch.no_grad():
+            for s_ in samples:
+                bt.set_sample_index(m, s_)
+                y = m(x)
+                singles.append(y.float().clone())
+                mc.accumulate(eager, y, 0.5)
+        assert not torch.equal(singles[0], singles[1])
+        g = mc.GraphedMC(m, x, kl=0.5)
+        for s_ in samples:
+            g.run(s_)
+        torch.cuda.synchronize()
+        got = g.packed.clone()
+        g.close()
+        assert torch.equal(got, eager)
+        u = mc.unpack(got, 2, 1000)
+        assert abs(float(u["samples"]) - 3) < 1e-6
+        with torch.no_grad():  # the layers are back to host-side sample indices
+            bt.set_sample_index(m, 8)
+            assert torch.equal(m(x).float(), singles[1])
+    finally:
+        bt.set_precision("f32")
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
