@@ -246,7 +246,7 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* p
   // each split keeps >= 4 stages so the DMA ring fills.
   int ks = 1;
   {
-    const long long ncu = 256;
+    const long long ncu = (bm == 256) ? 512 : 256;  // 256-pixel tiles run two blocks per CU
     long long best = -1;
     const int max_ks = stages / 4 > 1 ? (stages / 4 < 32 ? stages / 4 : 32) : 1;
     for (int c = 1; c <= max_ks; ++c) {
@@ -377,6 +377,11 @@ size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, i
   size_t wa = plan_ws(a, g);  // which kernel runs also depends on pointer alignment
   const size_t wb = pad256(plan_ws(b, g)) + patch_wt_bytes(b, g, BTX_KIND_FLIPOUT, prec, nullptr);
   if (wb > wa) wa = wb;
+  Plan b4;
+  if (!make_plan(g, prec, flags, 256, &b4)) {
+    const size_t w4 = pad256(plan_ws(b4, g)) + patch_wt_bytes(b4, g, BTX_KIND_FLIPOUT, prec, nullptr);
+    if (w4 > wa) wa = w4;
+  }
   Plan c;
   PatchPlan pt;
   if (make_patch_plan(g, act_dtype, prec, flags, &c, &pt)) {
@@ -428,8 +433,11 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     if (!ok) return BTX_E_UNSUPPORTED;
     dma = true;
   }
+  // LDS-DMA variant: 4-wave blocks on 256-pixel tiles (two per CU) unless BTX_DMA_NW=8 (A/B measurements)
+  static const char* dnw_env = getenv("BTX_DMA_NW");
+  const int dma_nw = (dnw_env && atoi(dnw_env) == 8) ? 8 : 4;
   if (dma) {
-    rc = make_plan(g, prec, flags, DBM, &pl);
+    rc = make_plan(g, prec, flags, 64 * dma_nw, &pl);
     if (rc) return rc;
   }
   // patch variant: stride-1 2-D convolutions keep the halo'd input patch of the tile in LDS (BTX_NO_PATCH=1 disables)
@@ -491,6 +499,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.KW = 1;
     p.sign_unaligned = 1;
   }
+  p.fd_Cg = make_fastdiv((uint32_t)p.Cg); p.fd_KW = make_fastdiv((uint32_t)p.KW); p.fd_KH = make_fastdiv((uint32_t)p.KH);
   p.seed_lo = (uint32_t)rng->seed; p.seed_hi = (uint32_t)(rng->seed >> 32);
   p.sample = rng->sample_idx; p.layer = rng->layer_id;
   p.sample_ptr = rng->sample_idx_dev;
@@ -504,6 +513,10 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   }
 
   if (const char* tp = getenv("BTX_TRACE_PTR")) p.trace = (void*)strtoull(tp, nullptr, 0);  // BTX_PT_TRACE builds only
+  p.pt_nw = dma_nw;
+  p.fd_inner = make_fastdiv((uint32_t)(pl.ntiles * g->groups * pl.ksplits)); p.fd_ksplits = make_fastdiv((uint32_t)pl.ksplits);
+  p.fd_ntiles = make_fastdiv((uint32_t)pl.ntiles); p.fd_rtiles = make_fastdiv(1u);
+  p.fd_Wo = make_fastdiv((uint32_t)pl.Wo); p.fd_Ho = make_fastdiv((uint32_t)pl.Ho); p.fd_Do = make_fastdiv((uint32_t)pl.Do);
   if (dma) {
     p.wt = sampled_w ? (void*)sampled_w : (void*)((unsigned char*)ws + wt_off);
     p.wt_ready = sampled_w ? 1 : 0;
@@ -515,6 +528,8 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (patch) {
     p.pt_G = pt.G; p.pt_R = pt.R; p.pt_Rp = pt.Rp; p.pt_Wp = pt.Wp; p.pt_PP = pt.PP; p.pt_NI = pt.NI;
+    p.fd_ptWp = make_fastdiv((uint32_t)pt.Wp); p.fd_ptRp = make_fastdiv((uint32_t)pt.Rp); p.fd_ptR = make_fastdiv((uint32_t)pt.R);
+    p.fd_rtiles = make_fastdiv((uint32_t)pt.rtiles);
     p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg, st)
                                  : launch_contract_patch_f32(kind, p, pl.nwg, st);

@@ -56,6 +56,30 @@ constexpr int WDL_OFF = WMU_OFF + NG * BN * 16;  // [NG][BN] x 16 B
 constexpr int STAGE_BYTES = WDL_OFF + NG * BN * 16;  // 28672
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // 57344
 
+// Division by a launch-invariant divisor (Granlund-Montgomery / Hacker's Delight 10-9): the host precomputes
+// (m, sh1, sh2), the device spends one mul_hi and four integer ops instead of the ~45-instruction generic sequence.
+// The tile prologues decode ~20 pixel indices per lane; with generic divisions that alone cost ~8000 cycles per block.
+struct FastDiv {
+  uint32_t m, sh;  // sh = sh1 | sh2 << 8
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  f.sh = (l < 1 ? l : 1) | ((l > 0 ? l - 1 : 0) << 8);
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t x, const FastDiv& f) {
+  const uint32_t t = __umulhi(x, f.m);
+  return (t + ((x - t) >> (f.sh & 31u))) >> (f.sh >> 8);
+}
+// quotient and remainder; d is the divisor the FastDiv was made for
+__device__ __forceinline__ void fdivmod(uint32_t x, const FastDiv& f, uint32_t d, uint32_t& q, uint32_t& r) {
+  q = fdiv(x, f);
+  r = x - q * d;
+}
+
 // patch variant (btx_contract_patch.h)
 constexpr int PT_WD = 4;  // depth of the weight-tile ring: W(s+3) is fetched while stage s multiplies and s+1 is read
 constexpr int PT_EP_ROW = 272;
@@ -94,6 +118,8 @@ struct ContractParams {
   uint32_t x_bytes, w_bytes;  // sizes of x and of mu/rho in bytes (buffer descriptors of the DMA variant)
   // patch variant (btx_contract_patch.h): tile = pt_G images x pt_R output rows x Wo; patch = pt_G x pt_Rp x pt_Wp pixels
   int pt_G, pt_R, pt_Rp, pt_Wp, pt_PP, pt_NI, pt_rtiles;
+  FastDiv fd_Wo, fd_Ho, fd_Do, fd_ptWp, fd_ptRp, fd_ptR;
+  FastDiv fd_inner, fd_ksplits, fd_ntiles, fd_Cg, fd_KW, fd_KH, fd_rtiles;  // wave-uniform index splits
   void* trace;  // BTX_PT_TRACE builds: per-wave phase timings (measurement only)
   int pt_nw, pt_astage, pt_lds;  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off

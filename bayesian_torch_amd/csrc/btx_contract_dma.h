@@ -44,17 +44,27 @@
 
 namespace btx {
 
-constexpr int DBM = 512;                    // pixels per workgroup tile (DMA variant)
+constexpr int DBM = 512;                    // pixels per workgroup tile, 8-wave blocks (one per CU)
 constexpr int DMA_D = 3;                    // activation + sign ring depth
-constexpr int DA_STAGE = NG * DBM * 16;     // 32768
-constexpr int DS_STAGE = DBM * 4;           // 2048 : one sign word per (pixel, stage)
 constexpr int DW_STAGE = 2 * NG * BN * 16;  // 8192 : mu tile at +0, delta tile at +4096
-constexpr int DA_OFF = 0;
-constexpr int DS_OFF = DA_OFF + DMA_D * DA_STAGE;     // 98304
-constexpr int DW_OFF = DS_OFF + DMA_D * DS_STAGE;     // 104448 : PT_WD weight tiles (pre-sampled, btx_presample.h)
-constexpr int DMA_LDS_MAIN = DW_OFF + PT_WD * DW_STAGE;  // 137216
-constexpr int DMA_LDS_EP = (NTHREADS / 64) * PT_EP_WAVE + 1024;  // 140288: epilogue staging (btx_epilogue.h)
-constexpr int DMA_LDS_BYTES = DMA_LDS_MAIN > DMA_LDS_EP ? DMA_LDS_MAIN : DMA_LDS_EP;
+// LDS map of a block of NW waves (tile = 64*NW pixels): DMA_D activation stages, DMA_D sign stages, WD weight tiles
+// (pre-sampled, btx_presample.h); the epilogue staging (btx_epilogue.h) reuses the same bytes.  4-wave blocks
+// (256 pixels) fit 80 KiB, so two share a CU: one block's prologue/epilogue overlaps the other's K loop — what layers
+// with few K stages (stems, 1x1 convs) need.
+template <int NW>
+struct DmaLds {
+  static constexpr int TP = 64 * NW;               // pixels per tile
+  static constexpr int WD = (NW == 4) ? 3 : 4;     // weight-tile ring depth; W(s + WD - 1) is fetched during stage s
+  static constexpr int A_STAGE = NG * TP * 16;     // 32768 | 16384
+  static constexpr int S_STAGE = TP * 4;           // one sign word per (pixel, stage)
+  static constexpr int A_OFF = 0;
+  static constexpr int S_OFF = A_OFF + DMA_D * A_STAGE;
+  static constexpr int W_OFF = S_OFF + DMA_D * S_STAGE;
+  static constexpr int MAIN = W_OFF + WD * DW_STAGE;          // 137216 | 76800
+  static constexpr int EP = NW * PT_EP_WAVE + 1024;           // 140288 | 70656
+  static constexpr int BYTES = MAIN > EP ? MAIN : EP;
+};
+static_assert(DmaLds<4>::BYTES <= 81920 && DmaLds<8>::BYTES <= 163840, "LDS budget");
 
 constexpr uint32_t DMA_OOB = 0xfffffff0u;  // byte offset beyond every descriptor: the hardware returns zeros
 
@@ -78,8 +88,15 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 }
 #undef BTX_VMCNT_CASE
 
-template <int PREC, int KIND>
-__global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const ContractParams p) {
+template <int PREC, int KIND, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const ContractParams p) {
+  using LD = DmaLds<NW>;
+  constexpr int TP = LD::TP, WD = LD::WD, DA_STAGE = LD::A_STAGE, DS_STAGE = LD::S_STAGE, DA_OFF = LD::A_OFF,
+                DS_OFF = LD::S_OFF, DW_OFF = LD::W_OFF;
+#ifdef BTX_PT_TRACE
+  const uint32_t tr_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+  uint32_t tr_ab = 0, tr_bc = 0, tr_cd = 0, tr_t1 = 0, tr_t2 = 0, tr_tg = 0;
+#endif
   const RngLive rl = rng_live<KIND>(p);
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   const int l31 = lane & 31;
   const int h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool upper = wave >= 4;  // waves 4-7 issue their DMAs after the MFMA block (see the main loop)
+  const bool upper = (NW == 8) ? (wave >= 4) : ((wave & 1) != 0);  // these waves issue their DMAs after the MFMA block
 
   int logical;
   {
@@ -99,17 +116,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
     const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
-  const int inner = p.ntiles * p.groups * p.ksplits;
-  const int mtile = logical / inner;
-  int rem = logical - mtile * inner;
-  const int split = rem % p.ksplits;
-  rem /= p.ksplits;
-  const int ntile = rem % p.ntiles;
-  const int group = rem / p.ntiles;
+  uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
+  fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
+  fdivmod(u_rem, p.fd_ksplits, (uint32_t)p.ksplits, u_t, u_split);
+  fdivmod(u_t, p.fd_ntiles, (uint32_t)p.ntiles, u_group, u_ntile);
+  const int mtile = (int)u_mtile, split = (int)u_split, ntile = (int)u_ntile, group = (int)u_group;
 
   const int k_begin = split * p.kper;
   const int k_end = min(p.K, k_begin + p.kper);
   const int nstages = (k_end - k_begin + BK - 1) / BK;
+
+  const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.wt_bytes, 0x00020000);
+  // ---- weight loader role: the stage's tile is 4 rows of mu (+ 4 rows of delta, Flipout) of 1 KiB in the pre-sampled
+  //      buffer.  8 waves: wave w fetches mu row w (w < 4) or delta row w-4;  4 waves: mu row w and delta row w.
+  const bool w_mu = (NW == 4) || (wave < 4);
+  const bool w_dl = (KIND == 1) && ((NW == 4) || (wave >= 4));
+  const int w_nops = (w_mu ? 1 : 0) + (w_dl ? 1 : 0);
+  const uint32_t w_base = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u + (uint32_t)lane * 16u +
+                          (uint32_t)(wave & 3) * 1024u + (uint32_t)(k_begin / G) * 1024u;
+  const int w_lds = DW_OFF + (wave & 3) * 1024;
+
+  auto issue_w = [&](int st) __attribute__((always_inline)) {
+    const uint32_t go = w_base + (uint32_t)st * (uint32_t)(BK / G) * 1024u;
+    unsigned char* ld = smem + w_lds + (st % WD) * DW_STAGE;
+    if (w_mu) dma16(wt_rsrc, go, ld);
+    if (w_dl) dma16(wt_rsrc, go + p.wt_delta_off, ld + 4096);
+  };
+  // the first weight tiles need nothing but the tile indices: their latency hides behind the pixel geometry below
+  for (int s = 0; s < WD - 1 && s < nstages; ++s) issue_w(s);
 
   // ---- loader role.  DMA instruction q (0..3) of wave w moves pixels 64w + 16q + (lane>>2), granule slot lane&3;
   //      each lane therefore keeps the geometry of FOUR pixels.  All offsets are 32-bit (host guarantees < 2^31
@@ -119,12 +153,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   uint32_t pb_off[4];
   bool pb_ok[4];
   auto decode = [&](int mm_, int& bd_, int& bh_, int& bw_, int& nbase_, uint32_t& off_) __attribute__((always_inline)) {
-    const int ow = mm_ % p.Wo;
-    int t = mm_ / p.Wo;
-    const int oh = t % p.Ho;
-    t /= p.Ho;
-    const int od = t % p.Do;
-    const int nb = t / p.Do;
+    uint32_t t, t2, uow, uoh, uod, unb;
+    fdivmod((uint32_t)mm_, p.fd_Wo, (uint32_t)p.Wo, t, uow);
+    fdivmod(t, p.fd_Ho, (uint32_t)p.Ho, t2, uoh);
+    fdivmod(t2, p.fd_Do, (uint32_t)p.Do, unb, uod);
+    const int ow = (int)uow, oh = (int)uoh, od = (int)uod, nb = (int)unb;
     nbase_ = nb * p.D;
     if (!p.transposed) {
       bd_ = od * p.sd - p.pd; bh_ = oh * p.sh - p.ph; bw_ = ow * p.sw - p.pw;
@@ -135,40 +168,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   };
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int mq = mtile * DBM + wave * 64 + q * 16 + (lane >> 2);
+    const int mq = mtile * TP + wave * 64 + q * 16 + (lane >> 2);
     pb_ok[q] = mq < p.M;
     decode(pb_ok[q] ? mq : 0, pb_d[q], pb_h[q], pb_w[q], pb_n[q], pb_off[q]);
   }
-  // tap-validity bitmasks (one bit per filter tap, computed once per workgroup) when the filter has <= 32 taps
-  const int ntaps = p.KD * p.KH * p.KW;
-  const bool use_mask = (ntaps <= 32) && !p.transposed;  // uniform
-  uint32_t vmask0 = 0u, vmask1 = 0u, vmask2 = 0u, vmask3 = 0u;
+  // tap validity, one bitmask per axis and pixel (bit k: tap k of that axis reads inside the input), computed once per
+  // workgroup with KD + KH + KW iterations; a tap is valid iff its three bits are set
+  const bool use_mask = (p.KD <= 32) && (p.KH <= 32) && (p.KW <= 32) && !p.transposed;  // uniform
+  uint32_t md[4] = {0u, 0u, 0u, 0u}, mh[4] = {0u, 0u, 0u, 0u}, mw[4] = {0u, 0u, 0u, 0u};
   if (use_mask) {
-    int t = 0;
-    for (int kd = 0; kd < p.KD; ++kd)
-      for (int kh = 0; kh < p.KH; ++kh)
-        for (int kw = 0; kw < p.KW; ++kw, ++t) {
-          // written out per pixel (no array indexing inside a runtime loop: keeps everything in registers)
-#define BTX_TAP_OK(q)                                                                                             \
-  ((pb_ok[q] && (unsigned)(pb_d[q] + kd * p.dd) < (unsigned)p.D && (unsigned)(pb_h[q] + kh * p.dh) < (unsigned)p.H && \
-    (unsigned)(pb_w[q] + kw * p.dw) < (unsigned)p.W) ? (1u << t) : 0u)
-          vmask0 |= BTX_TAP_OK(0);
-          vmask1 |= BTX_TAP_OK(1);
-          vmask2 |= BTX_TAP_OK(2);
-          vmask3 |= BTX_TAP_OK(3);
-#undef BTX_TAP_OK
-        }
+    for (int k = 0; k < p.KD; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) md[q] |= (pb_ok[q] && (unsigned)(pb_d[q] + k * p.dd) < (unsigned)p.D) ? (1u << k) : 0u;
+    }
+    for (int k = 0; k < p.KH; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mh[q] |= ((unsigned)(pb_h[q] + k * p.dh) < (unsigned)p.H) ? (1u << k) : 0u;
+    }
+    for (int k = 0; k < p.KW; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mw[q] |= ((unsigned)(pb_w[q] + k * p.dw) < (unsigned)p.W) ? (1u << k) : 0u;
+    }
   }
-  const uint32_t vmask[4] = {vmask0, vmask1, vmask2, vmask3};
   // byte offset of this lane's granule inside its pixel, folded into the per-pixel base
   uint32_t pb_boff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) pb_boff[q] = (pb_off[q] + (uint32_t)(G * g_lane)) * (uint32_t)sizeof(ACT);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.wt_bytes, 0x00020000);
   uint32_t sg_off;  // this thread's own pixel (tid): only the sign word needs it
   {
-    const int m = mtile * DBM + tid;
+    const int m = mtile * TP + tid;
     int a_, b_, c_, d_;
     decode(m < p.M ? m : 0, a_, b_, c_, d_, sg_off);
   }
@@ -176,30 +205,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   // wave-uniform K walk: channel offset inside the tap and the tap itself
   int s_c, s_kd, s_kh, s_kw, s_tap;
   {
-    const int tap = k_begin / p.Cg;
-    s_tap = tap;
-    s_c = k_begin - tap * p.Cg;
-    s_kw = tap % p.KW;
-    const int t2 = tap / p.KW;
-    s_kh = t2 % p.KH;
-    s_kd = t2 / p.KH;
+    uint32_t tap, c0, t2, kw0, kd0, kh0;
+    fdivmod((uint32_t)k_begin, p.fd_Cg, (uint32_t)p.Cg, tap, c0);
+    fdivmod(tap, p.fd_KW, (uint32_t)p.KW, t2, kw0);
+    fdivmod(t2, p.fd_KH, (uint32_t)p.KH, kd0, kh0);
+    s_tap = (int)tap; s_c = (int)c0; s_kw = (int)kw0; s_kh = (int)kh0; s_kd = (int)kd0;
   }
-
-  // ---- weight loader role: the stage's tile is 4 rows of mu (+ 4 rows of delta, Flipout) of 1 KiB in the pre-sampled
-  //      buffer; wave w fetches mu row w (w < 4) or delta row w-4 with one DMA instruction.
-  const bool w_wave = (KIND == 1) || (wave < 4);
-  const uint32_t w_base = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u + (uint32_t)lane * 16u +
-                          (uint32_t)(wave & 3) * 1024u + (wave >= 4 ? p.wt_delta_off : 0u) +
-                          (uint32_t)(k_begin / G) * 1024u;
-  const int w_lds = DW_OFF + (wave & 3) * 1024 + (wave >= 4 ? 4096 : 0);
 
   int a_slot_issue = 0;  // ring slot the next issue_acts() fills
 
   // =================== issue: all L2 -> LDS traffic of one stage (called for stages 0,1,2,... in order) ======
-  auto issue_w = [&](int st) __attribute__((always_inline)) {
-    if (w_wave)
-      dma16(wt_rsrc, w_base + (uint32_t)st * (uint32_t)(BK / G) * 1024u, smem + w_lds + (st & (PT_WD - 1)) * DW_STAGE);
-  };
   auto issue_acts = [&]() __attribute__((always_inline)) {  // stages in order: the K walk advances by one stage per call
     // activations: one tap for the whole stage; tap_off is wave-uniform
     uint32_t tap_off = 0;
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
       bool ok;
       uint32_t bo;
       if (use_mask) {
-        ok = (vmask[q] >> s_tap) & 1u;
+        ok = ((md[q] >> s_kd) & (mh[q] >> s_kh) & (mw[q] >> s_kw) & 1u) != 0u;
         bo = pb_boff[q] + tap_boff;
       } else if (!p.transposed) {
         const int id = pb_d[q] + s_kd * p.dd, ih = pb_h[q] + s_kh * p.dh, iw = pb_w[q] + s_kw * p.dw;
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
       // activations are zero, so the word is irrelevant there.  Transposed: recompute the input offset.)
       uint32_t off = sg_off + tap_off;
       if (p.transposed) {
-        const int m = mtile * DBM + tid;
+        const int m = mtile * TP + tid;
         int bd_, bh_, bw_, nb_;
         uint32_t o_;
         decode(m < p.M ? m : 0, bd_, bh_, bw_, nb_, o_);
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   auto mma_stage = [&](int st, int a_slot) __attribute__((always_inline)) {
     const unsigned char* as = smem + DA_OFF + a_slot * DA_STAGE;
     const unsigned char* ss = smem + DS_OFF + a_slot * DS_STAGE;
-    const unsigned char* ws = smem + DW_OFF + (st & (PT_WD - 1)) * DW_STAGE;
+    const unsigned char* ws = smem + DW_OFF + (st % WD) * DW_STAGE;
     uint32_t sw[2];
     if constexpr (KIND == 1) {
 #pragma unroll
@@ -353,60 +368,108 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_dma_kernel(const Contrac
   };
 
   // =================== main loop ==========================================================================
-  // Iteration s: every wave issues W(s+3) and acts(s+2), multiplies stage s, waits until everything it issued BEFORE
+  // Iteration s: every wave issues W(s+WD-1) and acts(s+2), multiplies stage s, waits until everything it issued BEFORE
   // this iteration has landed (vmcnt retires in order: at most this iteration's operations stay in flight) and meets
   // the others at one barrier.  acts(s+1) (issued one iteration ago) and W(s+1) (two iterations ago) are then visible.
   // The DMA instructions block at issue while the memory pipeline is full: waves 0-3 issue at the top of the
   // iteration, waves 4-7 after their MFMA block, so that of the two waves sharing a SIMD one is free to compute while
   // the other is stuck issuing.
+#ifdef BTX_PT_TRACE
+  tr_tg = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
   if (nstages > 0) {
-    for (int s = 0; s < PT_WD - 1 && s < nstages; ++s) issue_w(s);
     issue_acts();
     if (nstages > 1) issue_acts();
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int a_slot = 0;
+#ifdef BTX_PT_TRACE
+    tr_t1 = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     for (int s = 0; s < nstages; ++s) {
+#ifdef BTX_PT_TRACE
+      const uint32_t tA = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
       const bool acts_issued = s + 2 < nstages;
-      const bool w_issued = s + PT_WD - 1 < nstages;
+      const bool w_issued = s + WD - 1 < nstages;
       if (!upper) {
-        if (w_issued) issue_w(s + PT_WD - 1);
+        if (w_issued) issue_w(s + WD - 1);
         if (acts_issued) issue_acts();
       }
       mma_stage(s, a_slot);
       if (upper) {
-        if (w_issued) issue_w(s + PT_WD - 1);
+        if (w_issued) issue_w(s + WD - 1);
         if (acts_issued) issue_acts();
       }
-      wait_vmcnt((acts_issued ? 4 : 0) + ((w_issued && w_wave) ? 1 : 0));
+#ifdef BTX_PT_TRACE
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t tB = (uint32_t)__builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      wait_vmcnt((acts_issued ? 4 : 0) + (w_issued ? w_nops : 0));
+#ifdef BTX_PT_TRACE
+      const uint32_t tC = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef BTX_PT_TRACE
+      const uint32_t tD = (uint32_t)__builtin_amdgcn_s_memtime();
+      tr_ab += tB - tA; tr_bc += tC - tB; tr_cd += tD - tC;
+#endif
       a_slot = (a_slot == DMA_D - 1) ? 0 : a_slot + 1;
     }
   }
 
   // =================== epilogue (btx_epilogue.h) ============================================================
   {
-    const uint32_t m0 = (uint32_t)mtile * (uint32_t)DBM;
-    const int nvalid = min(DBM, p.M - (int)m0);
-    staged_epilogue<KIND, NTHREADS / 64>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    const uint32_t m0 = (uint32_t)mtile * (uint32_t)TP;
+    const int nvalid = min(TP, p.M - (int)m0);
+#ifdef BTX_PT_TRACE
+    tr_t2 = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+#ifdef BTX_EP_TRACE
+    uint32_t ep_t[2] = {0, 0};
+    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid, ep_t);
+    tr_ab = ep_t[0] - tr_t2; tr_bc = ep_t[1] - ep_t[0];
+#else
+    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+#endif
   }
+#ifdef BTX_PT_TRACE
+  if (p.trace) {
+#ifdef BTX_EP_TRACE
+    const uint32_t tr_tx = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t tr_t3 = (uint32_t)__builtin_amdgcn_s_memtime();
+#ifdef BTX_EP_TRACE
+    tr_cd = tr_t3 - tr_tx;
+#endif
+    if (lane == 0) {
+      uint32_t* tr = (uint32_t*)p.trace + (size_t)(blockIdx.x * NW + wave) * 8;
+      tr[0] = tr_t1 - tr_t0; tr[1] = tr_ab; tr[2] = tr_bc; tr[3] = tr_cd; tr[4] = tr_t3 - tr_t2; tr[5] = tr_t3 - tr_t0;
+      tr[6] = tr_t0; tr[7] = tr_tg - tr_t0;  // geometry part of the prologue
+    }
+  }
+#endif
 }
 
 template <int PREC>
 static int launch_contract_dma_impl(int kind, const ContractParams& p, int nwg, hipStream_t st) {
-#define BTX_LAUNCH_DMA(KIND)                                                                                        \
-  do {                                                                                                              \
-    auto kfn = contract_dma_kernel<PREC, KIND>;                                                                     \
-    static bool attr_done = false;                                                                                  \
-    if (!attr_done) {                                                                                               \
-      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES); \
-      if (e != hipSuccess) return (int)e;                                                                           \
-      attr_done = true;                                                                                             \
-    }                                                                                                               \
-    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(NTHREADS), DMA_LDS_BYTES, st, p);                                       \
+#define BTX_LAUNCH_DMA(KIND, NW)                                                                                        \
+  do {                                                                                                                  \
+    auto kfn = contract_dma_kernel<PREC, KIND, NW>;                                                                     \
+    static bool attr_done = false;                                                                                      \
+    if (!attr_done) {                                                                                                   \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, DmaLds<NW>::BYTES); \
+      if (e != hipSuccess) return (int)e;                                                                               \
+      attr_done = true;                                                                                                 \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(64 * NW), DmaLds<NW>::BYTES, st, p);                                        \
   } while (0)
   int rc = launch_presample_impl<PREC>(kind, p, st);
   if (rc) return rc;
-  if (kind == 0) BTX_LAUNCH_DMA(0); else BTX_LAUNCH_DMA(1);
+  if (p.pt_nw == 4) { if (kind == 0) BTX_LAUNCH_DMA(0, 4); else BTX_LAUNCH_DMA(1, 4); }
+  else { if (kind == 0) BTX_LAUNCH_DMA(0, 8); else BTX_LAUNCH_DMA(1, 8); }
 #undef BTX_LAUNCH_DMA
   return (int)hipGetLastError();
 }

@@ -64,17 +64,16 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
-  const int inner = p.ntiles * p.groups * p.ksplits;
-  const int mtile = logical / inner;
-  int rem = logical - mtile * inner;
-  const int split = rem % p.ksplits;
-  rem /= p.ksplits;
-  const int ntile = rem % p.ntiles;
-  const int group = rem / p.ntiles;
+  uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
+  fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
+  fdivmod(u_rem, p.fd_ksplits, (uint32_t)p.ksplits, u_t, u_split);
+  fdivmod(u_t, p.fd_ntiles, (uint32_t)p.ntiles, u_group, u_ntile);
+  const int mtile = (int)u_mtile, split = (int)u_split, ntile = (int)u_ntile, group = (int)u_group;
 
   // tile geometry
-  const int ig = mtile / p.pt_rtiles;                 // image group
-  const int rt = mtile - ig * p.pt_rtiles;            // row tile
+  uint32_t u_ig, u_rt;
+  fdivmod((uint32_t)mtile, p.fd_rtiles, (uint32_t)p.pt_rtiles, u_ig, u_rt);
+  const int ig = (int)u_ig, rt = (int)u_rt;           // image group, row tile
   const int img0 = ig * p.pt_G, row0 = rt * p.pt_R;   // first image / first output row of the tile
   const int T = p.KH * p.KW;
   const int ncb_total = p.Cg / BK;
@@ -99,10 +98,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     const int q = 16 * (wave + NW * j) + (lane >> 2);
     uint32_t bo = DMA_OOB;
     if (j < p.pt_NI && q < p.pt_PP) {
-      const int pc = q % p.pt_Wp;
-      const int t = q / p.pt_Wp;
-      const int pr = t % p.pt_Rp;
-      const int gi = t / p.pt_Rp;
+      uint32_t ut, upc, ugi, upr;
+      fdivmod((uint32_t)q, p.fd_ptWp, (uint32_t)p.pt_Wp, ut, upc);
+      fdivmod(ut, p.fd_ptRp, (uint32_t)p.pt_Rp, ugi, upr);
+      const int pc = (int)upc, pr = (int)upr, gi = (int)ugi;
       const int img = img0 + gi, ih = row0 + pr - p.ph, iw = pc - p.pw;
       if (img < p.NB && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
         bo = ((uint32_t)((img * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) *
@@ -118,10 +117,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     const int q = tid + NT * j;
     sg_ok[j] = q < p.pt_PP;
     const int qq = sg_ok[j] ? q : 0;
-    const int pc = qq % p.pt_Wp;
-    const int t = qq / p.pt_Wp;
-    const int pr = t % p.pt_Rp;
-    const int gi = t / p.pt_Rp;
+    uint32_t ut, upc, ugi, upr;
+    fdivmod((uint32_t)qq, p.fd_ptWp, (uint32_t)p.pt_Wp, ut, upc);
+    fdivmod(ut, p.fd_ptRp, (uint32_t)p.pt_Rp, ugi, upr);
+    const int pc = (int)upc, pr = (int)upr, gi = (int)ugi;
     sg_off[j] = (uint32_t)(((img0 + gi) * p.H + (row0 + pr - p.ph)) * p.W + (pc - p.pw)) * (uint32_t)p.C +
                 (uint32_t)(group * p.Cg);
   }
@@ -130,10 +129,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const int pl = wave * 64 + mi * 32 + l31;
-    const int c = pl % p.Wo;
-    const int t = pl / p.Wo;
-    const int r = t % p.pt_R;
-    const int gi = t / p.pt_R;
+    uint32_t ut, uc, ugi, ur;
+    fdivmod((uint32_t)pl, p.fd_Wo, (uint32_t)p.Wo, ut, uc);
+    fdivmod(ut, p.fd_ptR, (uint32_t)p.pt_R, ugi, ur);
+    const int c = (int)uc, r = (int)ur, gi = (int)ugi;
     const bool ok = (gi < p.pt_G) && (img0 + gi < p.NB) && (row0 + r < p.Ho);
     q0[mi] = ok ? (gi * p.pt_Rp + r) * p.pt_Wp + c : 0;
   }
