@@ -221,6 +221,13 @@ int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, in
   return 0;
 }
 
+// workgroup slots the split-K cost model assumes for 4-wave blocks (two per CU); BTX_SLOTS4 overrides (measurements)
+static long long slots4() {
+  static const char* e = getenv("BTX_SLOTS4");
+  static const long long v = e ? atoll(e) : 512;
+  return v > 0 ? v : 512;
+}
+
 // tiling plan shared by btx_contract_workspace_bytes and btx_contract_fwd
 struct Plan {
   int Do, Ho, Wo, Cg, Ng, M, K, mtiles, ntiles, ksplits, kper, nwg;
@@ -246,7 +253,7 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* p
   // each split keeps >= 4 stages so the DMA ring fills.
   int ks = 1;
   {
-    const long long ncu = (bm == 256) ? 512 : 256;  // 256-pixel tiles run two blocks per CU
+    const long long ncu = (bm == 256) ? slots4() : 256;  // 256-pixel tiles run two blocks per CU
     long long best = -1;
     const int max_ks = stages / 4 > 1 ? (stages / 4 < 32 ? stages / 4 : 32) : 1;
     for (int c = 1; c <= max_ks; ++c) {
@@ -339,7 +346,7 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
   int ks = 1;
   {
-    const long long slots = pt->nw == 4 ? 512 : 256;
+    const long long slots = pt->nw == 4 ? slots4() : 256;
     long long best = -1;
     for (int c = 1; c <= ncb && c <= 32; ++c) {
       const int per = (ncb + c - 1) / c;

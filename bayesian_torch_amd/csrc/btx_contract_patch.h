@@ -89,6 +89,30 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.wt_bytes, 0x00020000);
 
+  // ---- weight loader role: the stage's tile is 4 rows of mu (+ 4 rows of delta, Flipout) of 1 KiB.  8 waves: wave w
+  //      fetches mu row w (w < 4) or delta row w-4;  4 waves: wave w fetches mu row w and delta row w.
+  const bool w_mu = (NW == 4) || (wave < 4);
+  const bool w_dl = (KIND == 1) && ((NW == 4) || (wave >= 4));
+  const int w_nops = (w_mu ? 1 : 0) + (w_dl ? 1 : 0);
+  const uint32_t w_base = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u + (uint32_t)lane * 16u +
+                          (uint32_t)(wave & 3) * 1024u;
+  const int w_lds = PT_W_OFF + (wave & 3) * 1024;
+
+  // Stage s <-> (channel block cb_begin + s / T, tap s % T); first k of the stage = tap*Cg + cb*BK.  Both walks over
+  // the stages (the weight fetch, three stages ahead, and the fragment loads) keep their position incrementally.
+  int wi_s = 0, wi_t = 0, wi_cbk = cb_begin * BK, wi_k0 = cb_begin * BK;  // next stage to fetch
+  auto issue_w_next = [&]() __attribute__((always_inline)) {
+    const uint32_t go = w_base + (uint32_t)(wi_k0 / G) * 1024u;
+    unsigned char* ld = smem + w_lds + (wi_s & (PT_WD - 1)) * DW_STAGE;
+    if (w_mu) dma16(wt_rsrc, go, ld);
+    if (w_dl) dma16(wt_rsrc, go + p.wt_delta_off, ld + 4096);
+    ++wi_s;
+    wi_k0 += p.Cg;
+    if (++wi_t == T) { wi_t = 0; wi_cbk += BK; wi_k0 = wi_cbk; }
+  };
+  // the first weight tiles need nothing but the tile indices: fetch them before the pixel geometry is worked out
+  for (int s_ = 0; s_ < PT_WD - 1 && s_ < nstages; ++s_) issue_w_next();
+
   // ---- patch loader role: DMA instruction i (i = wave + 8*j, j < pt_NI) moves patch pixels 16i + (lane>>2),
   //      granule slot lane&3 (source-side swizzle as in the DMA variant).  Byte offset of channel block 0, or OOB.
   const int g_lane = (lane & 3) ^ ((lane >> 4) & 3);
@@ -108,6 +132,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
              (uint32_t)esz;
     }
     pp_boff[j] = bo;
+    if (nstages > 0 && j < p.pt_NI && 16 * (wave + NW * j) < p.pt_PP)  // patch of the first channel block: go
+      dma16(x_rsrc, bo == DMA_OOB ? DMA_OOB : bo + (uint32_t)(cb_begin * BK * esz),
+            smem + PT_A_OFF + (wave + NW * j) * 1024);
   }
   // ---- sign role: thread t hashes the words of patch pixels t and t+512 (element offset of channel block 0)
   uint32_t sg_off[2];
@@ -136,27 +163,6 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     const bool ok = (gi < p.pt_G) && (img0 + gi < p.NB) && (row0 + r < p.Ho);
     q0[mi] = ok ? (gi * p.pt_Rp + r) * p.pt_Wp + c : 0;
   }
-  // ---- weight loader role: the stage's tile is 4 rows of mu (+ 4 rows of delta, Flipout) of 1 KiB.  8 waves: wave w
-  //      fetches mu row w (w < 4) or delta row w-4;  4 waves: wave w fetches mu row w and delta row w.
-  const bool w_mu = (NW == 4) || (wave < 4);
-  const bool w_dl = (KIND == 1) && ((NW == 4) || (wave >= 4));
-  const int w_nops = (w_mu ? 1 : 0) + (w_dl ? 1 : 0);
-  const uint32_t w_base = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u + (uint32_t)lane * 16u +
-                          (uint32_t)(wave & 3) * 1024u;
-  const int w_lds = PT_W_OFF + (wave & 3) * 1024;
-
-  // Stage s <-> (channel block cb_begin + s / T, tap s % T); first k of the stage = tap*Cg + cb*BK.  Both walks over
-  // the stages (the weight fetch, three stages ahead, and the fragment loads) keep their position incrementally.
-  int wi_s = 0, wi_t = 0, wi_cbk = cb_begin * BK, wi_k0 = cb_begin * BK;  // next stage to fetch
-  auto issue_w_next = [&]() __attribute__((always_inline)) {
-    const uint32_t go = w_base + (uint32_t)(wi_k0 / G) * 1024u;
-    unsigned char* ld = smem + w_lds + (wi_s & (PT_WD - 1)) * DW_STAGE;
-    if (w_mu) dma16(wt_rsrc, go, ld);
-    if (w_dl) dma16(wt_rsrc, go + p.wt_delta_off, ld + 4096);
-    ++wi_s;
-    wi_k0 += p.Cg;
-    if (++wi_t == T) { wi_t = 0; wi_cbk += BK; wi_k0 = wi_cbk; }
-  };
   // one 1-KiB piece (16 patch pixels x 64 B) of the patch of channel block `cbi` (index relative to cb_begin)
   auto issue_patch_piece = [&](int cbi, int j) __attribute__((always_inline)) {
     const uint32_t cboff = (uint32_t)((cb_begin + cbi) * BK * esz);
@@ -315,10 +321,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
   // it needs; those counts are wave-uniform scalars.
   const int ppst = (p.pt_NI + (T > 3 ? T - 4 : 0)) / (T > 3 ? T - 3 : 1);  // pieces per stage: done 3 stages early
   if (nstages > 0) {
-    for (int j = 0; j < p.pt_NI; ++j)
-      if (16 * (wave + NW * j) < p.pt_PP) issue_patch_piece(0, j);
     write_signs(0);
-    for (int s = 0; s < PT_WD - 1 && s < nstages; ++s) issue_w_next();
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int nissued = 0, m1 = 0, mpiece = 0;  // marks: nissued right after W(s+2) / after the last patch piece
     int cbi = 0, t = 0;                                           // position of the stage being multiplied

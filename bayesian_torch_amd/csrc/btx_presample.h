@@ -21,11 +21,15 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
                                                int ntiles, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
                                                uint32_t sample, uint32_t layer) {
   constexpr int G = (PREC == 1) ? 8 : 4;
-  const uint32_t kq = (uint32_t)K >> 2;
-  const uint32_t quad = t % kq, np = t / kq;
-  const int ch = np & 63, tile = np >> 6;
-  const int group = tile / ntiles, ntile = tile - group * ntiles;
-  const int col = ntile * BN + ch;
+  // t enumerates the OUTPUT image linearly — (tile, k-granule, channel, quad of the granule), quad fastest — so a wave
+  // writes 512 (bf16) / 1024 (f32) contiguous bytes; its reads are 32-byte (bf16) / 16-byte runs, one per channel
+  constexpr uint32_t QPG = G / 4;  // quads per granule
+  const uint32_t qh = t % QPG, ch = (t / QPG) & 63u, rest = t / (QPG * 64u);
+  const uint32_t KG = (uint32_t)K / G;
+  const uint32_t tile = rest / KG, kg0 = rest - tile * KG;
+  const uint32_t quad = kg0 * QPG + qh;
+  const int group = (int)tile / ntiles, ntile = (int)tile - group * ntiles;
+  const int col = ntile * BN + (int)ch;
   float wm[4] = {0.f, 0.f, 0.f, 0.f}, wd[4] = {0.f, 0.f, 0.f, 0.f};
   if (col < Ng) {
     const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;

@@ -119,6 +119,40 @@ def one(prec, iters, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def gtime(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64, reps=20):
+    """GPU time of one layer call (all its kernels) with the host out of the picture: `reps` calls captured in a
+    hipGraph, replayed and timed with events"""
+    from bayesian_torch_amd import layers as L
+    dev = torch.device("cuda:0")
+    act = torch.bfloat16 if prec == "bf16" else torch.float32
+    torch.manual_seed(0)
+    layer = getattr(L, "Conv2d" + typ)(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(dev)
+    layer.precision = prec
+    x = torch.randn(bs, cin, hw, hw, device=dev).to(act).contiguous(memory_format=torch.channels_last)
+    side = torch.cuda.Stream(dev)
+    with torch.no_grad():
+        with torch.cuda.stream(side):
+            for i in range(3):
+                layer._forward_hip(x, sample_idx=i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(reps):
+                y = layer._forward_hip(x, sample_idx=i)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / (3 * reps) * 1e3
+    ho = y.shape[2]
+    fl = 2.0 * bs * ho * ho * cout * cin * k * k * (2 if typ == "Flipout" else 1)
+    return us, fl / (us * 1e-6) / 1e12
+
+
 def trace(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64):
     """per-wave phase timings of the patch kernel (needs a libbtx built with -DBTX_PT_TRACE, see BTX_LIB)"""
     import os
@@ -163,15 +197,20 @@ if __name__ == "__main__":
     ap.add_argument("--prec", default="bf16,f32")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shape", default="64,64,56,1,3")
+    ap.add_argument("--bs", type=int, default=64)
     a = ap.parse_args()
     if "one" in a.what or "timeone" in a.what:
         c = [int(v) for v in a.shape.split(",")]
         us = one(a.prec.split(",")[0], a.iters, *c)
         if "timeone" in a.what:
             print("shape %s: %.1f us / launch" % (a.shape, us))
+    if "gtime" in a.what:
+        c = [int(v) for v in a.shape.split(",")]
+        us, tf = gtime(a.prec.split(",")[0], *c, bs=a.bs)
+        print("shape %s bs %d: %.1f us / call  %.1f TFLOP/s" % (a.shape, a.bs, us, tf))
     if "trace" in a.what:
         c = [int(v) for v in a.shape.split(",")]
-        trace(a.prec.split(",")[0], *c)
+        trace(a.prec.split(",")[0], *c, bs=a.bs)
     if "parity" in a.what:
         parity()
     if "perf" in a.what:
