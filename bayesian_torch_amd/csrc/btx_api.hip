@@ -162,6 +162,51 @@ static void sign_keys(const BtxRng* rng, uint32_t stream, uint32_t* ka, uint32_t
   *kb = k.x[1];
 }
 
+
+// ========================================================================================================
+// btx_rowfuse_pack: the data-format step in front of the small-C stem path (BTX_FLAG_ROWFUSE) — logical [N,C,H,W]
+// activations in any strides/dtype -> zero-padded channels-last [N][Hp][Wp][cp] in the MFMA dtype, one pass
+// (replaces a fill + a strided copy + a cast).  One thread per output pixel.
+// ========================================================================================================
+template <typename IN, typename OUT, int CP>
+__global__ __launch_bounds__(256) void rowfuse_pack_kernel(const IN* __restrict__ x, OUT* __restrict__ out, int NB, int C,
+                                                           int H, int W, int Hp, int Wp, int ph, int pw, long long sn,
+                                                           long long sc, long long sh, long long sw, long long total) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int wp = (int)(t % Wp);
+    const long long r = t / Wp;
+    const int hp = (int)(r % Hp);
+    const int n = (int)(r / Hp);
+    const int h = hp - ph, w = wp - pw;
+    struct alignas(sizeof(OUT) * CP) Px { OUT v[CP]; };
+    Px px;
+    OUT* v = px.v;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) v[c] = (OUT)0.f;
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+      const IN* src = x + n * sn + h * sh + w * sw;
+#pragma unroll
+      for (int c = 0; c < CP; ++c)
+        if (c < C) v[c] = (OUT)(float)src[c * sc];
+    }
+    *(Px*)(out + t * CP) = px;  // one 8/16/32-byte store per pixel
+  }
+}
+template <typename IN, typename OUT>
+static int launch_rowfuse_pack(const void* x, void* out, int NB, int C, int H, int W, int Hp, int Wp, int cp, int ph,
+                               int pw, const int64_t* st, hipStream_t stream) {
+  const long long total = (long long)NB * Hp * Wp;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (cp == 4)
+    hipLaunchKernelGGL((rowfuse_pack_kernel<IN, OUT, 4>), dim3((int)blocks), dim3(256), 0, stream, (const IN*)x, (OUT*)out,
+                       NB, C, H, W, Hp, Wp, ph, pw, (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[3], total);
+  else
+    hipLaunchKernelGGL((rowfuse_pack_kernel<IN, OUT, 8>), dim3((int)blocks), dim3(256), 0, stream, (const IN*)x, (OUT*)out,
+                       NB, C, H, W, Hp, Wp, ph, pw, (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[3], total);
+  return (int)hipGetLastError();
+}
+
 extern "C" {
 
 int btx_abi_version(void) { return BTX_ABI_VERSION; }
@@ -365,6 +410,44 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   return true;
 }
 
+// Tile plan of the stem variant (btx_contract_stem.h): row-fused small-C 2-D convolutions; R output rows x full width
+// per workgroup, the input rows they need resident in LDS.
+struct StemPlan {
+  int R, Rp, rtiles, nw, astage, sbytes, lds, patch_bytes, nwg;
+};
+static bool make_stem_plan(const BtxGeom* g, int act_dtype, int prec, const Plan& pl, StemPlan* st) {
+  if (g->D != 1 || g->KD != 1 || pl.Do != 1 || g->groups != 1) return false;
+  const int esz = (act_dtype == BTX_ACT_BF16) ? 2 : 4;
+  const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
+  if ((g->KW * g->C) % bk || pl.K % bk) return false;
+  const long long rowB = (long long)g->W * g->C * esz;
+  for (int nw = 4; nw <= 8; nw += 4) {
+    const int tp = 64 * nw;
+    if (pl.Wo > tp) continue;
+    int R = tp / pl.Wo;
+    if (R > pl.Ho) R = pl.Ho;
+    const long long cap = (nw == 4 ? 81920 : 163840) - PT_WD * 8192;
+    for (; R >= 1; --R) {
+      const long long Rp = (long long)(R - 1) * g->sh + g->KH;
+      const long long pb = Rp * rowB;
+      const long long astage = (pb + 1023) / 1024 * 1024;
+      const long long sbytes = ((pb / esz + 31) / 32 + 3) * 4;
+      const long long sb16 = (sbytes + 15) / 16 * 16;
+      if (astage + sb16 > cap) continue;
+      long long lds = astage + sb16 + PT_WD * 8192;
+      const long long ep = (long long)nw * PT_EP_WAVE + 1024;
+      if (lds < ep) lds = ep;
+      st->R = R; st->Rp = (int)Rp; st->rtiles = (pl.Ho + R - 1) / R; st->nw = nw; st->astage = (int)astage;
+      st->sbytes = (int)sb16; st->lds = (int)lds; st->patch_bytes = (int)pb;
+      const long long nwg = (long long)g->NB * st->rtiles * pl.ntiles;
+      if (nwg > 0x7fffffffLL) return false;
+      st->nwg = (int)nwg;
+      return true;
+    }
+  }
+  return false;
+}
+
 // workspace of the patch variant: split-K partials (256-byte padded), then the pre-sampled weight tiles
 static size_t patch_wt_bytes(const Plan& pl, const BtxGeom* g, int kind, int prec, size_t* one) {
   const size_t arr = (size_t)g->groups * pl.ntiles * 64 * (size_t)pl.K * (prec == BTX_PREC_BF16 ? 2 : 4);
@@ -446,6 +529,18 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   if (dma) {
     rc = make_plan(g, prec, flags, 64 * dma_nw, &pl);
     if (rc) return rc;
+  }
+  // stem variant: row-fused small-C convolutions with the input rows of the tile resident in LDS (BTX_NO_STEM=1 disables)
+  static const bool no_stem = getenv("BTX_NO_STEM") != nullptr;
+  StemPlan stp;
+  bool stem = false;
+  if (dma && rowfuse && !no_stem) {
+    Plan sp;
+    if (!make_plan(g, prec, flags, DBM, &sp) && make_stem_plan(g, act_dtype, prec, sp, &stp)) {
+      sp.ksplits = 1; sp.kper = sp.K; sp.nwg = stp.nwg;
+      pl = sp;
+      stem = true;
+    }
   }
   // patch variant: stride-1 2-D convolutions keep the halo'd input patch of the tile in LDS (BTX_NO_PATCH=1 disables)
   static const bool no_patch = getenv("BTX_NO_PATCH") != nullptr;
@@ -533,7 +628,13 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   static const char* dbg_env = getenv("BTX_DBG");
   p.dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
   hipStream_t st = (hipStream_t)stream;
-  if (patch) {
+  if (stem) {
+    p.pt_R = stp.R; p.pt_Rp = stp.Rp; p.pt_rtiles = stp.rtiles; p.pt_nw = stp.nw; p.pt_astage = stp.astage;
+    p.st_sbytes = stp.sbytes; p.pt_lds = stp.lds; p.pt_PP = stp.patch_bytes;
+    p.fd_rtiles = make_fastdiv((uint32_t)stp.rtiles);
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_stem_bf16(kind, p, pl.nwg, st)
+                                 : launch_contract_stem_f32(kind, p, pl.nwg, st);
+  } else if (patch) {
     p.pt_G = pt.G; p.pt_R = pt.R; p.pt_Rp = pt.Rp; p.pt_Wp = pt.Wp; p.pt_PP = pt.PP; p.pt_NI = pt.NI;
     p.fd_ptWp = make_fastdiv((uint32_t)pt.Wp); p.fd_ptRp = make_fastdiv((uint32_t)pt.Rp); p.fd_ptR = make_fastdiv((uint32_t)pt.R);
     p.fd_rtiles = make_fastdiv((uint32_t)pt.rtiles);
@@ -638,6 +739,20 @@ int btx_fill_sign(int8_t* out, size_t n, const BtxRng* rng, uint32_t rng_stream,
 size_t btx_mc_packed_floats(int bs, int C) {
   if (bs <= 0 || C <= 0) return 0;
   return (size_t)2 * bs * C + (size_t)bs + 2;
+}
+
+int btx_rowfuse_pack(const void* x, int in_dtype, const int64_t* strides_ncHW, int NB, int C, int H, int W, void* out,
+                     int out_dtype, int Hp, int Wp, int cp, int ph, int pw, void* stream) {
+  if (!x || !out || !strides_ncHW) return BTX_E_NULL;
+  if (NB <= 0 || C <= 0 || H <= 0 || W <= 0 || ph < 0 || pw < 0 || Hp < H + ph || Wp < W + pw) return BTX_E_SHAPE;
+  if ((cp != 4 && cp != 8) || C > cp) return BTX_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const bool ib = in_dtype == BTX_ACT_BF16, ob = out_dtype == BTX_ACT_BF16;
+  if ((!ib && in_dtype != BTX_ACT_F32) || (!ob && out_dtype != BTX_ACT_F32)) return BTX_E_DTYPE;
+  if (ib && ob) return launch_rowfuse_pack<__bf16, __bf16>(x, out, NB, C, H, W, Hp, Wp, cp, ph, pw, strides_ncHW, st);
+  if (ib && !ob) return launch_rowfuse_pack<__bf16, float>(x, out, NB, C, H, W, Hp, Wp, cp, ph, pw, strides_ncHW, st);
+  if (!ib && ob) return launch_rowfuse_pack<float, __bf16>(x, out, NB, C, H, W, Hp, Wp, cp, ph, pw, strides_ncHW, st);
+  return launch_rowfuse_pack<float, float>(x, out, NB, C, H, W, Hp, Wp, cp, ph, pw, strides_ncHW, st);
 }
 
 int btx_mc_accumulate(const void* logits, int bs, int C, int act_dtype, float kl, float* packed, void* stream) {

@@ -121,7 +121,8 @@ struct ContractParams {
   FastDiv fd_Wo, fd_Ho, fd_Do, fd_ptWp, fd_ptRp, fd_ptR;
   FastDiv fd_inner, fd_ksplits, fd_ntiles, fd_Cg, fd_KW, fd_KH, fd_rtiles;  // wave-uniform index splits
   void* trace;  // BTX_PT_TRACE builds: per-wave phase timings (measurement only)
-  int pt_nw, pt_astage, pt_lds;  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
+  int pt_nw, pt_astage, pt_lds;
+  int st_sbytes;  // stem variant: bytes of the s_in word array in LDS  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off
   uint32_t wt_bytes, wt_delta_off;
   int wt_ready;  // wt was filled by btx_sample_weights: skip the per-launch sampling pre-pass
@@ -723,6 +724,8 @@ int launch_contract_bf16(int kind, int act_bf16, bool gen, const ContractParams&
 int launch_contract_dma_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_dma_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_patch_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_stem_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_stem_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
 struct PresampleBatch;
 int launch_presample_batch_f32(const PresampleBatch& b, hipStream_t st);
 int launch_presample_batch_bf16(const PresampleBatch& b, hipStream_t st);

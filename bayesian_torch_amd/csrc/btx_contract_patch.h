@@ -24,6 +24,7 @@
 #include "btx_contract_dma.h"
 #include "btx_epilogue.h"
 #include "btx_presample.h"
+#include "btx_mma.h"
 
 namespace btx {
 
@@ -33,9 +34,6 @@ namespace btx {
 // epilogue and barrier waits then overlap the other's MFMAs.  Blocks of 8 waves (512-pixel tiles, one per CU) take the
 // shapes whose patch does not fit.
 
-#ifndef BTX_PT_ABL
-#define BTX_PT_ABL 0  // measurement-only ablation bits: 1 no MFMA, 2 no LDS fragment reads, 4 no DMA in the loop,
-#endif                // 8 no per-stage barrier, 16 no sign masks, 32 no epilogue
 
 // ContractParams fields used in addition: pt_G, pt_R, pt_Rp, pt_Wp, pt_PP, pt_NI, pt_rtiles, wt (pre-sampled weight
 // tiles), wt_bytes, wt_delta_off; kper = channel blocks per split * BK.
@@ -199,10 +197,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
   // words).  They are double-buffered: the reads of stage s+1 are issued BEFORE the MFMAs of stage s, so that after the
   // per-stage barrier the LDS pipe and the matrix pipe work at the same time instead of one after the other.  The
   // delta weights of a stage are read at the start of its own multiply (the 8 mean MFMAs cover their latency).
-  struct Frag {
-    u32x4 a[NG / 2][2], wm[NG / 2][2];
-    uint32_t sw[2];
-  };
+  using Frag = StageFrag;
   auto load_frag = [&](Frag& f, int cbi, int toff, int wslot) __attribute__((always_inline)) {
     const unsigned char* as = smem + PT_A_OFF + (cbi & 1) * a_stage;
     const unsigned char* ss = smem + PT_S_OFF + (cbi & 1) * s_stage;
@@ -235,79 +230,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     }
   };
   auto compute = [&](Frag& f, int wslot) __attribute__((always_inline)) {
-    const unsigned char* ws = smem + PT_W_OFF + wslot * DW_STAGE;
-    u32x4 wd[NG / 2][2];
-    if constexpr (KIND == 1) {
-      if constexpr (BTX_PT_ABL & 2) {
-#pragma unroll
-        for (int kk = 0; kk < NG / 2; ++kk) wd[kk][0] = wd[kk][1] = (u32x4){(uint32_t)wslot, 7u, 1u, 4u};
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < NG / 2; ++kk)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            wd[kk][ni] = *(const u32x4*)(ws + NG * BN * 16 + ((2 * kk + h) * BN + ni * 32 + l31) * 16);
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < NG / 2; ++kk) {
-      if constexpr (PREC == 1) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(f.wm[kk][ni]), "v"(f.a[kk][mi])); accm[mi][ni][0] += 1.f; }
-            else accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, f.wm[kk][ni]), __builtin_bit_cast(bf16x8, f.a[kk][mi]), accm[mi][ni], 0, 0, 0);
-          }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(f.wm[kk][ni][e]), u2f(f.a[kk][mi][e]), accm[mi][ni], 0, 0, 0);
-      }
-    }
-    if constexpr (KIND == 1) {
-#pragma unroll
-      for (int kk = 0; kk < NG / 2; ++kk) {
-        const int row = 2 * kk + h;
-        if constexpr (PREC == 1) {
-          if constexpr (!(BTX_PT_ABL & 16)) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-              const uint32_t swr = f.sw[mi] << (4 * row);
-#pragma unroll
-              for (int d = 0; d < 4; ++d) f.a[kk][mi][d] ^= ((swr << d) & 0x80008000u);
-            }
-          }
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(wd[kk][ni]), "v"(f.a[kk][mi])); accd[mi][ni][0] += 1.f; }
-              else accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                  __builtin_bit_cast(bf16x8, wd[kk][ni]), __builtin_bit_cast(bf16x8, f.a[kk][mi]), accd[mi][ni], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            const uint32_t swr = f.sw[mi] << (2 * row);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) f.a[kk][mi][e] ^= ((swr << ((e >> 1) + ((e & 1) ? 0 : 16))) & 0x80000000u);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
-                accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wd[kk][ni][e]), u2f(f.a[kk][mi][e]), accd[mi][ni], 0, 0, 0);
-        }
-      }
-    }
+    stage_mma<PREC, KIND>(f, smem + PT_W_OFF + wslot * DW_STAGE, accm, accd, l31, h);
   };
 
   // =================== main loop ==========================================================================

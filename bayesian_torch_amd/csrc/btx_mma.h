@@ -1,0 +1,97 @@
+// btx_mma.h — one K-stage of the sample-and-contract MFMA block, shared by the patch and the stem kernels (gfx950).
+#pragma once
+#include "btx_contract.h"
+
+#ifndef BTX_PT_ABL
+#define BTX_PT_ABL 0  // measurement-only ablation bits: 1 no MFMA, 2 no LDS fragment reads, 4 no DMA in the loop,
+#endif                // 8 no per-stage barrier, 16 no sign masks, 32 no epilogue
+
+namespace btx {
+
+// Fragments of one K-stage held in registers: activations a[kk][mi], mean weights wm[kk][ni], the sign word of each of
+// the lane's two pixels (32 bf16 / 16 f32 elements of the stage, bit of element e at ((e&1) ? 31 : 15) - (e>>1)).
+struct StageFrag {
+  u32x4 a[NG / 2][2], wm[NG / 2][2];
+  uint32_t sw[2];
+};
+
+// mean MFMAs from the fragment registers; the delta weights are read from the LDS tile `ws` (mu at +0, delta at
+// +NG*BN*16) while those run; then the activations get their s_in signs (XOR mask) and the delta MFMAs follow.
+template <int PREC, int KIND>
+__device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws, f32x16 (&accm)[2][2],
+                                          f32x16 (&accd)[2][2], int l31, int h) {
+    u32x4 wd[NG / 2][2];
+    if constexpr (KIND == 1) {
+      if constexpr (BTX_PT_ABL & 2) {
+#pragma unroll
+        for (int kk = 0; kk < NG / 2; ++kk) wd[kk][0] = wd[kk][1] = (u32x4){7u, 7u, 1u, 4u};
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < NG / 2; ++kk)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            wd[kk][ni] = *(const u32x4*)(ws + NG * BN * 16 + ((2 * kk + h) * BN + ni * 32 + l31) * 16);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < NG / 2; ++kk) {
+      if constexpr (PREC == 1) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(f.wm[kk][ni]), "v"(f.a[kk][mi])); accm[mi][ni][0] += 1.f; }
+            else accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, f.wm[kk][ni]), __builtin_bit_cast(bf16x8, f.a[kk][mi]), accm[mi][ni], 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(f.wm[kk][ni][e]), u2f(f.a[kk][mi][e]), accm[mi][ni], 0, 0, 0);
+      }
+    }
+    if constexpr (KIND == 1) {
+#pragma unroll
+      for (int kk = 0; kk < NG / 2; ++kk) {
+        const int row = 2 * kk + h;
+        if constexpr (PREC == 1) {
+          if constexpr (!(BTX_PT_ABL & 16)) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+              const uint32_t swr = f.sw[mi] << (4 * row);
+#pragma unroll
+              for (int d = 0; d < 4; ++d) f.a[kk][mi][d] ^= ((swr << d) & 0x80008000u);
+            }
+          }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(wd[kk][ni]), "v"(f.a[kk][mi])); accd[mi][ni][0] += 1.f; }
+              else accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, wd[kk][ni]), __builtin_bit_cast(bf16x8, f.a[kk][mi]), accd[mi][ni], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const uint32_t swr = f.sw[mi] << (2 * row);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f.a[kk][mi][e] ^= ((swr << ((e >> 1) + ((e & 1) ? 0 : 16))) & 0x80000000u);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wd[kk][ni][e]), u2f(f.a[kk][mi][e]), accd[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+}  // namespace btx

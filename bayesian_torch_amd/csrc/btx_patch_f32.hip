@@ -1,8 +1,12 @@
 // Instantiates the f32 "patch" variant (stride-1 2-D convolutions, halo'd input patch resident in LDS).
 #include "btx_contract_patch.h"
+#include "btx_contract_stem.h"
 namespace btx {
 int launch_contract_patch_f32(int kind, const ContractParams& p, int nwg, hipStream_t st) {
   return launch_contract_patch_impl<0>(kind, p, nwg, st);
+}
+int launch_contract_stem_f32(int kind, const ContractParams& p, int nwg, hipStream_t st) {
+  return launch_contract_stem_impl<0>(kind, p, nwg, st);
 }
 int launch_presample_batch_f32(const PresampleBatch& b, hipStream_t st) {
   hipLaunchKernelGGL((presample_batch_kernel<0>), dim3(b.total_blocks), dim3(256), 0, st, b);

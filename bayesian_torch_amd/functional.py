@@ -370,9 +370,22 @@ def rowfuse_plan(op, x_shape):
     return dict(op=fop, Hp=Hp, Wp=Wp, ph=ph, pw=pw, Ho=Ho, Wo=Wo, kw=kw, kwp=kwp, cp=cp, cin=op.in_channels)
 
 
-def rowfuse_input(x, plan):
-    """logical [N,C,H,W] -> zero-padded logical [N,cp,Hp,Wp] stored channels-last"""
+def rowfuse_input(x, plan, out_dtype=None):
+    """logical [N,C,H,W] -> zero-padded logical [N,cp,Hp,Wp] stored channels-last (in `out_dtype`).  CUDA tensors:
+    one pass of btx_rowfuse_pack; CPU tensors: F.pad."""
     n, c, h, w = x.shape
+    out_dtype = out_dtype or x.dtype
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and out_dtype in (torch.float32, torch.bfloat16):
+        L = _lib.lib()
+        out = torch.empty((n, plan["cp"], plan["Hp"], plan["Wp"]), dtype=out_dtype, device=x.device,
+                          memory_format=torch.channels_last)
+        st = (ctypes.c_int64 * 4)(*x.stride())
+        code = lambda dt: _lib.ACT_BF16 if dt == torch.bfloat16 else _lib.ACT_F32
+        _lib.check(L.btx_rowfuse_pack(x.data_ptr(), code(x.dtype), st, n, c, h, w, out.data_ptr(), code(out_dtype),
+                                      plan["Hp"], plan["Wp"], plan["cp"], plan["ph"], plan["pw"],
+                                      torch.cuda.current_stream(x.device).cuda_stream))
+        return out
+    x = x.to(out_dtype)
     xp = F.pad(x.permute(0, 2, 3, 1), (0, plan["cp"] - c, plan["pw"], plan["Wp"] - w - plan["pw"], plan["ph"],
                                        plan["Hp"] - h - plan["ph"]))
     return xp.permute(0, 3, 1, 2)

@@ -271,7 +271,7 @@ class _VariationalNd(BaseVariationalLayer_):
             pre = self._take_presampled(sample_idx, prec, ("rowfuse", plan["cp"], plan["kwp"]))
             # the padded copy is made in the MFMA dtype (the rounding a staging kernel would apply anyway); the
             # output keeps the caller's activation dtype
-            xin = BF.rowfuse_input(x, plan).to(torch.bfloat16 if prec == "bf16" else torch.float32)
+            xin = BF.rowfuse_input(x, plan, torch.bfloat16 if prec == "bf16" else torch.float32)
             fo = plan["op"].out_spatial((1, plan["Hp"], plan["Wp"]))
             if epilogue is not None and epilogue.get("residual") is not None and fo[2] != plan["Wo"]:
                 raise _lib.BtxError("residual epilogue is not available for this row-fused stem geometry")

@@ -185,6 +185,15 @@ size_t btx_sampled_w_bytes(const BtxGeom* g, int kind, int prec);
 int btx_sample_weights(const BtxSampleItem* items_host, int n_items, const BtxRng* rng /* layer_id unused */,
                        int prec, void* stream);
 
+/* §8(f): the data format in front of the path.  Small-C stems (BTX_FLAG_ROWFUSE) take channels-last [NB][Hp][Wp][cp]
+ * activations with the conv padding materialised and the channels zero-padded to cp (4 or 8), in the MFMA dtype.
+ * btx_rowfuse_pack writes that tensor in ONE pass from the caller's logical [N,C,H,W] activations of any layout:
+ * strides_ncHW = element strides of (n, c, h, w), host array of 4; element (n,c,h,w) lands at
+ * out[n][h+ph][w+pw][c]; everything else is zero.  (The reference hands F.conv2d the NCHW tensor and a padding
+ * argument: layers/flipout_layers/conv_flipout.py:376-383.) */
+int btx_rowfuse_pack(const void* x, int in_dtype, const int64_t* strides_ncHW_host, int NB, int C, int H, int W,
+                     void* out, int out_dtype, int Hp, int Wp, int cp, int ph, int pw, void* stream);
+
 /* Output spatial extent for a geometry (same arithmetic as torch's conv / conv_transpose). */
 int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, int32_t* Wo);
 
