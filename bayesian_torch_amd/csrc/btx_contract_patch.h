@@ -242,7 +242,11 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
   //      other waves at the barrier.
   // vmcnt retires in order, so "landed" = at most as many operations outstanding as this wave has issued after the one
   // it needs; those counts are wave-uniform scalars.
+#ifdef BTX_PT_PIECE_STAGES
+  const int ppst = (p.pt_NI + BTX_PT_PIECE_STAGES - 1) / BTX_PT_PIECE_STAGES;  // measurement: pieces within N stages
+#else
   const int ppst = (p.pt_NI + (T > 3 ? T - 4 : 0)) / (T > 3 ? T - 3 : 1);  // pieces per stage: done 3 stages early
+#endif
   if (nstages > 0) {
     write_signs(0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
 #ifdef BTX_PT_TRACE
       const uint32_t tA = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
-      if (!(BTX_PT_ABL & 4) && wi_s < nstages) { issue_w_next(); nissued += w_nops; m2 = nissued; }
-      if (!(BTX_PT_ABL & 4) && next_cb) {
+      if (!(BTX_PT_ABL & (4 | 128)) && wi_s < nstages) { issue_w_next(); nissued += w_nops; m2 = nissued; }
+      if (!(BTX_PT_ABL & (4 | 256)) && next_cb) {
         for (int j = t * ppst; j < (t + 1) * ppst && j < p.pt_NI; ++j)
           if (16 * (wave + NW * j) < p.pt_PP) { issue_patch_piece(cbi + 1, j); mpiece = ++nissued; }
         if (t == 0) write_signs(cbi + 1);  // the sign slot of block cbi+1 was last read during block cbi-1
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
 #endif
       int allowed = nissued - m1;
       if (next_cb && t == (T >= 2 ? T - 2 : 0)) allowed = min(allowed, nissued - mpiece);
-      wait_vmcnt(allowed);
+      if constexpr (!(BTX_PT_ABL & 64)) wait_vmcnt(allowed);
 #ifdef BTX_PT_TRACE
       const uint32_t tC = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif

@@ -29,12 +29,13 @@ for step in "$@"; do
     patchab) for sh in 64,64,56,1,3 128,128,28,1,3 256,256,14,1,3 512,512,7,1,3; do for v in "X=0" "BTX_PATCH_NW=8" "BTX_NO_PATCH=1"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py timeone --prec bf16 --iters 30 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/patchab.log 2>&1; echo "patchab rc=$?" ;;
     dmaab) for sh in 3,64,224,2,7 64,128,56,2,3 64,128,56,2,1 128,256,28,2,3 256,512,14,2,3 256,512,14,2,1; do for v in "X=0" "BTX_DMA_NW=8"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py timeone --prec bf16 --iters 30 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/dmaab.log 2>&1; echo "dmaab rc=$?" ;;
     pytest_contract) timeout 900 python -m pytest tests/test_gpu_contract.py -m gpu -q -x > gpurun_out/pytest_contract.log 2>&1; echo "pytest_contract rc=$?"; tail -15 gpurun_out/pytest_contract.log ;;
-    ptrace) for sh in 64,64,56,1,3 3,64,224,2,7 64,128,56,2,1; do echo "== $sh"; BTX_LIB=$PWD/build_variants/libbtx_trace.so timeout 300 python tools/gpu_diag.py trace --prec bf16 --shape $sh 2>&1 | grep -v amdgpu.ids; done > gpurun_out/ptrace.log 2>&1; echo "ptrace rc=$?" ;;
+    ptrace) for sh in 64,64,56,1,3 128,128,28,1,3 256,256,14,1,3 512,512,7,1,3 64,128,56,2,3 64,128,56,2,1; do echo "== $sh"; BTX_LIB=$PWD/build_variants/libbtx_trace.so timeout 300 python tools/gpu_diag.py trace --prec bf16 --shape $sh 2>&1 | grep -v amdgpu.ids; done > gpurun_out/ptrace.log 2>&1; echo "ptrace rc=$?" ;;
     ptrace1) for bs in 16 32 64; do echo "== bs $bs"; BTX_LIB=$PWD/build_variants/libbtx_trace.so timeout 300 python tools/gpu_diag.py trace --prec bf16 --shape 64,64,56,1,3 --bs $bs 2>&1 | grep -v "amdgpu.ids\|wave "; done > gpurun_out/ptrace1.log 2>&1; echo "ptrace1 rc=$?" ;;
     ksab) for sh in 256,256,14,1,3 512,512,7,1,3 128,256,28,2,3 256,512,14,2,3 256,512,14,2,1 128,128,28,1,3; do for v in 256 384 512 768; do echo -n "SLOTS4=$v "; BTX_SLOTS4=$v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/ksab.log 2>&1; echo "ksab rc=$?" ;;
     gtimes) for sh in 3,64,224,2,7 64,64,56,1,3 64,128,56,2,3 64,128,56,2,1 128,128,28,1,3 128,256,28,2,3 128,256,28,2,1 256,256,14,1,3 256,512,14,2,3 256,512,14,2,1 512,512,7,1,3; do timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep -E "shape|rror"; done > gpurun_out/gtimes.log 2>&1; echo "gtimes rc=$?" ;;
     stemab) for v in "X=0" "BTX_NO_STEM=1"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape 3,64,224,2,7 2>&1 | grep -E "shape|rror"; done > gpurun_out/stemab.log 2>&1; echo "stemab rc=$?" ;;
     kprof_stem) R="$PWD"; cd /tmp; timeout 300 rocprofv3 --kernel-trace -d "$R/gpurun_out/kprof" -o kp -- python "$R/tools/gpu_diag.py" one --prec bf16 --iters 10 --shape 3,64,224,2,7 > /dev/null 2>&1; cd "$R"; echo "kprof rc=$?" ;;
+    gvariants) for f in build_variants/libbtx_*.so; do for sh in 64,64,56,1,3 256,256,14,1,3; do echo -n "$(basename $f) "; BTX_LIB=$PWD/$f timeout 300 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep shape; done; done > gpurun_out/gvariants.log 2>&1; echo "gvariants rc=$?" ;;
     kstats) R="$PWD"; cd /tmp; for v in main a31 a63 a1 a4; do lib="$R/build_variants/libbtx_$v.so"; [ $v = main ] && lib="$R/bayesian_torch_amd/libbtx.so"; BTX_LIB=$lib timeout 300 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/ks_$v" -o ks -- python "$R/tools/gpu_diag.py" one --prec bf16 --iters 10 > /dev/null 2>&1; echo "== $v"; find "$R/gpurun_out/ks_$v" -name "*kernel_stats.csv" | head -1 | xargs cat | grep -E "patch|presample|Name" | cut -c1-200; done > "$R/gpurun_out/kstats.log" 2>&1; cd "$R"; echo "kstats rc=$?" ;;
     prof)   cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$OLDPWD" ;;
   esac
