@@ -33,6 +33,9 @@ __device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws,
             wd[kk][ni] = *(const u32x4*)(ws + NG * BN * 16 + ((2 * kk + h) * BN + ni * 32 + l31) * 16);
       }
     }
+#ifdef BTX_MMA_PRIO
+    __builtin_amdgcn_s_setprio(BTX_MMA_PRIO);
+#endif
 #pragma unroll
     for (int kk = 0; kk < NG / 2; ++kk) {
       if constexpr (PREC == 1) {
@@ -92,6 +95,9 @@ __device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws,
         }
       }
     }
-  }
+#ifdef BTX_MMA_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
 
 }  // namespace btx

@@ -266,9 +266,11 @@ class _VariationalNd(BaseVariationalLayer_):
         self._btx_last_xshape = tuple(x.shape)
         plan = self._rowfuse_plan(x) if noise is None else None
         if plan is not None:  # small-C stem: one kernel row per K-stage on the LDS-DMA kernel
-            mu_f, rho_f = BF.rowfuse_weights(mu_p, rho_p, plan)
             prec = self.precision or BF.get_precision()
             pre = self._take_presampled(sample_idx, prec, ("rowfuse", plan["cp"], plan["kwp"]))
+            # with pre-sampled tiles the launch never reads mu/rho (the row-fused path has no in-register sampler to
+            # fall back to), so the padded copies are only made when the launch samples for itself
+            mu_f, rho_f = BF.rowfuse_weights(mu_p, rho_p, plan) if pre is None else (mu_p, rho_p)
             # the padded copy is made in the MFMA dtype (the rounding a staging kernel would apply anyway); the
             # output keeps the caller's activation dtype
             xin = BF.rowfuse_input(x, plan, torch.bfloat16 if prec == "bf16" else torch.float32)

@@ -26,7 +26,7 @@ for step in "$@"; do
             done; cd "$R" ;;
     ablate) for d in 0 1 2 4 8 16 17 18 19 27 31; do echo "== BTX_DBG=$d"; BTX_DBG=$d timeout 300 python tools/gpu_diag.py timeone --prec bf16 --iters 20; done > gpurun_out/ablate.log 2>&1; echo "ablate rc=$?" ;;
     variants) for f in build_variants/libbtx_*.so; do for sh in 64,64,56,1,3 256,256,14,1,3; do echo -n "$(basename $f) "; BTX_LIB=$PWD/$f timeout 300 python tools/gpu_diag.py timeone --prec bf16 --iters 30 --shape $sh 2>&1 | grep shape; done; done > gpurun_out/variants.log 2>&1; echo "variants rc=$?" ;;
-    patchab) for sh in 64,64,56,1,3 128,128,28,1,3 256,256,14,1,3 512,512,7,1,3; do for v in "X=0" "BTX_PATCH_NW=8" "BTX_NO_PATCH=1"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py timeone --prec bf16 --iters 30 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/patchab.log 2>&1; echo "patchab rc=$?" ;;
+    patchab) for sh in 64,64,56,1,3 128,128,28,1,3 256,256,14,1,3 512,512,7,1,3; do for v in "X=0" "BTX_PATCH_NW=8" "BTX_NO_PATCH=1"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/patchab.log 2>&1; echo "patchab rc=$?" ;;
     dmaab) for sh in 3,64,224,2,7 64,128,56,2,3 64,128,56,2,1 128,256,28,2,3 256,512,14,2,3 256,512,14,2,1; do for v in "X=0" "BTX_DMA_NW=8"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py timeone --prec bf16 --iters 30 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/dmaab.log 2>&1; echo "dmaab rc=$?" ;;
     pytest_contract) timeout 900 python -m pytest tests/test_gpu_contract.py -m gpu -q -x > gpurun_out/pytest_contract.log 2>&1; echo "pytest_contract rc=$?"; tail -15 gpurun_out/pytest_contract.log ;;
     ptrace) for sh in 64,64,56,1,3 128,128,28,1,3 256,256,14,1,3 512,512,7,1,3 64,128,56,2,3 64,128,56,2,1; do echo "== $sh"; BTX_LIB=$PWD/build_variants/libbtx_trace.so timeout 300 python tools/gpu_diag.py trace --prec bf16 --shape $sh 2>&1 | grep -v amdgpu.ids; done > gpurun_out/ptrace.log 2>&1; echo "ptrace rc=$?" ;;
