@@ -332,7 +332,7 @@ static bool dma_shape_ok(const BtxGeom* g, int act_dtype, int prec, const Plan& 
 // Tile plan of the patch variant (btx_contract_patch.h): stride-1 2-D convolutions with more than one tap whose
 // activations already have the contraction dtype.  Returns false when the shape is not eligible.
 struct PatchPlan {
-  int G, R, Rp, Wp, PP, NI, rtiles, nw, astage, lds;
+  int G, R, Rp, Wp, PP, NI, rtiles, nw, mi, astage, lds;
 };
 // tile of `tp` output pixels whose patch holds at most `ppcap` pixels
 static bool patch_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, PatchPlan* pt) {
@@ -372,17 +372,22 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   // 8-wave blocks, one per CU: 60 pieces = 960 pixels.  BTX_PATCH_NW=8 forces the latter (A/B measurements).
   static const char* nw_env = getenv("BTX_PATCH_NW");
   const bool force8 = nw_env && atoi(nw_env) == 8;
-  if (!force8 && patch_tile(g, *pl, 256, 352, pt)) pt->nw = 4;
+  // BTX_PATCH_MI=4: 4 waves x 128 pixels, one block per CU, 256 accumulators per wave (A/B measurements)
+  static const char* mi_env = getenv("BTX_PATCH_MI");
+  const bool want_mi4 = mi_env && atoi(mi_env) == 4;
+  pt->mi = 2;
+  if (want_mi4 && patch_tile(g, *pl, 512, 960, pt)) { pt->nw = 4; pt->mi = 4; }
+  else if (!force8 && patch_tile(g, *pl, 256, 352, pt)) pt->nw = 4;
   else if (patch_tile(g, *pl, 512, 960, pt)) pt->nw = 8;
   else return false;
   const int pieces = (pt->PP + 15) / 16;
   pt->NI = (pieces + pt->nw - 1) / pt->nw;
-  if (pt->NI > PT_MAXNI) return false;
+  if (pt->NI > (pt->mi == 4 ? 16 : PT_MAXNI)) return false;
   pt->astage = pieces * 1024;
   int lds = 2 * pt->astage + 2 * (pt->astage / 16) + PT_WD * 8192;
   const int ep = pt->nw * PT_EP_WAVE + 1024;
   if (lds < ep) lds = ep;
-  if (lds > (pt->nw == 4 ? 81920 : 163840)) return false;
+  if (lds > ((pt->nw == 4 && pt->mi == 2) ? 81920 : 163840)) return false;
   pt->lds = lds;
   // grid: m-tiles are (image group, row tile); split-K over the channel blocks
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
@@ -391,7 +396,7 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
   int ks = 1;
   {
-    const long long slots = pt->nw == 4 ? slots4() : 256;
+    const long long slots = (pt->nw == 4 && pt->mi == 2) ? slots4() : 256;
     long long best = -1;
     for (int c = 1; c <= ncb && c <= 32; ++c) {
       const int per = (ncb + c - 1) / c;
@@ -638,7 +643,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.pt_G = pt.G; p.pt_R = pt.R; p.pt_Rp = pt.Rp; p.pt_Wp = pt.Wp; p.pt_PP = pt.PP; p.pt_NI = pt.NI;
     p.fd_ptWp = make_fastdiv((uint32_t)pt.Wp); p.fd_ptRp = make_fastdiv((uint32_t)pt.Rp); p.fd_ptR = make_fastdiv((uint32_t)pt.R);
     p.fd_rtiles = make_fastdiv((uint32_t)pt.rtiles);
-    p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
+    p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_mi = pt.mi; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg, st)
                                  : launch_contract_patch_f32(kind, p, pl.nwg, st);
   } else if (dma)

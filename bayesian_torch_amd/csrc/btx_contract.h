@@ -122,6 +122,7 @@ struct ContractParams {
   FastDiv fd_inner, fd_ksplits, fd_ntiles, fd_Cg, fd_KW, fd_KH, fd_rtiles;  // wave-uniform index splits
   void* trace;  // BTX_PT_TRACE builds: per-wave phase timings (measurement only)
   int pt_nw, pt_astage, pt_lds;
+  int pt_mi;      // patch variant: 32-pixel MFMA tiles per wave (2 | 4)
   int st_sbytes;  // stem variant: bytes of the s_in word array in LDS  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off
   uint32_t wt_bytes, wt_delta_off;

@@ -37,10 +37,16 @@ namespace btx {
 
 // ContractParams fields used in addition: pt_G, pt_R, pt_Rp, pt_Wp, pt_PP, pt_NI, pt_rtiles, wt (pre-sampled weight
 // tiles), wt_bytes, wt_delta_off; kper = channel blocks per split * BK.
-template <int PREC, int KIND, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const ContractParams p) {
+// MI = 32-pixel MFMA tiles per wave: 2 (64 pixels, 128 accumulator registers, two waves per SIMD) or 4 (128 pixels, 256
+// accumulators — the unified 512-entry register file of a single wave per SIMD; every weight fragment read from LDS
+// then feeds twice as many MFMAs).
+template <int PREC, int KIND, int NW, int MI>
+__global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_kernel(const ContractParams p) {
   const RngLive rl = rng_live<KIND>(p);
   constexpr int NT = 64 * NW;
+  constexpr int WPX = 32 * MI;                      // pixels per wave
+  constexpr int MAXNI = (MI == 4) ? 16 : PT_MAXNI;  // DMA pieces per wave per patch slot
+  constexpr int SJ = (MI == 4) ? 4 : 2;             // sign words per thread per patch slot
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
   constexpr int BK = NG * G;
@@ -114,9 +120,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
   // ---- patch loader role: DMA instruction i (i = wave + 8*j, j < pt_NI) moves patch pixels 16i + (lane>>2),
   //      granule slot lane&3 (source-side swizzle as in the DMA variant).  Byte offset of channel block 0, or OOB.
   const int g_lane = (lane & 3) ^ ((lane >> 4) & 3);
-  uint32_t pp_boff[PT_MAXNI];
+  uint32_t pp_boff[MAXNI];
 #pragma unroll
-  for (int j = 0; j < PT_MAXNI; ++j) {
+  for (int j = 0; j < MAXNI; ++j) {
     const int q = 16 * (wave + NW * j) + (lane >> 2);
     uint32_t bo = DMA_OOB;
     if (j < p.pt_NI && q < p.pt_PP) {
@@ -135,10 +141,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
             smem + PT_A_OFF + (wave + NW * j) * 1024);
   }
   // ---- sign role: thread t hashes the words of patch pixels t and t+512 (element offset of channel block 0)
-  uint32_t sg_off[2];
-  bool sg_ok[2];
+  uint32_t sg_off[SJ];
+  bool sg_ok[SJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < SJ; ++j) {
     const int q = tid + NT * j;
     sg_ok[j] = q < p.pt_PP;
     const int qq = sg_ok[j] ? q : 0;
@@ -150,10 +156,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
                 (uint32_t)(group * p.Cg);
   }
   // ---- MFMA role: wave owns output pixels [64*wave, +64) of the tile, flattened (image, row, col)
-  int q0[2];       // patch pixel of tap (0,0) for this lane's two output pixels
+  int q0[MI];      // patch pixel of tap (0,0) for each of this lane's output pixels
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int pl = wave * 64 + mi * 32 + l31;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int pl = wave * WPX + mi * 32 + l31;
     uint32_t ut, uc, ugi, ur;
     fdivmod((uint32_t)pl, p.fd_Wo, (uint32_t)p.Wo, ut, uc);
     fdivmod(ut, p.fd_ptR, (uint32_t)p.pt_R, ugi, ur);
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     unsigned char* as = smem + PT_A_OFF + (cbi & 1) * a_stage + (wave + NW * j) * 1024;
     uint32_t bo = DMA_OOB;
 #pragma unroll
-    for (int jj = 0; jj < PT_MAXNI; ++jj)
+    for (int jj = 0; jj < MAXNI; ++jj)
       if (jj == j) bo = pp_boff[jj];
     dma16(x_rsrc, bo == DMA_OOB ? DMA_OOB : bo + cboff, as);
   };
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     if constexpr (KIND == 1) {
       unsigned char* ss = smem + PT_S_OFF + (cbi & 1) * s_stage;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < SJ; ++j) {
         if (sg_ok[j]) {
           const uint32_t off = sg_off[j] + (uint32_t)((cb_begin + cbi) * BK);
           uint32_t w = btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
@@ -185,9 +191,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
       }
     }
   };
-  f32x16 accm[2][2], accd[2][2];
+  f32x16 accm[MI][2], accd[MI][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MI; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -197,40 +203,40 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
   // words).  They are double-buffered: the reads of stage s+1 are issued BEFORE the MFMAs of stage s, so that after the
   // per-stage barrier the LDS pipe and the matrix pipe work at the same time instead of one after the other.  The
   // delta weights of a stage are read at the start of its own multiply (the 8 mean MFMAs cover their latency).
-  using Frag = StageFrag;
+  using Frag = StageFragT<MI>;
   auto load_frag = [&](Frag& f, int cbi, int toff, int wslot) __attribute__((always_inline)) {
     const unsigned char* as = smem + PT_A_OFF + (cbi & 1) * a_stage;
     const unsigned char* ss = smem + PT_S_OFF + (cbi & 1) * s_stage;
     const unsigned char* ws = smem + PT_W_OFF + wslot * DW_STAGE;
-    int q[2];
+    int q[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) q[mi] = q0[mi] + toff;
+    for (int mi = 0; mi < MI; ++mi) q[mi] = q0[mi] + toff;
     if constexpr (BTX_PT_ABL & 2) {
 #pragma unroll
       for (int kk = 0; kk < NG / 2; ++kk)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
           f.a[kk][i] = (u32x4){(uint32_t)q[0], (uint32_t)kk, 3u, 4u};
-          f.wm[kk][i] = (u32x4){(uint32_t)q[1], 7u, (uint32_t)wslot, 4u};
+          f.wm[kk][i & 1] = (u32x4){(uint32_t)q[1], 7u, (uint32_t)wslot, 4u};
+          f.sw[i] = (uint32_t)toff;
         }
-      f.sw[0] = f.sw[1] = (uint32_t)toff;
     } else {
 #pragma unroll
       for (int kk = 0; kk < NG / 2; ++kk) {
         const int row = 2 * kk + h;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) f.a[kk][mi] = *(const u32x4*)(as + q[mi] * 64 + ((row ^ ((q[mi] >> 2) & 3)) * 16));
+        for (int mi = 0; mi < MI; ++mi) f.a[kk][mi] = *(const u32x4*)(as + q[mi] * 64 + ((row ^ ((q[mi] >> 2) & 3)) * 16));
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) f.wm[kk][ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
       }
       if constexpr (KIND == 1) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) f.sw[mi] = *(const uint32_t*)(ss + q[mi] * 4);
+        for (int mi = 0; mi < MI; ++mi) f.sw[mi] = *(const uint32_t*)(ss + q[mi] * 4);
       }
     }
   };
   auto compute = [&](Frag& f, int wslot) __attribute__((always_inline)) {
-    stage_mma<PREC, KIND>(f, smem + PT_W_OFF + wslot * DW_STAGE, accm, accd, l31, h);
+    stage_mma<PREC, KIND, MI>(f, smem + PT_W_OFF + wslot * DW_STAGE, accm, accd, l31, h);
   };
 
   // =================== main loop ==========================================================================
@@ -318,7 +324,17 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
     const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
     const int nvalid = nimg * nrow * p.Wo;
     const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
-    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+if constexpr (MI == 2) {
+      staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    } else {
+#pragma unroll
+      for (int hf = 0; hf < MI / 2; ++hf) {
+        __builtin_amdgcn_sched_barrier(0);  // one half of the 256 accumulators at a time
+        staged_epilogue<KIND, NW>(p, rl, reinterpret_cast<const f32x16(&)[2][2]>(accm[2 * hf]),
+                                  reinterpret_cast<const f32x16(&)[2][2]>(accd[2 * hf]), smem, tid, wave, lane, ntile,
+                                  group, split, m0, nvalid, nullptr, wave * (MI / 2) + hf, hf == 0);
+      }
+    }
   }
 #ifdef BTX_PT_TRACE
   if (p.trace) {
@@ -335,9 +351,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_patch_kernel(const Contra
 
 template <int PREC>
 static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg, hipStream_t st) {
-#define BTX_LAUNCH_PT(KIND, NW)                                                                                   \
+#define BTX_LAUNCH_PT(KIND, NW, MI)                                                                                 \
   do {                                                                                                            \
-    auto kfn = contract_patch_kernel<PREC, KIND, NW>;                                                             \
+    auto kfn = contract_patch_kernel<PREC, KIND, NW, MI>;                                                           \
     static bool attr_done = false;                                                                                \
     if (!attr_done) {                                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);   \
@@ -348,8 +364,9 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
   } while (0)
   int rc = launch_presample_impl<PREC>(kind, p, st);
   if (rc) return rc;
-  if (p.pt_nw == 4) { if (kind == 0) BTX_LAUNCH_PT(0, 4); else BTX_LAUNCH_PT(1, 4); }
-  else { if (kind == 0) BTX_LAUNCH_PT(0, 8); else BTX_LAUNCH_PT(1, 8); }
+  if (p.pt_mi == 4) { if (kind == 0) BTX_LAUNCH_PT(0, 4, 4); else BTX_LAUNCH_PT(1, 4, 4); }
+  else if (p.pt_nw == 4) { if (kind == 0) BTX_LAUNCH_PT(0, 4, 2); else BTX_LAUNCH_PT(1, 4, 2); }
+  else { if (kind == 0) BTX_LAUNCH_PT(0, 8, 2); else BTX_LAUNCH_PT(1, 8, 2); }
 #undef BTX_LAUNCH_PT
   return (int)hipGetLastError();
 }

@@ -82,7 +82,11 @@ template <int KIND, int NW>
 __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
                                                 const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int wave,
                                                 int lane, int ntile, int group, int split, uint32_t m0, int nvalid,
-                                                uint32_t* ep_t = nullptr) {
+                                                uint32_t* ep_t = nullptr, int pwave = -1, bool first = true) {
+  // pwave: index of the 64-pixel group of the tile these fragments hold (default: the wave index); `wave` selects the
+  // wave-private staging area.  first == false: the per-channel constants are already in LDS (second half of a wave
+  // that owns 128 pixels).
+  if (pwave < 0) pwave = wave;
   constexpr int EP_ROW = PT_EP_ROW;
   constexpr int EP_WAVE = PT_EP_WAVE;
   const int l31 = lane & 31, h = lane >> 5;
@@ -92,7 +96,7 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
   const bool has_ba = has_bias || has_aff;
   // per-channel constants of the tile in LDS: [bias_mean | bias_delta | scale | shift] x 64 (identity where absent)
   float* ba_lds = (float*)(smem + NW * EP_WAVE);
-  if (has_ba) {
+  if (has_ba && first) {
     if (tid < BN) {
       const int col = ntile * BN + tid;
       const int gcol = group * p.Ng + (col < p.Ng ? col : 0);
@@ -123,7 +127,7 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
     if constexpr (KIND == 1) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        const int pl_ = min(wave * 64 + mi * 32 + l31, max(nvalid - 1, 0));
+        const int pl_ = min(pwave * 64 + mi * 32 + l31, max(nvalid - 1, 0));
         const uint32_t orow = (m0 + (uint32_t)pl_) * (uint32_t)p.N + (uint32_t)(group * p.Ng + ntile * BN);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
@@ -171,7 +175,7 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
     // generic path: ragged channel tiles, unaligned s_out words, explicit sign arrays (parity mode)
 #pragma unroll 1
     for (int mi = 0; mi < 2; ++mi) {
-      const int pl_ = wave * 64 + mi * 32 + l31;
+      const int pl_ = pwave * 64 + mi * 32 + l31;
       const bool pix_ok = pl_ < nvalid;
       const uint32_t orow = (m0 + (uint32_t)(pix_ok ? pl_ : 0)) * (uint32_t)p.N + (uint32_t)(group * p.Ng);
 #pragma unroll
@@ -228,7 +232,7 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int pix = r8 * 8 + (lane >> 3);
-        const int pl = wave * 64 + pix;
+        const int pl = pwave * 64 + pix;
         if (pl < nvalid && nv > 0) {
           const f32x4 lo = *(const f32x4*)(ep + pix * EP_ROW + cg * 32);
           const f32x4 hi = *(const f32x4*)(ep + pix * EP_ROW + cg * 32 + 16);

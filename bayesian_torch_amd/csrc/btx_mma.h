@@ -10,16 +10,18 @@ namespace btx {
 
 // Fragments of one K-stage held in registers: activations a[kk][mi], mean weights wm[kk][ni], the sign word of each of
 // the lane's two pixels (32 bf16 / 16 f32 elements of the stage, bit of element e at ((e&1) ? 31 : 15) - (e>>1)).
-struct StageFrag {
-  u32x4 a[NG / 2][2], wm[NG / 2][2];
-  uint32_t sw[2];
+template <int MI>
+struct StageFragT {
+  u32x4 a[NG / 2][MI], wm[NG / 2][2];
+  uint32_t sw[MI];
 };
+using StageFrag = StageFragT<2>;
 
 // mean MFMAs from the fragment registers; the delta weights are read from the LDS tile `ws` (mu at +0, delta at
 // +NG*BN*16) while those run; then the activations get their s_in signs (XOR mask) and the delta MFMAs follow.
-template <int PREC, int KIND>
-__device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws, f32x16 (&accm)[2][2],
-                                          f32x16 (&accd)[2][2], int l31, int h) {
+template <int PREC, int KIND, int MI = 2>
+__device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const unsigned char* ws, f32x16 (&accm)[MI][2],
+                                          f32x16 (&accd)[MI][2], int l31, int h) {
     u32x4 wd[NG / 2][2];
     if constexpr (KIND == 1) {
       if constexpr (BTX_PT_ABL & 2) {
@@ -40,7 +42,7 @@ __device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws,
     for (int kk = 0; kk < NG / 2; ++kk) {
       if constexpr (PREC == 1) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(f.wm[kk][ni]), "v"(f.a[kk][mi])); accm[mi][ni][0] += 1.f; }
@@ -51,7 +53,7 @@ __device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws,
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
               accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(f.wm[kk][ni][e]), u2f(f.a[kk][mi][e]), accm[mi][ni], 0, 0, 0);
@@ -64,14 +66,14 @@ __device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws,
         if constexpr (PREC == 1) {
           if constexpr (!(BTX_PT_ABL & 16)) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
               const uint32_t swr = f.sw[mi] << (4 * row);
 #pragma unroll
               for (int d = 0; d < 4; ++d) f.a[kk][mi][d] ^= ((swr << d) & 0x80008000u);
             }
           }
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
               if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(wd[kk][ni]), "v"(f.a[kk][mi])); accd[mi][ni][0] += 1.f; }
@@ -80,7 +82,7 @@ __device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws,
             }
         } else {
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
+          for (int mi = 0; mi < MI; ++mi) {
             const uint32_t swr = f.sw[mi] << (2 * row);
 #pragma unroll
             for (int e = 0; e < 4; ++e) f.a[kk][mi][e] ^= ((swr << ((e >> 1) + ((e & 1) ? 0 : 16))) & 0x80000000u);
@@ -88,7 +90,7 @@ __device__ __forceinline__ void stage_mma(StageFrag& f, const unsigned char* ws,
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
               for (int ni = 0; ni < 2; ++ni)
                 accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wd[kk][ni][e]), u2f(f.a[kk][mi][e]), accd[mi][ni], 0, 0, 0);
