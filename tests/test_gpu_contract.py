@@ -159,6 +159,57 @@ def test_fused_noise_kernels_vs_oracle(prec, act):
     print("worst rel-L2 (%s/%s): %.3g" % (prec, act, worst))
 
 
+def _random_conv_cases(n, seed):
+    """seeded random 2-D geometries that steer through every kernel variant: stems (C <= 4), channel padding,
+    stride-1 patch tiles with ragged rows / several images per tile, strided and dilated LDS-DMA tiles, groups,
+    ragged output-channel tiles, split-K"""
+    import random
+    rng = random.Random(seed)
+    cases = []
+    while len(cases) < n:
+        cin = rng.choice([1, 3, 4, 8, 16, 24, 32, 40, 64, 96, 128])
+        groups = rng.choice([1, 1, 1, 2, 4])
+        if cin % groups or (cin // groups) % 8 and groups > 1:
+            groups = 1
+        cout = rng.choice([groups * rng.randint(1, 40), 64, 72, 128, 8 * rng.randint(1, 20)])
+        cout = max(groups, cout // groups * groups)
+        kh, kw = rng.choice([(1, 1), (3, 3), (3, 3), (2, 2), (5, 5), (1, 3), (3, 1), (7, 7)])
+        stride = rng.choice([1, 1, 1, 2, 2, 3])
+        dil = rng.choice([1, 1, 1, 2])
+        pad = rng.randint(0, 3)
+        h, w = rng.randint(4, 40), rng.randint(4, 40)
+        if (h + 2 * pad - dil * (kh - 1) - 1) < 0 or (w + 2 * pad - dil * (kw - 1) - 1) < 0:
+            continue
+        nb = rng.randint(1, 9)
+        typ = rng.choice(["Flipout", "Flipout", "Reparameterization"])
+        kwargs = dict(in_channels=cin, out_channels=cout, kernel_size=(kh, kw), stride=stride, padding=pad,
+                      dilation=dil, groups=groups, bias=rng.random() < 0.5)
+        if typ == "Reparameterization":
+            kwargs.update(prior_mean=0, prior_variance=1, posterior_mu_init=0, posterior_rho_init=-3.0)
+        cases.append(("Conv2d" + typ, kwargs, (nb, cin, h, w)))
+    return cases
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_random_geometries_match_oracle(prec):
+    """48 seeded random conv geometries per precision, in-kernel noise, vs the CPU oracle fed with the same noise"""
+    dev = _dev()
+    worst = 0.0
+    for i, (cls, kw, xshape) in enumerate(_random_conv_cases(48, 20260925 + (prec == "bf16"))):
+        layer, x, out, geo, a = _run_fused(cls, kw, xshape, prec, prec, dev, sample=i, seed_init=100 + i)
+        o = out.float().cpu().numpy()
+        assert np.isfinite(o).all(), (cls, kw, xshape)
+        ref = oracle_forward(geo, a["x"], a["mu_w"], a["rho_w"], a["mu_b"], a["rho_b"], a["eps_w"], a["eps_b"],
+                             a["sign_in"], a["sign_out"], bf16=(prec == "bf16"))
+        if prec == "bf16":
+            ref = torch.from_numpy(ref).to(torch.bfloat16).float().numpy()
+        tol = TOL_F32 if prec == "f32" else 3e-3
+        err = rel_l2(o, ref)
+        worst = max(worst, err)
+        assert err < tol, (i, cls, kw, xshape, prec, err)
+    print("worst rel-L2 over random geometries (%s): %.3g" % (prec, worst))
+
+
 def test_determinism_and_sample_dependence():
     dev = _dev()
     from bayesian_torch_amd import layers as L

@@ -37,6 +37,7 @@ for step in "$@"; do
     kprof_stem) R="$PWD"; cd /tmp; timeout 300 rocprofv3 --kernel-trace -d "$R/gpurun_out/kprof" -o kp -- python "$R/tools/gpu_diag.py" one --prec bf16 --iters 10 --shape 3,64,224,2,7 > /dev/null 2>&1; cd "$R"; echo "kprof rc=$?" ;;
     gvariants) for f in build_variants/libbtx_*.so; do for sh in 64,64,56,1,3 256,256,14,1,3; do echo -n "$(basename $f) "; BTX_LIB=$PWD/$f timeout 300 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep shape; done; done > gpurun_out/gvariants.log 2>&1; echo "gvariants rc=$?" ;;
     mi4ab) for sh in 64,64,56,1,3 128,128,28,1,3 256,256,14,1,3 512,512,7,1,3; do for v in "X=0" "BTX_PATCH_MI=4"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/mi4ab.log 2>&1; echo "mi4ab rc=$?"; BTX_PATCH_MI=4 timeout 900 python -m pytest tests/test_gpu_contract.py -m gpu -q -x 2>&1 | tail -3 ;;
+    redab) for sh in 256,256,14,1,3 512,512,7,1,3 256,512,14,2,3 256,512,14,2,1; do for v in "X=0" "BTX_NO_FUSED_REDUCE=1"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/redab.log 2>&1; echo "redab rc=$?" ;;
     kstats) R="$PWD"; cd /tmp; for v in main a31 a63 a1 a4; do lib="$R/build_variants/libbtx_$v.so"; [ $v = main ] && lib="$R/bayesian_torch_amd/libbtx.so"; BTX_LIB=$lib timeout 300 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/ks_$v" -o ks -- python "$R/tools/gpu_diag.py" one --prec bf16 --iters 10 > /dev/null 2>&1; echo "== $v"; find "$R/gpurun_out/ks_$v" -name "*kernel_stats.csv" | head -1 | xargs cat | grep -E "patch|presample|Name" | cut -c1-200; done > "$R/gpurun_out/kstats.log" 2>&1; cd "$R"; echo "kstats rc=$?" ;;
     prof)   cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1; echo "prof rc=$?"; cd "$OLDPWD" ;;
   esac
