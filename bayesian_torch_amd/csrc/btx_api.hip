@@ -207,6 +207,61 @@ static int launch_rowfuse_pack(const void* x, void* out, int NB, int C, int H, i
   return (int)hipGetLastError();
 }
 
+
+// ========================================================================================================
+// btx_maxpool2d_cl: channels-last max pooling, the op between the stem and layer1 of a ResNet (reference
+// models/deterministic/resnet_large.py: self.maxpool).  HBM-bound: every thread owns 8 channels (16 B bf16 / 32 B
+// f32) of one output pixel, reads its window with 16-byte loads, writes once.
+// ========================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2d_cl_kernel(const T* __restrict__ x, T* __restrict__ out, int NB, int H,
+                                                           int W, int C, int Ho, int Wo, int k, int s, int pad,
+                                                           long long total) {
+  const int cgs = C >> 3;  // groups of 8 channels
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int cg = (int)(t % cgs);
+    long long r = t / cgs;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int kh = 0; kh < k; ++kh) {
+      const int h = ho * s - pad + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int w = wo * s - pad + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const T* src = x + (((long long)n * H + h) * W + w) * C + cg * 8;
+        if constexpr (sizeof(T) == 2) {
+          const u32x4 v = *(const u32x4*)src;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            m[2 * j] = fmaxf(m[2 * j], u2f(v[j] << 16));
+            m[2 * j + 1] = fmaxf(m[2 * j + 1], u2f(v[j] & 0xffff0000u));
+          }
+        } else {
+          const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { m[j] = fmaxf(m[j], a[j]); m[4 + j] = fmaxf(m[4 + j], b[j]); }
+        }
+      }
+    }
+    T* dst = out + (((long long)n * Ho + ho) * Wo + wo) * C + cg * 8;
+    if constexpr (sizeof(T) == 2) {
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (f2u(m[2 * j]) >> 16) | (f2u(m[2 * j + 1]) & 0xffff0000u);  // exact: inputs are bf16
+      *(u32x4*)dst = o;
+    } else {
+      *(f32x4*)dst = (f32x4){m[0], m[1], m[2], m[3]};
+      *(f32x4*)(dst + 4) = (f32x4){m[4], m[5], m[6], m[7]};
+    }
+  }
+}
+
 extern "C" {
 
 int btx_abi_version(void) { return BTX_ABI_VERSION; }
@@ -758,6 +813,29 @@ int btx_rowfuse_pack(const void* x, int in_dtype, const int64_t* strides_ncHW, i
   if (ib && !ob) return launch_rowfuse_pack<__bf16, float>(x, out, NB, C, H, W, Hp, Wp, cp, ph, pw, strides_ncHW, st);
   if (!ib && ob) return launch_rowfuse_pack<float, __bf16>(x, out, NB, C, H, W, Hp, Wp, cp, ph, pw, strides_ncHW, st);
   return launch_rowfuse_pack<float, float>(x, out, NB, C, H, W, Hp, Wp, cp, ph, pw, strides_ncHW, st);
+}
+
+int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, int C, int k, int stride, int pad,
+                     void* stream) {
+  if (!x || !out) return BTX_E_NULL;
+  if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || 2 * pad > k) return BTX_E_SHAPE;
+  if (C % 8) return BTX_E_UNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)out) & 15)) return BTX_E_ALIGN;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return BTX_E_SHAPE;
+  const long long total = (long long)NB * Ho * Wo * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 262144) blocks = 262144;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == BTX_ACT_BF16)
+    hipLaunchKernelGGL(maxpool2d_cl_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, (const __bf16*)x, (__bf16*)out, NB,
+                       H, W, C, Ho, Wo, k, stride, pad, total);
+  else if (dtype == BTX_ACT_F32)
+    hipLaunchKernelGGL(maxpool2d_cl_kernel<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (float*)out, NB, H,
+                       W, C, Ho, Wo, k, stride, pad, total);
+  else
+    return BTX_E_DTYPE;
+  return (int)hipGetLastError();
 }
 
 int btx_mc_accumulate(const void* logits, int bs, int C, int act_dtype, float kl, float* packed, void* stream) {

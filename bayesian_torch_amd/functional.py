@@ -475,3 +475,15 @@ def softplus_naive(rho):
 def kl_aten(mu_q, sigma_q, mu_p, sigma_p):
     kl = torch.log(sigma_p) - torch.log(sigma_q) + (sigma_q ** 2 + (mu_q - mu_p) ** 2) / (2 * (sigma_p ** 2)) - 0.5
     return kl.mean()
+
+
+def maxpool2d_hip(x, kernel, stride, padding):
+    """torch.nn.functional.max_pool2d for channels-last CUDA tensors through btx_maxpool2d_cl (C % 8 == 0)"""
+    L = _lib.lib()
+    n, c, h, w = x.shape
+    xp = x.contiguous(memory_format=torch.channels_last)
+    ho, wo = (h + 2 * padding - kernel) // stride + 1, (w + 2 * padding - kernel) // stride + 1
+    out = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _lib.check(L.btx_maxpool2d_cl(xp.data_ptr(), out.data_ptr(), _lib.ACT_BF16 if x.dtype == torch.bfloat16 else _lib.ACT_F32,
+                                  n, h, w, c, kernel, stride, padding, torch.cuda.current_stream(x.device).cuda_stream))
+    return out

@@ -80,8 +80,18 @@ def fuse_resnet(model):
     if hasattr(model, "conv1") and hasattr(model, "bn1") and hasattr(model, "maxpool") and _is_var(model.conv1):
         model._stem = _Folded(model.conv1, model.bn1)
 
+        def pool(mp, y):
+            """the stem's max-pool on the channels-last activations (own HBM-bound kernel when the geometry allows)"""
+            ints = all(isinstance(v, int) for v in (mp.kernel_size, mp.stride, mp.padding, mp.dilation))
+            if (y.is_cuda and isinstance(mp, nn.MaxPool2d) and ints and mp.dilation == 1 and not mp.ceil_mode
+                    and not mp.return_indices and y.shape[1] % 8 == 0 and 2 * mp.padding <= mp.kernel_size
+                    and y.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled()):
+                from .. import functional as BF
+                return BF.maxpool2d_hip(y, mp.kernel_size, mp.stride, mp.padding)
+            return mp(y)
+
         def fwd(self, x):
-            x = self.maxpool(self._stem(x, None, True))
+            x = pool(self.maxpool, self._stem(x, None, True))
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
             x = self.avgpool(x)
             return self.fc(x.flatten(1))

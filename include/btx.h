@@ -194,6 +194,12 @@ int btx_sample_weights(const BtxSampleItem* items_host, int n_items, const BtxRn
 int btx_rowfuse_pack(const void* x, int in_dtype, const int64_t* strides_ncHW_host, int NB, int C, int H, int W,
                      void* out, int out_dtype, int Hp, int Wp, int cp, int ph, int pw, void* stream);
 
+/* §8(f): the op right behind the stem of the reference's ResNets (models/deterministic/resnet_large.py: maxpool after
+ * conv1-bn1-relu, torch.nn.MaxPool2d(kernel, stride, padding), dilation 1, floor mode).  Channels-last [NB][H][W][C]
+ * -> [NB][Ho][Wo][C], C % 8 == 0, 2*pad <= k; identical results to torch (max is exact). */
+int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, int C, int k, int stride, int pad,
+                     void* stream);
+
 /* Output spatial extent for a geometry (same arithmetic as torch's conv / conv_transpose). */
 int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, int32_t* Wo);
 

@@ -156,6 +156,19 @@ def test_fused_epilogue_matches_unfused_layer(prec, act, tol):
         assert (got >= 0).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_cl_is_bit_exact_vs_torch(dtype):
+    from bayesian_torch_amd import functional as BF
+    dev = _dev()
+    torch.manual_seed(3)
+    for (n, c, h, w, k, s_, p_) in [(2, 64, 112, 112, 3, 2, 1), (3, 8, 7, 9, 3, 2, 1), (1, 16, 10, 10, 2, 2, 0),
+                                   (2, 24, 13, 5, 3, 1, 1), (1, 8, 4, 4, 5, 3, 2)]:
+        x = torch.randn(n, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        ref = torch.nn.functional.max_pool2d(x, k, s_, p_)
+        got = BF.maxpool2d_hip(x, k, s_, p_)
+        assert got.shape == ref.shape and torch.equal(got, ref), (n, c, h, w, k, s_, p_)
+
+
 def test_fused_resnet18_matches_unfused():
     import bayesian_torch_amd as bt
     from bayesian_torch_amd.models.resnet import resnet18
