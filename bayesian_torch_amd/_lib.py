@@ -42,7 +42,8 @@ class Noise(ctypes.Structure):
 
 class SampleItem(ctypes.Structure):
     _fields_ = [("geom", ctypes.POINTER(Geom)), ("mu_w", ctypes.c_void_p), ("rho_w", ctypes.c_void_p),
-                ("out", ctypes.c_void_p), ("kind", ctypes.c_int32), ("layer_id", ctypes.c_uint32)]
+                ("out", ctypes.c_void_p), ("kind", ctypes.c_int32), ("layer_id", ctypes.c_uint32),
+                ("src_KW", ctypes.c_int32), ("src_C", ctypes.c_int32)]
 
 
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss",

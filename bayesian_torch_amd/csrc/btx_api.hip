@@ -748,7 +748,8 @@ int btx_sample_weights(const BtxSampleItem* items, int n_items, const BtxRng* rn
       const BtxSampleItem& s = items[base + i];
       if (!s.geom || !s.mu_w || !s.rho_w || !s.out) return BTX_E_NULL;
       if (s.kind != BTX_KIND_REPARAM && s.kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
-      if ((((uintptr_t)s.mu_w | (uintptr_t)s.rho_w | (uintptr_t)s.out) & 15)) return BTX_E_ALIGN;
+      const bool remap = s.src_C != 0 || s.src_KW != 0;  // scalar reads: no alignment requirement on mu/rho
+      if ((((uintptr_t)s.out) & 15) || (!remap && (((uintptr_t)s.mu_w | (uintptr_t)s.rho_w) & 15))) return BTX_E_ALIGN;
       Plan pl;
       int rc = make_plan(s.geom, prec, 0, DBM, &pl);
       if (rc) return rc;
@@ -762,6 +763,12 @@ int btx_sample_weights(const BtxSampleItem* items, int n_items, const BtxRng* rn
       it.first_block = blocks;
       it.layer = s.layer_id;
       it.Ng = pl.Ng; it.K = pl.K; it.ntiles = pl.ntiles; it.kind = s.kind;
+      if (s.src_C != 0 || s.src_KW != 0) {
+        if (s.geom->groups != 1 || s.src_C <= 0 || s.src_KW <= 0 || s.src_C > s.geom->C || s.src_KW > s.geom->KW ||
+            s.geom->C % 4)
+          return BTX_E_UNSUPPORTED;
+        it.Cp = s.geom->C; it.KWp = s.geom->KW; it.src_KW = s.src_KW; it.src_C = s.src_C;
+      }
       uint32_t nb = (it.nquads + 1023u) / 1024u;  // ~4 quads per thread
       if (nb < 1) nb = 1;
       if (nb > 1024u) nb = 1024u;

@@ -19,7 +19,8 @@ template <int PREC>
 __device__ __forceinline__ void presample_quad(int kind, const float* __restrict__ mu, const float* __restrict__ rho,
                                                unsigned char* __restrict__ wt, uint32_t delta_off, int Ng, int K,
                                                int ntiles, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
-                                               uint32_t sample, uint32_t layer) {
+                                               uint32_t sample, uint32_t layer, int Cp = 0, int KWp = 0, int src_KW = 0,
+                                               int src_C = 0) {
   constexpr int G = (PREC == 1) ? 8 : 4;
   // t enumerates the OUTPUT image linearly — (tile, k-granule, channel, quad of the granule), quad fastest — so a wave
   // writes 512 (bf16) / 1024 (f32) contiguous bytes; its reads are 32-byte (bf16) / 16-byte runs, one per channel
@@ -33,8 +34,24 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
   float wm[4] = {0.f, 0.f, 0.f, 0.f}, wd[4] = {0.f, 0.f, 0.f, 0.f};
   if (col < Ng) {
     const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
-    const f32x4 mu4 = *(const f32x4*)(mu + e0);
-    const f32x4 rho4 = *(const f32x4*)(rho + e0);
+    f32x4 mu4, rho4;
+    if (Cp == 0) {
+      mu4 = *(const f32x4*)(mu + e0);
+      rho4 = *(const f32x4*)(rho + e0);
+    } else {
+      // padded layout [n][rows][KWp][Cp] sampled straight from the caller's unpadded [n][rows][src_KW][src_C] weights:
+      // padded taps / channels get mu = 0 and sigma = 0 (rho = -1e30), i.e. they contribute exactly nothing
+      const uint32_t k = 4u * quad, tap_p = k / (uint32_t)Cp, c0 = k - tap_p * (uint32_t)Cp;
+      const uint32_t rowtap = tap_p / (uint32_t)KWp, kw = tap_p - rowtap * (uint32_t)KWp;
+      const uint32_t rows = (uint32_t)K / (uint32_t)(Cp * KWp);
+      const uint32_t sbase = (((uint32_t)(group * Ng + col) * rows + rowtap) * (uint32_t)src_KW + kw) * (uint32_t)src_C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = kw < (uint32_t)src_KW && c0 + e < (uint32_t)src_C;
+        mu4[e] = ok ? mu[sbase + c0 + e] : 0.f;
+        rho4[e] = ok ? rho[sbase + c0 + e] : -1e30f;
+      }
+    }
     float eps[4];
     btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
 #pragma unroll
@@ -76,6 +93,7 @@ struct PresampleItem {
   unsigned char* wt;
   uint32_t delta_off, nquads, first_block, layer;
   int Ng, K, ntiles, kind;
+  int Cp, KWp, src_KW, src_C;  // Cp != 0: mu/rho are the unpadded weights of a channel-/tap-padded layout
 };
 struct PresampleBatch {
   PresampleItem it[PRESAMPLE_MAX_ITEMS];
@@ -93,7 +111,7 @@ __global__ __launch_bounds__(256) void presample_batch_kernel(const PresampleBat
   const uint32_t nblk = (i + 1 < b.n ? b.it[i + 1].first_block : b.total_blocks) - it.first_block;
   for (uint32_t t = (blockIdx.x - it.first_block) * 256u + threadIdx.x; t < it.nquads; t += nblk * 256u)
     presample_quad<PREC>(it.kind, it.mu, it.rho, it.wt, it.delta_off, it.Ng, it.K, it.ntiles, t, b.seed_lo, b.seed_hi,
-                         sample, it.layer);
+                         sample, it.layer, it.Cp, it.KWp, it.src_KW, it.src_C);
 }
 
 template <int PREC>

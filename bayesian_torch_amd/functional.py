@@ -195,15 +195,16 @@ def _weight_geom(op):
 
 def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None):
     """btx_sample_weights: ONE launch samples the weights of every layer in `items` for MC sample `sample_idx`.
-    items = [(kind, op, mu_p, rho_p, layer_id)] with GEMM-major f32 mu/rho as handed to contract_hip; returns the list
-    of uint8 tile buffers, to be passed as contract_hip(..., sampled_w=buf)."""
+    items = [(kind, op, mu_p, rho_p, layer_id[, src_kw, src_c])] with GEMM-major f32 mu/rho as handed to contract_hip —
+    or, with (src_kw, src_c), the UNPADDED weights of the padded geometry `op` (BtxSampleItem.src_KW/src_C); returns
+    the list of uint8 tile buffers, to be passed as contract_hip(..., sampled_w=buf)."""
     L = _lib.lib()
     if not items:
         return []
     prec_c = _lib.PREC_BF16 if prec == "bf16" else _lib.PREC_F32
     arr = (_lib.SampleItem * len(items))()
     geoms, outs = [], []
-    for i, (kind, op, mu_p, rho_p, layer_id) in enumerate(items):
+    for i, (kind, op, mu_p, rho_p, layer_id, *src) in enumerate(items):
         g = _weight_geom(op)
         geoms.append(g)
         nbytes = L.btx_sampled_w_bytes(ctypes.byref(g), kind, prec_c)
@@ -214,6 +215,8 @@ def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None):
         arr[i].geom = ctypes.pointer(g)
         arr[i].mu_w, arr[i].rho_w, arr[i].out = mu_p.data_ptr(), rho_p.data_ptr(), buf.data_ptr()
         arr[i].kind, arr[i].layer_id = kind, int(layer_id) & 0xFFFFFFFF
+        if src:
+            arr[i].src_KW, arr[i].src_C = int(src[0]), int(src[1])
     stream = torch.cuda.current_stream(device).cuda_stream
     r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, 0, sample_dev.data_ptr() if sample_dev is not None else None)
     _lib.check(L.btx_sample_weights(arr, len(items), ctypes.byref(r), prec_c, stream))

@@ -213,33 +213,29 @@ class _VariationalNd(BaseVariationalLayer_):
         return self._forward_aten(input, return_kl)
 
     # ---- MI355X path -----------------------------------------------------------------------------------------
-    def _kernel_weights(self, x_shape):
-        """(layout tag, op, mu, rho) as the HIP kernels of the in-kernel-noise path receive them for an input of
-        shape `x_shape`: GEMM-major, row-fused for small-C stems, channel-padded where C % 8 != 0"""
-        mu, rho = self._w()
-        mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
-        plan = None
-        if self._op.nd == 2 and self._op.in_channels <= 4:
-            plan = BF.rowfuse_plan(self._op, tuple(x_shape))
-        if plan is not None:
-            mu_f, rho_f = BF.rowfuse_weights(mu_p, rho_p, plan)
-            return ("rowfuse", plan["cp"], plan["kwp"]), plan["op"], mu_f, rho_f, plan
-        if self._btx_cpad is not None:
-            extra = self._btx_cpad - self._op.in_channels
-            return (("cpad", self._btx_cpad), self._op_pad, torch.nn.functional.pad(mu_p, (0, extra)),
-                    torch.nn.functional.pad(rho_p, (0, extra)), None)
-        return ("plain",), self._op, mu_p, rho_p, None
-
     def presample_item(self, sample_idx, prec):
         """What bayesian_torch_amd.presample() needs to sample this layer's weights ahead of its next forward (None
-        until the layer has seen an input: the stem layouts depend on the input shape)"""
+        until the layer has seen an input: the stem layouts depend on the input shape).  Padded layouts (row-fused
+        stems, channel padding) are sampled straight from the unpadded parameters (BtxSampleItem.src_KW / src_C)."""
         shape = getattr(self, "_btx_last_xshape", None)
         if shape is None:
             return None
-        tag, op, mu_k, rho_k, _ = self._kernel_weights(shape)
+        mu, rho = self._w()
+        op0 = self._op
+        mu_p, rho_p = BF.gemm_major_view(mu, op0), BF.gemm_major_view(rho, op0)
+        plan = BF.rowfuse_plan(op0, tuple(shape)) if (op0.nd == 2 and op0.in_channels <= 4) else None
+        if plan is not None:
+            tag, op, src = ("rowfuse", plan["cp"], plan["kwp"]), plan["op"], (plan["kw"], plan["cin"])
+        elif self._btx_cpad is not None:
+            kw_last = op0.kernel[2] if op0.nd else 1
+            tag, op, src = ("cpad", self._btx_cpad), self._op_pad, (kw_last, op0.in_channels)
+        else:
+            tag, op, src = ("plain",), op0, ()
+        if src and op0.transposed:
+            return None  # the transposed GEMM-major order is not [N][taps][C] of the padded geometry: per-launch sampling
         kind = _lib.KIND_FLIPOUT if self._family == "flipout" else _lib.KIND_REPARAM
         key = (_rng.seed(), self._sample_key(sample_idx), self._btx_layer_id, self.precision or prec, tag)
-        return key, (kind, op, mu_k, rho_k, self._btx_layer_id)
+        return key, (kind, op, mu_p, rho_p, self._btx_layer_id) + tuple(src)
 
     def _sample_key(self, sample_idx):
         sdev = getattr(self, "_btx_sample_dev", None)  # graph mode (mc.GraphedMC): the index lives on the device

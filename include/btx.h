@@ -180,6 +180,11 @@ typedef struct BtxSampleItem {
   void*          out;        /* device */
   int32_t        kind;
   uint32_t       layer_id;
+  int32_t        src_KW, src_C;  /* both 0: mu_w/rho_w have geom's layout.  Otherwise geom describes a PADDED layout
+                                    [N][KD*KH][KW][C] (row-fused stems: KW and C padded; channel-padded layers: C padded)
+                                    and mu_w/rho_w are the caller's unpadded [N][KD*KH][src_KW][src_C] weights: padded
+                                    positions are sampled as exact zeros, noise indices are those of the padded layout
+                                    (what the contraction launched on the padded geometry expects).  groups == 1. */
 } BtxSampleItem;
 size_t btx_sampled_w_bytes(const BtxGeom* g, int kind, int prec);
 int btx_sample_weights(const BtxSampleItem* items_host, int n_items, const BtxRng* rng /* layer_id unused */,

@@ -236,6 +236,37 @@ def test_presample_is_bit_identical_and_one_shot(prec, act):
         bt.set_precision("f32")
 
 
+def test_presample_of_padded_layouts_is_bit_identical():
+    """channel-padded layers (C % 8 != 0) and row-fused stems are sampled ahead straight from the unpadded parameters
+    (BtxSampleItem.src_KW / src_C): same bits as the per-launch sampling of the padded copies"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    bt.manual_seed(9)
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(L.Conv2dFlipout(3, 24, 5, stride=2, padding=2), torch.nn.ReLU(),
+                              L.Conv2dFlipout(24, 20, 3, padding=1), torch.nn.ReLU(),
+                              L.Conv2dReparameterization(20, 8, 3, 1, 1), torch.nn.Flatten(),
+                              L.LinearFlipout(8 * 10 * 9, 50), torch.nn.ReLU(), L.LinearReparameterization(50, 10)).to(dev).eval()
+    for mod in net:  # the variational layers return (out, kl)
+        if hasattr(mod, "kl_loss"):
+            mod.forward = (lambda f: (lambda x, return_kl=False: f(x, return_kl=False)))(mod.forward)
+    bt.assign_layer_ids(net)
+    for prec in ("f32", "bf16"):
+        bt.set_precision(prec)
+        try:
+            x = torch.randn(4, 3, 20, 18, device=dev)
+            with torch.no_grad():
+                bt.set_sample_index(net, 6)
+                y0 = net(x)
+                bt.set_sample_index(net, 6, presample=True)
+                assert sum(1 for mod in net.modules() if getattr(mod, "_btx_pre", None) is not None) == 5
+                y1 = net(x)
+            assert torch.equal(y0, y1), prec
+        finally:
+            bt.set_precision("f32")
+
+
 def test_graphed_mc_replays_equal_eager_samples():
     """mc.GraphedMC: one captured hipGraph, replayed with the sample index in device memory, must reproduce the eager
     forwards of exactly those sample indices (same kernels, same noise, same accumulation order -> bit-identical)."""
