@@ -481,7 +481,8 @@ static bool make_stem_plan(const BtxGeom* g, int act_dtype, int prec, const Plan
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   if ((g->KW * g->C) % bk || pl.K % bk) return false;
   const long long rowB = (long long)g->W * g->C * esz;
-  for (int nw = 4; nw <= 8; nw += 4) {
+  static const char* snw_env = getenv("BTX_STEM_NW");  // 8: skip the 4-wave plan (A/B measurements)
+  for (int nw = (snw_env && atoi(snw_env) == 8) ? 8 : 4; nw <= 8; nw += 4) {
     const int tp = 64 * nw;
     if (pl.Wo > tp) continue;
     int R = tp / pl.Wo;

@@ -33,7 +33,7 @@ for step in "$@"; do
     ptrace1) for bs in 16 32 64; do echo "== bs $bs"; BTX_LIB=$PWD/build_variants/libbtx_trace.so timeout 300 python tools/gpu_diag.py trace --prec bf16 --shape 64,64,56,1,3 --bs $bs 2>&1 | grep -v "amdgpu.ids\|wave "; done > gpurun_out/ptrace1.log 2>&1; echo "ptrace1 rc=$?" ;;
     ksab) for sh in 256,256,14,1,3 512,512,7,1,3 128,256,28,2,3 256,512,14,2,3 256,512,14,2,1 128,128,28,1,3; do for v in 256 384 512 768; do echo -n "SLOTS4=$v "; BTX_SLOTS4=$v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/ksab.log 2>&1; echo "ksab rc=$?" ;;
     gtimes) for sh in 3,64,224,2,7 64,64,56,1,3 64,128,56,2,3 64,128,56,2,1 128,128,28,1,3 128,256,28,2,3 128,256,28,2,1 256,256,14,1,3 256,512,14,2,3 256,512,14,2,1 512,512,7,1,3; do timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep -E "shape|rror"; done > gpurun_out/gtimes.log 2>&1; echo "gtimes rc=$?" ;;
-    stemab) for v in "X=0" "BTX_NO_STEM=1"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape 3,64,224,2,7 2>&1 | grep -E "shape|rror"; done > gpurun_out/stemab.log 2>&1; echo "stemab rc=$?" ;;
+    stemab) for v in "X=0" "BTX_STEM_NW=8" "BTX_NO_STEM=1"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape 3,64,224,2,7 2>&1 | grep -E "shape|rror"; done > gpurun_out/stemab.log 2>&1; echo "stemab rc=$?" ;;
     kprof_stem) R="$PWD"; cd /tmp; timeout 300 rocprofv3 --kernel-trace -d "$R/gpurun_out/kprof" -o kp -- python "$R/tools/gpu_diag.py" one --prec bf16 --iters 10 --shape 3,64,224,2,7 > /dev/null 2>&1; cd "$R"; echo "kprof rc=$?" ;;
     gvariants) for f in build_variants/libbtx_*.so; do for sh in 64,64,56,1,3 256,256,14,1,3; do echo -n "$(basename $f) "; BTX_LIB=$PWD/$f timeout 300 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep shape; done; done > gpurun_out/gvariants.log 2>&1; echo "gvariants rc=$?" ;;
     mi4ab) for sh in 64,64,56,1,3 128,128,28,1,3 256,256,14,1,3 512,512,7,1,3; do for v in "X=0" "BTX_PATCH_MI=4"; do echo -n "$v "; env $v timeout 120 python tools/gpu_diag.py gtime --prec bf16 --shape $sh 2>&1 | grep -E "shape|rror"; done; done > gpurun_out/mi4ab.log 2>&1; echo "mi4ab rc=$?"; BTX_PATCH_MI=4 timeout 900 python -m pytest tests/test_gpu_contract.py -m gpu -q -x 2>&1 | tail -3 ;;
