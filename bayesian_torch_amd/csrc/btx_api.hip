@@ -686,8 +686,6 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.wt_bytes = (uint32_t)wt_all;
     p.wt_delta_off = (uint32_t)wt_one;
   }
-  static const char* dbg_env = getenv("BTX_DBG");
-  p.dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
   hipStream_t st = (hipStream_t)stream;
   if (stem) {
     p.pt_R = stp.R; p.pt_Rp = stp.Rp; p.pt_rtiles = stp.rtiles; p.pt_nw = stp.nw; p.pt_astage = stp.astage;

@@ -114,7 +114,6 @@ struct ContractParams {
   int ep_relu;
   int out_bf16;        // output element type: 1 bf16, 0 f32 (DMA variant; the others store the activation dtype)
   int sign_unaligned;  // DMA variant: a stage's elements may straddle two 32-sign words (row-fused stems)
-  uint32_t dbg;  // BTX_DBG ablation bits (measurement only; 0 in production)
   uint32_t x_bytes, w_bytes;  // sizes of x and of mu/rho in bytes (buffer descriptors of the DMA variant)
   // patch variant (btx_contract_patch.h): tile = pt_G images x pt_R output rows x Wo; patch = pt_G x pt_Rp x pt_Wp pixels
   int pt_G, pt_R, pt_Rp, pt_Wp, pt_PP, pt_NI, pt_rtiles;

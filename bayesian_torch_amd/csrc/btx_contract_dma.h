@@ -1,46 +1,37 @@
-// btx_contract_dma.h — the LDS-DMA pipeline of the fused sample-and-contract kernel (gfx950): the hot variant.
+// btx_contract_dma.h — the per-tap LDS-DMA pipeline of the sample-and-contract kernel (gfx950): every aligned shape the
+// patch / stem kernels do not take (strided and dilated convolutions, 1x1, 1-D / 3-D, transposed, Linear).
 //
-// Same math, LDS fragment image and epilogue conventions as btx_contract.h::contract_kernel, but NOTHING is staged
-// through registers, which buys the big tile:
+// Same math, LDS fragment image and MFMA conventions as btx_contract.h::contract_kernel, but nothing is staged through
+// registers:
 //
-//   * workgroup tile 512 pixels x 64 channels, 8 waves, a wave owns 64 pixels x 64 channels (2x2 MFMA 32x32
-//     tiles; Flipout: 128 accumulator registers).  One sampled weight quad now serves 512 output rows — the
-//     sampling VALU per MFMA is half that of the 256-pixel register-staged tile;
+//   * workgroup tile 64*NW pixels x 64 channels (NW = 4: two workgroups per CU; 8: one), a wave owns 64 pixels x 64
+//     channels (2x2 MFMA 32x32 tiles; Flipout: 128 accumulator registers);
 //   * a K-stage (32 bf16 / 16 f32 consecutive k = 64 bytes of one pixel) lies inside ONE filter tap (needs
-//     C/groups % stage == 0).  One global_load_lds_dwordx4 moves 16 pixels x 64 B: the four 16-byte granules of a
+//     C/groups % stage == 0).  One buffer_load ... lds moves 16 pixels x 64 B: the four 16-byte granules of a
 //     pixel sit in ADJACENT LANES of one instruction (measured on MI355X, tools/ubench/dma_pattern.hip: 0.90
 //     cycles per 16-B request per CU, vs 1.84 when the same bytes are split over four instructions and 4.9 for one
 //     granule per cache line).  The LDS image is pixel-major with an XOR swizzle, slot = granule ^ ((pixel>>2)&3),
 //     applied on the SOURCE side (the DMA destination is lane-linear), which makes every 16-lane group of the MFMA
-//     fragment reads (16 pixels, one granule) hit 16 distinct 16-byte bank slots;
-//   * the raw f32 (mu, rho) quads ride the same DMA path into a 2-stage ring; the wave that fetched quad row w
-//     reads it back, runs softplus + Philox/Box–Muller on the raw hardware transcendentals and writes the bf16/f32
-//     MFMA weight tile;
+//     fragment reads (16 pixels, one granule) hit 16 distinct 16-byte bank slots; out-of-image taps and tile tails are
+//     zero-filled by the buffer descriptor (per-axis tap-validity bitmasks computed once per workgroup);
+//   * the weights arrive as MFMA-ready tiles, sampled once per launch (btx_presample.h), by the same DMA path into a
+//     ring of WD slots, WD-1 stages ahead;
 //   * every VMEM op in the loop is an LDS-DMA, so hipcc inserts no vmcnt of its own: one counted
 //     `s_waitcnt vmcnt(N)` + lgkmcnt(0) + raw s_barrier per stage, never vmcnt(0) in steady state
 //     (cdna_hip_programming.md §5 "Pipelining across barriers").
 //
 // Ring bookkeeping, iteration s (stage s is being multiplied):
-//   issue   raw(s+2) -> raw slot s&1 (read by P(s) during iteration s-1), then acts/sign(s+2) -> slot (s+2)%3
-//           (read by M(s-1) during iteration s-1) — both reads are behind the barrier that ended iteration s-1
-//   M(s)    acts/sign slot s%3, weight tile s&1
-//   P(s+1)  raw slot (s+1)&1 (landed + visible since the barrier of iteration s-1), writes weight tile (s+1)&1
-//   end     vmcnt(4): everything older than this iteration's 4 activation DMAs has landed = raw(s+2), acts(s+1)
+//   issue   W(s+WD-1) -> weight slot (s+WD-1)%WD, acts/sign(s+2) -> slot (s+2)%3 — both slots were last read during
+//           iteration s-1, behind the barrier that ended it
+//   M(s)    acts/sign slot s%3, weight tile s%WD
+//   end     vmcnt(n), n = the operations this wave issued during THIS iteration: everything older has landed, i.e.
+//           acts(s+1) and W(s+1)
 #pragma once
 #include <type_traits>
-// Measurement-only switches (never defined in the product build):
-//   BTX_ABLATE           honour ContractParams::dbg bits (skip sampling / MFMA / sign hash / activation DMA)
-//   BTX_MP_BARRIER       keep a sched_barrier between the MFMA block and the sampling block
-//   BTX_NO_KK_BARRIER    drop the sched_barrier between the two k-halves of a stage
-//   BTX_NO_STAGGER       all waves issue their activation DMAs at the top of the iteration
-#ifdef BTX_ABLATE
-#define BTX_DBG(bit) (p.dbg & (bit))
-#else
-#define BTX_DBG(bit) false
-#endif
 #include "btx_contract.h"
 #include "btx_epilogue.h"
 #include "btx_presample.h"
+#include "btx_mma.h"
 
 namespace btx {
 
@@ -292,79 +283,21 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     const unsigned char* as = smem + DA_OFF + a_slot * DA_STAGE;
     const unsigned char* ss = smem + DS_OFF + a_slot * DS_STAGE;
     const unsigned char* ws = smem + DW_OFF + (st % WD) * DW_STAGE;
-    uint32_t sw[2];
-    if constexpr (KIND == 1) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) sw[mi] = *(const uint32_t*)(ss + (wave * 64 + mi * 32 + l31) * 4);
-    }
+    StageFrag f;  // every fragment read of the stage is issued up front; the MFMAs follow as the data arrives (btx_mma.h)
 #pragma unroll
     for (int kk = 0; kk < NG / 2; ++kk) {
-      // Register diet (the 128-accumulator Flipout tile leaves ~120 VGPRs for everything else): the two k-halves
-      // of the stage stay apart, and the delta weights are fetched only after the mu-MFMAs have been issued.
-#ifndef BTX_NO_KK_BARRIER
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       const int row = 2 * kk + h;
-      u32x4 a[2], wq[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        a[mi] = *(const u32x4*)(as + (wave * 64 + mi * 32 + l31) * 64 + ((row ^ ((l31 >> 2) & 3)) * 16));
+        f.a[kk][mi] = *(const u32x4*)(as + (wave * 64 + mi * 32 + l31) * 64 + ((row ^ ((l31 >> 2) & 3)) * 16));
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) wq[ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
-      if constexpr (PREC == 1) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, wq[ni]), __builtin_bit_cast(bf16x8, a[mi]), accm[mi][ni], 0, 0, 0);
-        if constexpr (KIND == 1) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            wq[ni] = *(const u32x4*)(ws + NG * BN * 16 + (row * BN + ni * 32 + l31) * 16);
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            const uint32_t swr = sw[mi] << (4 * row);  // this granule row's 8 sign bits at bits 15-d / 31-d
-#pragma unroll
-            for (int d = 0; d < 4; ++d) a[mi][d] ^= ((swr << d) & 0x80008000u);
-          }
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                  __builtin_bit_cast(bf16x8, wq[ni]), __builtin_bit_cast(bf16x8, a[mi]), accd[mi][ni], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wq[ni][e]), u2f(a[mi][e]), accm[mi][ni], 0, 0, 0);
-        if constexpr (KIND == 1) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            wq[ni] = *(const u32x4*)(ws + NG * BN * 16 + (row * BN + ni * 32 + l31) * 16);
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            const uint32_t swr = sw[mi] << (2 * row);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[mi][e] ^= ((swr << ((e >> 1) + ((e & 1) ? 0 : 16))) & 0x80000000u);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
-                accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wq[ni][e]), u2f(a[mi][e]), accd[mi][ni], 0, 0, 0);
-        }
-      }
+      for (int ni = 0; ni < 2; ++ni) f.wm[kk][ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
     }
+    if constexpr (KIND == 1) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) f.sw[mi] = *(const uint32_t*)(ss + (wave * 64 + mi * 32 + l31) * 4);
+    }
+    stage_mma<PREC, KIND>(f, ws, accm, accd, l31, h);
   };
 
   // =================== main loop ==========================================================================
