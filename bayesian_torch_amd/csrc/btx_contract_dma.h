@@ -67,17 +67,26 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte
                                            0, 0, 0);
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant)
-#define BTX_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant).  A small decision tree over the
+// counts the pipelines actually produce; a value in between waits for the next smaller one, which is only more
+// conservative (fewer operations left in flight).
+#define BTX_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
-  switch (n) {
-    BTX_VMCNT_CASE(0) BTX_VMCNT_CASE(1) BTX_VMCNT_CASE(2) BTX_VMCNT_CASE(3) BTX_VMCNT_CASE(4) BTX_VMCNT_CASE(5)
-    BTX_VMCNT_CASE(6) BTX_VMCNT_CASE(7) BTX_VMCNT_CASE(8) BTX_VMCNT_CASE(9) BTX_VMCNT_CASE(10) BTX_VMCNT_CASE(11)
-    BTX_VMCNT_CASE(12) BTX_VMCNT_CASE(13) BTX_VMCNT_CASE(14) BTX_VMCNT_CASE(15) BTX_VMCNT_CASE(16)
-    default: if (n > 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  if (n >= 4) {
+    if (n >= 8) {
+      if (n >= 16) BTX_VM(16); else if (n >= 12) BTX_VM(12); else BTX_VM(8);
+    } else {
+      if (n >= 6) BTX_VM(6); else if (n == 5) BTX_VM(5); else BTX_VM(4);
+    }
+  } else {
+    if (n >= 2) {
+      if (n == 3) BTX_VM(3); else BTX_VM(2);
+    } else {
+      if (n == 1) BTX_VM(1); else BTX_VM(0);
+    }
   }
 }
-#undef BTX_VMCNT_CASE
+#undef BTX_VM
 
 template <int PREC, int KIND, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const ContractParams p) {
