@@ -3,9 +3,9 @@
 
 Workload (BASELINE.json metric / configs[3], per-GPU shard): dnn_to_bnn(ResNet18) Flipout, 224x224, batch 64,
 synthetic input, reference init draws (torch.manual_seed(0)), MC sample s keyed (seed=2024, sample_idx=s).
-A "step" = one Monte-Carlo sample: one stochastic forward of the whole converted model (21 fused
-sample-and-contract launches + the stock BN/ReLU/pool ops between them) + the on-device accumulation of the
-predictive statistics.  N>1: every rank runs its own K samples (weak scaling, sample indices interleaved by rank),
+A "step" = one Monte-Carlo sample: one stochastic forward of the whole converted model (one weight-sampling launch,
+21 contraction launches with eval-BN / residual / ReLU folded into their stores, the pooling ops between them) + the
+on-device accumulation of the predictive statistics, replayed as ONE hipGraph per sample (--no-graph: eager launches).  N>1: every rank runs its own K samples (weak scaling, sample indices interleaved by rank),
 then ONE RCCL all-reduce of the packed statistics inside the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -13,9 +13,9 @@ then ONE RCCL all-reduce of the packed statistics inside the timed region.
            bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel = btx::contract_kernel (Flipout): algorithmic FLOPs of every launch in the timed region
-                (2*2*M*N*K per Flipout launch) / its HIP-event duration on the launch stream, vs the
-                dense MFMA peak of the contraction dtype.
+  roofline      the contraction launches (dominant kernel: btx::contract_patch_kernel, Flipout): algorithmic FLOPs of every
+                launch (2*2*M*N*K per Flipout launch) / its HIP-event duration on the launch stream, vs
+                the dense MFMA peak of the contraction dtype.
   cpu_baseline  oracle/bt_ref.py (the reference's ATen op chain) timed on the host cores, rank 0, N=1 only.
 """
 import argparse
@@ -222,7 +222,10 @@ def main():
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": traffic, "kernel": "btx::contract_kernel<%s,%s,%s>" % (args.prec, act, args.type),
+                    "traffic": traffic,
+                    "kernel": "btx_contract_fwd_ex launches <%s,%s,%s>: contract_patch_kernel (13 of 21 launches, the "
+                              "dominant kernel; `traffic` is its layer1 launch), contract_dma_kernel, contract_stem_kernel, "
+                              "incl. their split-K reduce" % (args.prec, act, args.type),
                     "launches": len(log), "avg_launch_us": 1e3 * total_ms / len(log),
                     "kernel_time_frac_of_step": (total_ms * 1e-3 / log_steps) / (elapsed / args.steps),
                     "algorithmic_gflop_per_step": total_flops / log_steps / 1e9,
