@@ -121,7 +121,9 @@ class GraphedMC:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) keep making runtime calls while this
+        # thread captures
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._one()
         self.packed.zero_()
 

@@ -143,11 +143,27 @@ def main():
     else:
         # one MC sample (weight sampling + 21 fused contractions + pooling + accumulation) = one hipGraph replay;
         # the sample index is a device word the kernels read when they run (BtxRng.sample_idx_dev)
-        graphed = mc.GraphedMC(model, x, kl=kl)
+        try:
+            graphed = mc.GraphedMC(model, x, kl=kl)
+        except Exception as e:  # a runtime that cannot capture: measure the eager path rather than nothing
+            print("bench: hipGraph capture failed (%s: %s) - falling back to eager launches" % (type(e).__name__, e),
+                  file=sys.stderr)
+            for m_ in model.modules():
+                if hasattr(m_, "_btx_sample_dev"):
+                    m_._btx_sample_dev = None
+            torch.cuda.synchronize(dev)
+    if graphed is not None:
         packed = graphed.packed
 
         def step(s_global):
             graphed.run(s_global)
+    elif not args.no_graph:
+        packed = torch.zeros(mc.packed_numel(args.batch, 1000), dtype=torch.float32, device=dev)
+
+        def step(s_global):
+            bt.set_sample_index(model, s_global, presample=not args.no_presample)
+            logits = model(x)
+            mc.accumulate(packed, logits, kl)
 
     def barrier():
         if world > 1:
