@@ -156,6 +156,37 @@ def test_fused_epilogue_matches_unfused_layer(prec, act, tol):
         assert (got >= 0).all()
 
 
+def test_fused_resnet50_bottlenecks_match_unfused():
+    """Bottleneck blocks (1x1 / strided 3x3 / 1x1 + projection shortcut): BN/residual/ReLU folded into the stores vs the
+    stock torch ops, f32 MFMA mode, same sample index"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.resnet import resnet50
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    dev = _dev()
+    torch.manual_seed(0)
+    m = resnet50()
+    bt.dnn_to_bnn(m, dict(PRIOR, type="Flipout"))
+    for b in m.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.running_mean.normal_(0, 0.1)
+            b.running_var.uniform_(0.5, 1.5)
+            b.weight.data.uniform_(0.5, 1.5)
+            b.bias.data.normal_(0, 0.1)
+    m = m.to(dev).eval()
+    bt.assign_layer_ids(m)
+    bt.set_precision("f32")
+    x = torch.randn(2, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        bt.set_sample_index(m, 2)
+        a = m(x)
+        assert fuse_resnet(m) == 17
+        bt.set_sample_index(m, 2, presample=True)
+        b = m(x)
+    assert torch.isfinite(a).all()
+    err = float((a - b).norm() / a.norm())
+    assert err < 1e-4, err
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_maxpool_cl_is_bit_exact_vs_torch(dtype):
     from bayesian_torch_amd import functional as BF
