@@ -306,7 +306,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) f.sw[mi] = *(const uint32_t*)(ss + (wave * 64 + mi * 32 + l31) * 4);
     }
-    stage_mma<PREC, KIND>(f, ws, accm, accd, l31, h);
+    DeltaFrag dfrag;
+    load_delta<KIND>(dfrag, ws, l31, h);
+    stage_mma<PREC, KIND>(f, dfrag, accm, accd, l31, h);
   };
 
   // =================== main loop ==========================================================================

@@ -235,10 +235,6 @@ __global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_ker
       }
     }
   };
-  auto compute = [&](Frag& f, int wslot) __attribute__((always_inline)) {
-    stage_mma<PREC, KIND, MI>(f, smem + PT_W_OFF + wslot * DW_STAGE, accm, accd, l31, h);
-  };
-
   // =================== main loop ==========================================================================
   // Iteration s (tap t of channel block cbi), every wave:
   //   1. issues the DMA of W(s+3) and its share of the pieces of the NEXT block's patch (+ that block's sign words);
@@ -283,8 +279,10 @@ __global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_ker
           if (16 * (wave + NW * j) < p.pt_PP) { issue_patch_piece(cbi + 1, j); mpiece = ++nissued; }
         if (t == 0) write_signs(cbi + 1);  // the sign slot of block cbi+1 was last read during block cbi-1
       }
+      DeltaFrag dfrag;  // this stage's delta weights first, then the prefetch of the next stage's fragments
+      load_delta<KIND>(dfrag, smem + PT_W_OFF + (s & (PT_WD - 1)) * DW_STAGE, l31, h);
       if (s + 1 < nstages) { load_frag(nxt, l_cbi, l_toff, (s + 1) & (PT_WD - 1)); advance_load(); }
-      compute(cur, s & (PT_WD - 1));
+      stage_mma<PREC, KIND, MI>(cur, dfrag, accm, accd, l31, h);
 #ifdef BTX_PT_TRACE
       __builtin_amdgcn_sched_barrier(0);
       const uint32_t tB = (uint32_t)__builtin_amdgcn_s_memtime();

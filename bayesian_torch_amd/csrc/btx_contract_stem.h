@@ -158,8 +158,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_stem_kernel(const Contrac
     auto iter = [&](int s, StageFrag& cur, StageFrag& nxt) __attribute__((always_inline)) {
       int m2 = nissued;
       if (s + WD - 1 < nstages) { issue_w(s + WD - 1); nissued += w_nops; m2 = nissued; }
+      DeltaFrag dfrag;  // this stage's delta weights first, then the prefetch of the next stage's fragments
+      load_delta<KIND>(dfrag, smem + W_OFF + (s & (WD - 1)) * DW_STAGE, l31, h);
       if (s + 1 < nstages) { load_frag(nxt, l_e, (s + 1) & (WD - 1)); advance_load(); }
-      stage_mma<PREC, KIND>(cur, smem + W_OFF + (s & (WD - 1)) * DW_STAGE, accm, accd, l31, h);
+      stage_mma<PREC, KIND>(cur, dfrag, accm, accd, l31, h);
       wait_vmcnt(nissued - m1);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       m1 = m2;

@@ -17,24 +17,34 @@ struct StageFragT {
 };
 using StageFrag = StageFragT<2>;
 
-// mean MFMAs from the fragment registers; the delta weights are read from the LDS tile `ws` (mu at +0, delta at
-// +NG*BN*16) while those run; then the activations get their s_in signs (XOR mask) and the delta MFMAs follow.
-template <int PREC, int KIND, int MI = 2>
-__device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const unsigned char* ws, f32x16 (&accm)[MI][2],
-                                          f32x16 (&accd)[MI][2], int l31, int h) {
-    u32x4 wd[NG / 2][2];
-    if constexpr (KIND == 1) {
-      if constexpr (BTX_PT_ABL & 2) {
+// delta-weight fragments of a stage (Flipout), read from the LDS tile `ws` (mu at +0, delta at +NG*BN*16)
+struct DeltaFrag {
+  u32x4 w[NG / 2][2];
+};
+template <int KIND>
+__device__ __forceinline__ void load_delta(DeltaFrag& d, const unsigned char* ws, int l31, int h) {
+  if constexpr (KIND == 1) {
+    if constexpr (BTX_PT_ABL & 2) {
 #pragma unroll
-        for (int kk = 0; kk < NG / 2; ++kk) wd[kk][0] = wd[kk][1] = (u32x4){7u, 7u, 1u, 4u};
-      } else {
+      for (int kk = 0; kk < NG / 2; ++kk) d.w[kk][0] = d.w[kk][1] = (u32x4){7u, 7u, 1u, 4u};
+    } else {
 #pragma unroll
-        for (int kk = 0; kk < NG / 2; ++kk)
+      for (int kk = 0; kk < NG / 2; ++kk)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            wd[kk][ni] = *(const u32x4*)(ws + NG * BN * 16 + ((2 * kk + h) * BN + ni * 32 + l31) * 16);
-      }
+        for (int ni = 0; ni < 2; ++ni)
+          d.w[kk][ni] = *(const u32x4*)(ws + NG * BN * 16 + ((2 * kk + h) * BN + ni * 32 + l31) * 16);
     }
+  }
+}
+
+// mean MFMAs from the fragment registers, then the activations get their s_in signs (XOR mask) and the delta MFMAs
+// follow.  The caller issues load_delta() BEFORE any LDS read it wants to stay in flight across this call (the fragment
+// prefetch of the next stage): LDS returns in order, so delta fragments queued behind a prefetch would make the delta
+// MFMAs wait for data they do not need.
+template <int PREC, int KIND, int MI = 2>
+__device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& dfrag, f32x16 (&accm)[MI][2],
+                                          f32x16 (&accd)[MI][2], int l31, int h) {
+    const u32x4 (&wd)[NG / 2][2] = dfrag.w;
 #ifdef BTX_MMA_PRIO
     __builtin_amdgcn_s_setprio(BTX_MMA_PRIO);
 #endif
