@@ -48,7 +48,7 @@ class SampleItem(ctypes.Structure):
 
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss",
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
-           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_rowfuse_pack", "btx_maxpool2d_cl")
+           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
 
 
 def lib_path():
@@ -99,6 +99,8 @@ def lib():
                                    i32, vp]
     L.btx_maxpool2d_cl.restype = i32
     L.btx_maxpool2d_cl.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.btx_avgpool_global_cl.restype = i32
+    L.btx_avgpool_global_cl.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.btx_mc_accumulate.restype = i32
     L.btx_mc_accumulate.argtypes = [vp, i32, i32, i32, f32, vp, vp]
     if L.btx_abi_version() != ABI_VERSION:

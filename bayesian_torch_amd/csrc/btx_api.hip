@@ -262,6 +262,43 @@ __global__ __launch_bounds__(256) void maxpool2d_cl_kernel(const T* __restrict__
   }
 }
 
+
+// btx_avgpool_global_cl: global average pooling of channels-last activations ([NB][HW][C] -> [NB][C], f32 accumulate),
+// the op in front of the classifier of the reference's ResNets (resnet_large.py: avgpool).  One workgroup per image and
+// 64-channel slab: 8 lanes cover the slab with 16-byte loads, 32 pixel groups run in parallel, LDS tree at the end.
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_global_cl_kernel(const T* __restrict__ x, T* __restrict__ out, int HW, int C,
+                                                                float inv) {
+  const int n = blockIdx.y, slab = blockIdx.x;
+  const int cg = threadIdx.x & 7, pg = threadIdx.x >> 3;  // 8 channel groups x 32 pixel groups
+  const int c0 = slab * 64 + cg * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < C) {
+    for (int pix = pg; pix < HW; pix += 32) {
+      const T* src = x + ((long long)n * HW + pix) * C + c0;
+      if constexpr (sizeof(T) == 2) {
+        const u32x4 v = *(const u32x4*)src;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[2 * j] += u2f(v[j] << 16); acc[2 * j + 1] += u2f(v[j] & 0xffff0000u); }
+      } else {
+        const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+      }
+    }
+  }
+  __shared__ float red[32][64 + 1];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[pg][cg * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int g = 0; g < 32; ++g) s += red[g][threadIdx.x];  // fixed order: deterministic
+    const int c = slab * 64 + threadIdx.x;
+    if (c < C) out[(long long)n * C + c] = (T)(s * inv);
+  }
+}
+
 extern "C" {
 
 int btx_abi_version(void) { return BTX_ABI_VERSION; }
@@ -839,6 +876,24 @@ int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, 
   else if (dtype == BTX_ACT_F32)
     hipLaunchKernelGGL(maxpool2d_cl_kernel<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (float*)out, NB, H,
                        W, C, Ho, Wo, k, stride, pad, total);
+  else
+    return BTX_E_DTYPE;
+  return (int)hipGetLastError();
+}
+
+int btx_avgpool_global_cl(const void* x, void* out, int dtype, int NB, int HW, int C, void* stream) {
+  if (!x || !out) return BTX_E_NULL;
+  if (NB <= 0 || HW <= 0 || C <= 0) return BTX_E_SHAPE;
+  if (C % 8) return BTX_E_UNSUPPORTED;
+  if (((uintptr_t)x) & 15) return BTX_E_ALIGN;
+  const dim3 grid((C + 63) / 64, NB);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == BTX_ACT_BF16)
+    hipLaunchKernelGGL(avgpool_global_cl_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, (__bf16*)out, HW, C,
+                       1.0f / (float)HW);
+  else if (dtype == BTX_ACT_F32)
+    hipLaunchKernelGGL(avgpool_global_cl_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)out, HW, C,
+                       1.0f / (float)HW);
   else
     return BTX_E_DTYPE;
   return (int)hipGetLastError();

@@ -490,3 +490,14 @@ def maxpool2d_hip(x, kernel, stride, padding):
     _lib.check(L.btx_maxpool2d_cl(xp.data_ptr(), out.data_ptr(), _lib.ACT_BF16 if x.dtype == torch.bfloat16 else _lib.ACT_F32,
                                   n, h, w, c, kernel, stride, padding, torch.cuda.current_stream(x.device).cuda_stream))
     return out
+
+
+def avgpool_global_hip(x):
+    """adaptive_avg_pool2d(x, 1).flatten(1) for channels-last CUDA tensors through btx_avgpool_global_cl (C % 8 == 0)"""
+    L = _lib.lib()
+    n, c, h, w = x.shape
+    xp = x.contiguous(memory_format=torch.channels_last)
+    out = torch.empty((n, c), dtype=x.dtype, device=x.device)
+    _lib.check(L.btx_avgpool_global_cl(xp.data_ptr(), out.data_ptr(), _lib.ACT_BF16 if x.dtype == torch.bfloat16 else _lib.ACT_F32,
+                                       n, h * w, c, torch.cuda.current_stream(x.device).cuda_stream))
+    return out

@@ -93,8 +93,12 @@ def fuse_resnet(model):
         def fwd(self, x):
             x = pool(self.maxpool, self._stem(x, None, True))
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-            x = self.avgpool(x)
-            return self.fc(x.flatten(1))
+            ap = self.avgpool
+            if (x.is_cuda and isinstance(ap, nn.AdaptiveAvgPool2d) and ap.output_size in (1, (1, 1)) and x.shape[1] % 8 == 0
+                    and x.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled()):
+                from .. import functional as BF
+                return self.fc(BF.avgpool_global_hip(x))
+            return self.fc(ap(x).flatten(1))
         model.forward = types.MethodType(fwd, model)
         n += 1
     return n

@@ -205,6 +205,10 @@ int btx_rowfuse_pack(const void* x, int in_dtype, const int64_t* strides_ncHW_ho
 int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, int C, int k, int stride, int pad,
                      void* stream);
 
+/* Global average pooling in front of the classifier (resnet_large.py: AdaptiveAvgPool2d((1,1))): channels-last
+ * [NB][HW][C] -> [NB][C], f32 accumulation in a fixed order, C % 8 == 0. */
+int btx_avgpool_global_cl(const void* x, void* out, int dtype, int NB, int HW, int C, void* stream);
+
 /* Output spatial extent for a geometry (same arithmetic as torch's conv / conv_transpose). */
 int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, int32_t* Wo);
 

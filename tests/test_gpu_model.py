@@ -156,6 +156,20 @@ def test_fused_epilogue_matches_unfused_layer(prec, act, tol):
         assert (got >= 0).all()
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 4e-3)])
+def test_avgpool_global_cl_matches_torch(dtype, tol):
+    from bayesian_torch_amd import functional as BF
+    dev = _dev()
+    torch.manual_seed(5)
+    for (n, c, h, w) in [(64, 512, 7, 7), (3, 72, 5, 9), (1, 8, 1, 1), (2, 2048, 7, 7)]:
+        x = torch.randn(n, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        ref = x.float().mean(dim=(2, 3))
+        got = BF.avgpool_global_hip(x).float()
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max())), (n, c, h, w)
+        assert torch.equal(BF.avgpool_global_hip(x), BF.avgpool_global_hip(x))
+
+
 def test_fused_resnet50_bottlenecks_match_unfused():
     """Bottleneck blocks (1x1 / strided 3x3 / 1x1 + projection shortcut): BN/residual/ReLU folded into the stores vs the
     stock torch ops, f32 MFMA mode, same sample index"""
