@@ -122,6 +122,7 @@ def gemm_major_view(w, op):
 
 
 _WS = {}
+_GEOM_CACHE = {}  # (id(op), batch, extent, kind, dtypes, flags) -> (BtxGeom, workspace bytes, op)
 
 # optional per-launch HIP-event timing of btx_contract_fwd (bench.py's roofline leg).  Events are recorded on the
 # stream the kernel is launched on (torch's current stream == the stream handed to the C-ABI).
@@ -242,20 +243,27 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     out_sp = op.out_spatial(spatial)
     if min(out_sp) <= 0:
         raise ValueError("output size is too small")
-    g = _lib.Geom()
-    g.NB, (g.D, g.H, g.W), g.C, g.N = nb, spatial, op.in_channels, op.out_channels
-    g.KD, g.KH, g.KW = op.kernel
-    g.sd, g.sh, g.sw = op.stride
-    g.pd, g.ph, g.pw = op.padding
-    g.dd, g.dh, g.dw = op.dilation
-    g.od, g.oh, g.ow = op.output_padding
-    g.groups = op.groups
     flags = (_lib.FLAG_TRANSPOSED if op.transposed else 0) | extra_flags
     if out_dtype is not None and out_dtype != x.dtype:
         flags |= _lib.FLAG_OUT_BF16 if out_dtype == torch.bfloat16 else _lib.FLAG_OUT_F32
+    # the geometry struct and the workspace size depend on shapes only: built once per (op, batch, extent, modes)
+    gkey = (id(op), nb, spatial, kind, act, prec_c, flags)
+    cached = _GEOM_CACHE.get(gkey)
+    if cached is None or cached[2] is not op:
+        g = _lib.Geom()
+        g.NB, (g.D, g.H, g.W), g.C, g.N = nb, spatial, op.in_channels, op.out_channels
+        g.KD, g.KH, g.KW = op.kernel
+        g.sd, g.sh, g.sw = op.stride
+        g.pd, g.ph, g.pw = op.padding
+        g.dd, g.dh, g.dw = op.dilation
+        g.od, g.oh, g.ow = op.output_padding
+        g.groups = op.groups
+        if len(_GEOM_CACHE) > 4096:
+            _GEOM_CACHE.clear()
+        cached = _GEOM_CACHE[gkey] = (g, L.btx_contract_workspace_bytes(ctypes.byref(g), kind, act, prec_c, flags), op)
+    g, need = cached[0], cached[1]
     out = _alloc_out(op, nb, out_sp, out_dtype or x.dtype, x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
-    need = L.btx_contract_workspace_bytes(ctypes.byref(g), kind, act, prec_c, flags)
     ws = _workspace(x.device, need, stream) if need else None
     r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF,
                  sample_dev.data_ptr() if sample_dev is not None else None)

@@ -223,7 +223,9 @@ class _VariationalNd(BaseVariationalLayer_):
         mu, rho = self._w()
         op0 = self._op
         mu_p, rho_p = BF.gemm_major_view(mu, op0), BF.gemm_major_view(rho, op0)
-        plan = BF.rowfuse_plan(op0, tuple(shape)) if (op0.nd == 2 and op0.in_channels <= 4) else None
+        plan = None
+        if op0.nd == 2 and op0.in_channels <= 4:
+            plan = self.__dict__.get("_btx_plans", {}).get(tuple(shape)) or BF.rowfuse_plan(op0, tuple(shape))
         if plan is not None:
             tag, op, src = ("rowfuse", plan["cp"], plan["kwp"]), plan["op"], (plan["kw"], plan["cin"])
         elif self._btx_cpad is not None:
@@ -243,8 +245,8 @@ class _VariationalNd(BaseVariationalLayer_):
 
     def _take_presampled(self, sample_idx, prec, tag):
         """one-shot: the buffer bayesian_torch_amd.presample() left for exactly this (seed, sample, layer, prec, layout)"""
-        pre = getattr(self, "_btx_pre", None)
-        self._btx_pre = None
+        pre = self.__dict__.get("_btx_pre")
+        self.__dict__["_btx_pre"] = None  # plain attribute: skip nn.Module.__setattr__'s bookkeeping on the hot path
         if pre is not None and pre[0] == (_rng.seed(), self._sample_key(sample_idx), self._btx_layer_id, prec, tag):
             return pre[1]
         return None
@@ -254,12 +256,12 @@ class _VariationalNd(BaseVariationalLayer_):
         mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
         if sample_idx is None:
             sample_idx = self._btx_sample
-            self._btx_sample += 1
+            self.__dict__["_btx_sample"] = sample_idx + 1
         kind = _lib.KIND_FLIPOUT if self._family == "flipout" else _lib.KIND_REPARAM
         mb = self.mu_bias.detach() if self.mu_bias is not None else None
         rb = self.rho_bias.detach() if self.rho_bias is not None else None
         op = self._op
-        self._btx_last_xshape = tuple(x.shape)
+        self.__dict__["_btx_last_xshape"] = tuple(x.shape)
         plan = self._rowfuse_plan(x) if noise is None else None
         if plan is not None:  # small-C stem: one kernel row per K-stage on the LDS-DMA kernel
             prec = self.precision or BF.get_precision()
@@ -310,7 +312,13 @@ class _VariationalNd(BaseVariationalLayer_):
     def _rowfuse_plan(self, x):
         if self._op.nd != 2 or self._op.in_channels > 4 or not x.is_cuda:
             return None
-        return BF.rowfuse_plan(self._op, tuple(x.shape))
+        cache = self.__dict__.setdefault("_btx_plans", {})  # geometry only: one plan (and one OpDesc) per input shape
+        key = tuple(x.shape)
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = BF.rowfuse_plan(self._op, key)
+        return cache[key]
 
     def materialize_noise(self, sample_idx, x_shape=None, out_shape=None, x_dtype=None):
         """The noise BTX-RNG v1 defines for MC sample `sample_idx` of this layer, in the reference's logical
