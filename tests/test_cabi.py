@@ -58,3 +58,40 @@ def test_abi_version_and_argument_errors_without_gpu():
     g.H = g.W = 56
     g.C = g.N = 64
     assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) == 2 * 64 * 576 * 2
+
+
+def test_argument_errors_of_the_sampling_and_format_entry_points():
+    """host-side validation of btx_sample_weights / btx_sampled_w_bytes / btx_rowfuse_pack / btx_maxpool2d_cl /
+    btx_avgpool_global_cl: every call below returns before anything is launched"""
+    from bayesian_torch_amd import _lib
+    L = _lib.lib()
+    g = _lib.Geom()
+    g.NB, g.D, g.H, g.W, g.C, g.N = 1, 1, 3, 3, 64, 128
+    g.KD, g.KH, g.KW = 1, 3, 3
+    g.sd = g.sh = g.sw = 1
+    g.dd = g.dh = g.dw = 1
+    g.groups = 1
+    # tile image of a 128 x (3*3*64) weight matrix: 2 n-tiles x 64 channels x K elements, bf16, mu + delta for Flipout
+    assert L.btx_sampled_w_bytes(ctypes.byref(g), 1, 1) == 2 * 128 * 576 * 2
+    assert L.btx_sampled_w_bytes(ctypes.byref(g), 0, 1) == 128 * 576 * 2
+    assert L.btx_sampled_w_bytes(ctypes.byref(g), 1, 0) == 2 * 128 * 576 * 4
+    g.N = 100  # ragged n-tile: padded to 128 channels
+    assert L.btx_sampled_w_bytes(ctypes.byref(g), 0, 1) == 128 * 576 * 2
+    r = _lib.Rng(1, 2, 3, None)
+    assert L.btx_sample_weights(None, 1, ctypes.byref(r), 1, None) == -1
+    items = (_lib.SampleItem * 1)()
+    assert L.btx_sample_weights(items, 1, None, 1, None) == -1
+    assert L.btx_sample_weights(items, 0, ctypes.byref(r), 1, None) == 0
+    assert L.btx_sample_weights(items, 1, ctypes.byref(r), 7, None) == -5       # unknown precision
+    assert L.btx_sample_weights(items, 1, ctypes.byref(r), 1, None) == -1       # NULL geom / pointers inside the item
+    st = (ctypes.c_int64 * 4)(1, 1, 1, 1)
+    one = ctypes.c_void_p(16)
+    assert L.btx_rowfuse_pack(None, 1, st, 1, 3, 8, 8, one, 1, 8, 8, 4, 0, 0, None) == -1
+    assert L.btx_rowfuse_pack(one, 1, st, 1, 3, 8, 8, one, 1, 7, 8, 4, 0, 0, None) == -2   # Hp < H
+    assert L.btx_rowfuse_pack(one, 1, st, 1, 5, 8, 8, one, 1, 8, 8, 4, 0, 0, None) == -3   # C > cp
+    assert L.btx_rowfuse_pack(one, 9, st, 1, 3, 8, 8, one, 1, 8, 8, 4, 0, 0, None) == -5   # dtype
+    assert L.btx_maxpool2d_cl(one, one, 1, 1, 8, 8, 12, 3, 2, 1, None) == -3               # C % 8
+    assert L.btx_maxpool2d_cl(one, one, 1, 1, 8, 8, 16, 3, 2, 2, None) == -2               # 2*pad > k
+    assert L.btx_maxpool2d_cl(ctypes.c_void_p(8), one, 1, 1, 8, 8, 16, 3, 2, 1, None) == -6  # alignment
+    assert L.btx_avgpool_global_cl(one, one, 1, 1, 49, 12, None) == -3
+    assert L.btx_avgpool_global_cl(None, one, 1, 1, 49, 16, None) == -1
