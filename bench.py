@@ -203,6 +203,9 @@ def main():
             with torch.no_grad():
                 BF.enable_launch_timing(True)
                 for k in range(min(args.steps, 10)):
+                    # a ~2 ms spin kernel in front of every step lets the host run ahead: without it the GPU would wait for
+                    # the next launch INSIDE an event pair (eager issue of a step takes longer than its kernels)
+                    torch.cuda._sleep(5_000_000)
                     bt.set_sample_index(model, k * world + rank, presample=not args.no_presample)
                     mc.accumulate(scratch, model(x), kl)
                 torch.cuda.synchronize(dev)
