@@ -88,6 +88,33 @@ def mc_forward(model, x, num_samples, sample_offset=0, with_kl=False, group=None
     return packed
 
 
+@torch.no_grad()
+def mc_forward_batched(model, x, num_samples, chunk=4, sample_offset=0, with_kl=False):
+    """Opt-in batched-MC Flipout: the reference's own trick `data = torch.cat([data]*S, 0)` then ONE
+    forward (examples/main_bayesian_flipout_imagenet.py:613-618).  `chunk` replicas of the batch go through the model
+    together: they share one weight perturbation (one sampling pass, `chunk` x larger pixel tiles) and are decorrelated
+    by their per-example Flipout signs only — pseudo-independent samples, NOT the statistics of `mc_forward`, which
+    draws fresh weights per sample.  Returns the packed statistics of all `num_samples` replicas (this rank only)."""
+    bs = x.shape[0]
+    packed = None
+    kl = float(get_kl_loss(model)) if with_kl else 0.0
+    done, cid = 0, 0
+    while done < num_samples:
+        c = min(chunk, num_samples - done)
+        xb = torch.cat([x] * c, 0) if c > 1 else x
+        _rng.set_sample_index(model, sample_offset + cid, presample=xb.is_cuda)
+        logits = model(xb)
+        if isinstance(logits, tuple):
+            logits = logits[0]
+        if packed is None:
+            packed = torch.zeros(packed_numel(bs, logits.shape[1]), dtype=torch.float32, device=logits.device)
+        for i in range(c):
+            accumulate(packed, logits[i * bs:(i + 1) * bs], kl)
+        done += c
+        cid += 1
+    return packed
+
+
 class GraphedMC:
     """One Monte-Carlo sample — weight sampling, the model forward, the accumulation of the predictive statistics —
     captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed per sample.

@@ -141,3 +141,29 @@ def test_cuda_path_fails_loudly_without_library(monkeypatch):
     monkeypatch.setattr(_lib, "lib_path", lambda: "/nonexistent/libbtx.so")
     with pytest.raises(_lib.BtxError, match="no fallback"):
         _lib.lib()
+
+
+def test_batched_mc_flipout_mode_on_cpu():
+    """mc.mc_forward_batched (opt-in: replicas share the weight perturbation) through the ATen path: sample count and
+    normalisation of the accumulated statistics"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd import layers as L
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = L.LinearFlipout(12, 16)
+            self.b = L.LinearFlipout(16, 5)
+
+        def forward(self, x):
+            return self.b(torch.relu(self.a(x, return_kl=False)), return_kl=False)
+
+    net = Net().eval()
+    x = torch.randn(4, 12)
+    packed = mc.mc_forward_batched(net, x, 5, chunk=2, with_kl=True)
+    u = mc.unpack(packed, 4, 5)
+    assert abs(float(u["samples"]) - 5) < 1e-6
+    assert torch.allclose(u["mean_prob"].sum(1), torch.ones(4), atol=1e-5)
+    assert abs(float(u["kl"]) - float(bt.get_kl_loss(net))) < 1e-4 * abs(float(bt.get_kl_loss(net)))

@@ -312,6 +312,47 @@ def test_presample_of_padded_layouts_is_bit_identical():
             bt.set_precision("f32")
 
 
+def test_batched_mc_flipout_mode():
+    """opt-in batched-MC (shared weight perturbation, per-example signs): S replicas in ceil(S/chunk) forwards; the
+    replicas of one chunk differ through their signs; with sigma -> 0 it degenerates to the deterministic forward"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    bt.manual_seed(3)
+    torch.manual_seed(2)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = L.Conv2dFlipout(8, 32, 3, padding=1)
+            self.c2 = L.Conv2dFlipout(32, 32, 3, stride=2, padding=1)
+            self.fc = L.LinearFlipout(32 * 8 * 8, 10)
+
+        def forward(self, x):
+            x = torch.relu(self.c1(x, return_kl=False))
+            x = torch.relu(self.c2(x, return_kl=False))
+            return self.fc(x.flatten(1), return_kl=False)
+
+    net = Net().to(dev).eval()
+    bt.assign_layer_ids(net)
+    x = torch.randn(6, 8, 16, 16, device=dev)
+    packed = mc.mc_forward_batched(net, x, 7, chunk=3)
+    u = mc.unpack(packed, 6, 10)
+    assert abs(float(u["samples"]) - 7) < 1e-6
+    assert torch.allclose(u["mean_prob"].sum(1), torch.ones(6, device=dev), atol=1e-4)
+    with torch.no_grad():
+        bt.set_sample_index(net, 0)
+        y = net(torch.cat([x, x], 0))
+        assert not torch.allclose(y[:6], y[6:])                      # same weights, different signs
+        for m in (net.c1, net.c2, net.fc):
+            getattr(m, "rho_" + m._wn).data.fill_(-40.0)
+            m.rho_bias.data.fill_(-40.0)
+        bt.set_sample_index(net, 0)
+        y = net(torch.cat([x, x], 0))
+        assert torch.allclose(y[:6], y[6:], atol=1e-5)               # sigma -> 0: no perturbation left
+
+
 def test_graphed_mc_replays_equal_eager_samples():
     """mc.GraphedMC: one captured hipGraph, replayed with the sample index in device memory, must reproduce the eager
     forwards of exactly those sample indices (same kernels, same noise, same accumulation order -> bit-identical)."""
