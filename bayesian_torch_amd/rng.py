@@ -46,9 +46,15 @@ def assign_layer_ids(model, start=1):
 def set_sample_index(model, idx, presample=False):
     """Pin the Monte-Carlo sample index used by the NEXT forward of every variational layer in `model`.
     presample=True additionally samples the weights of all layers for that index in ONE launch (see presample())."""
+    devs = {}
     for m in model.modules():
         if hasattr(m, "_btx_layer_id"):
             m._btx_sample = int(idx)
+            sdev = getattr(m, "_btx_sample_dev", None)  # a live mc.GraphedMC keeps the index on the device: keep it in step
+            if sdev is not None:
+                devs[sdev.data_ptr()] = sdev
+    for sdev in devs.values():
+        sdev.fill_(int(idx) & 0x7FFFFFFF)
     if presample:
         _presample(model, idx)
 

@@ -387,6 +387,9 @@ def test_graphed_mc_replays_equal_eager_samples():
             g.run(s_)
         torch.cuda.synchronize()
         got = g.packed.clone()
+        with torch.no_grad():  # while the graph is alive the layers read the device word: set_sample_index keeps it in step
+            bt.set_sample_index(m, 8)
+            assert torch.equal(m(x).float(), singles[1])
         g.close()
         assert torch.equal(got, eager)
         u = mc.unpack(got, 2, 1000)
