@@ -130,42 +130,76 @@ class GraphedMC:
 
     The parameters must not be re-allocated while the graph is alive (in-place updates are seen by the replays)."""
 
-    def __init__(self, model, x, kl=0.0, warmup=2):
+    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1):
+        """lanes > 1: one replay evaluates `lanes` MC samples, each on its own stream inside the graph (independent noise:
+        the same results as one at a time) — the kernels of one sample fill the GPU while those of another are in their
+        ramp-up / tail; use run_many()."""
         if not x.is_cuda:
             raise ValueError("GraphedMC needs CUDA (ROCm) tensors")
-        self.model, self.x, self.kl = model, x, float(kl)
+        self.model, self.x, self.kl, self.lanes = model, x, float(kl), int(lanes)
         dev = x.device
-        self.sample_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sample_devs = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(self.lanes)]
+        self.sample_dev = self.sample_devs[0]
         self._layers = [m for m in model.modules() if hasattr(m, "_btx_layer_id")]
-        for m in self._layers:
-            m._btx_sample_dev = self.sample_dev
         self.packed = None
+        self._lane_packed = [None] * self.lanes
+        self._streams = [torch.cuda.Stream(dev) for _ in range(self.lanes)] if self.lanes > 1 else []
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(max(1, warmup) + 1):  # 1st pass records the input shapes presample() needs
-                self._one()
+                for k in range(self.lanes):
+                    self._lane(k)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) keep making runtime calls while this
         # thread captures
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self._one()
-        self.packed.zero_()
+            if self.lanes == 1:
+                self._lane(0)
+            else:
+                main = torch.cuda.current_stream(dev)
+                for k, st in enumerate(self._streams):
+                    st.wait_stream(main)
+                    with torch.cuda.stream(st):
+                        self._lane(k)
+                for st in self._streams:
+                    main.wait_stream(st)
+                for k in range(1, self.lanes):  # fold the lanes' statistics into lane 0's buffer
+                    self._lane_packed[0].add_(self._lane_packed[k])
+                    self._lane_packed[k].zero_()
+        for pk in self._lane_packed:
+            pk.zero_()
+        for m in self._layers:
+            m._btx_sample_dev = self.sample_dev
 
-    def _one(self):
+    def _lane(self, k):
+        for m in self._layers:
+            m.__dict__["_btx_sample_dev"] = self.sample_devs[k]
         _rng.presample(self.model, 0)
         logits = self.model(self.x)
         if isinstance(logits, tuple):
             logits = logits[0]
-        if self.packed is None:
+        if self._lane_packed[k] is None:
             self.logits_shape = tuple(logits.shape)
-            self.packed = torch.zeros(packed_numel(*logits.shape), dtype=torch.float32, device=logits.device)
-        accumulate(self.packed, logits, self.kl)
+            self._lane_packed[k] = torch.zeros(packed_numel(*logits.shape), dtype=torch.float32, device=logits.device)
+            if k == 0:
+                self.packed = self._lane_packed[0]
+        accumulate(self._lane_packed[k], logits, self.kl)
 
     def run(self, sample_idx):
+        if self.lanes != 1:
+            raise ValueError("this graph evaluates %d samples per replay: use run_many()" % self.lanes)
         self.sample_dev.fill_(int(sample_idx) & 0x7FFFFFFF)
+        self.graph.replay()
+
+    def run_many(self, sample_indices):
+        """one replay = len(sample_indices) == lanes MC samples"""
+        if len(sample_indices) != self.lanes:
+            raise ValueError("expected %d sample indices" % self.lanes)
+        for w, i in zip(self.sample_devs, sample_indices):
+            w.fill_(int(i) & 0x7FFFFFFF)
         self.graph.replay()
 
     def close(self):

@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/residual as separate torch ops")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every MC sample from Python instead of "
                     "replaying one captured hipGraph per sample")
+    ap.add_argument("--lanes", type=int, default=3, help="MC samples evaluated concurrently (one stream each) inside one "
+                    "hipGraph replay; independent noise, identical results to one at a time")
     ap.add_argument("--no-presample", action="store_true", help="sample the weights per layer launch instead of once per MC sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
@@ -144,19 +146,30 @@ def main():
         # one MC sample (weight sampling + 21 fused contractions + pooling + accumulation) = one hipGraph replay;
         # the sample index is a device word the kernels read when they run (BtxRng.sample_idx_dev)
         try:
-            graphed = mc.GraphedMC(model, x, kl=kl)
+            graphed = mc.GraphedMC(model, x, kl=kl, lanes=max(1, args.lanes))
+            graphed1 = mc.GraphedMC(model, x, kl=kl, lanes=1) if graphed.lanes > 1 else None  # for a ragged last group
         except Exception as e:  # a runtime that cannot capture: measure the eager path rather than nothing
             print("bench: hipGraph capture failed (%s: %s) - falling back to eager launches" % (type(e).__name__, e),
                   file=sys.stderr)
+            graphed = None
             for m_ in model.modules():
                 if hasattr(m_, "_btx_sample_dev"):
                     m_._btx_sample_dev = None
             torch.cuda.synchronize(dev)
     if graphed is not None:
         packed = graphed.packed
+        lanes = graphed.lanes
 
-        def step(s_global):
-            graphed.run(s_global)
+        def run_steps(indices):
+            """MC samples `indices`, `lanes` at a time (one hipGraph replay per group), the ragged rest one by one"""
+            full = len(indices) // lanes * lanes
+            for i in range(0, full, lanes):
+                if lanes == 1:
+                    graphed.run(indices[i])
+                else:
+                    graphed.run_many(indices[i:i + lanes])
+            for i in indices[full:]:
+                graphed1.run(i)
     elif not args.no_graph:
         packed = torch.zeros(mc.packed_numel(args.batch, 1000), dtype=torch.float32, device=dev)
 
@@ -164,6 +177,11 @@ def main():
             bt.set_sample_index(model, s_global, presample=not args.no_presample)
             logits = model(x)
             mc.accumulate(packed, logits, kl)
+
+    if graphed is None:
+        def run_steps(indices):
+            for i in indices:
+                step(i)
 
     def barrier():
         if world > 1:
@@ -173,22 +191,26 @@ def main():
     with torch.no_grad():
         # Initialisation, untimed and in addition to --warmup: the HIP runtime grows an internal pool once after
         # ~500 kernel launches (a single 40-60 ms host stall, measured with --per-step); run past it.
-        for w in range(PREWARM_STEPS):
-            step(20_000_000 + w * world + rank)
-        for w in range(args.warmup):
-            step(10_000_000 + w * world + rank)
+        run_steps([20_000_000 + w * world + rank for w in range(PREWARM_STEPS)])
+        run_steps([10_000_000 + w * world + rank for w in range(args.warmup)])
         if world > 1:
             dist.all_reduce(packed)  # warm the communicator too
         packed.zero_()
+        if graphed is not None and graphed.lanes > 1:
+            graphed1.packed.zero_()
         if not args.no_launch_timing and graphed is None:
             BF.enable_launch_timing(True)
         barrier()
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            ts = time.perf_counter()
-            step(k * world + rank)
-            if args.per_step:
+        if args.per_step:
+            for k in range(args.steps):
+                ts = time.perf_counter()
+                run_steps([k * world + rank])
                 print("step %d: host %.3f ms (launch only, no sync)" % (k, 1e3 * (time.perf_counter() - ts)), file=sys.stderr)
+        else:
+            run_steps([k * world + rank for k in range(args.steps)])
+        if graphed is not None and graphed.lanes > 1:
+            packed.add_(graphed1.packed)  # the ragged rest of the last group
         if world > 1:
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)
         barrier()
@@ -196,6 +218,8 @@ def main():
     stats = packed.clone()
     if graphed is not None:
         graphed.close()
+        if graphed.lanes > 1:
+            graphed1.close()
         if not args.no_launch_timing:
             # Kernel durations for the roofline: HIP events cannot bracket the nodes of a replayed graph, so the same
             # launches are issued once more eagerly, with an event pair around each, right after the timed region.
@@ -266,7 +290,8 @@ def main():
                                    "(seed 0), activations %s, eval-BN/ReLU/residual %s, %s" % (
                                        args.type, args.batch, args.steps, act,
                                        "as torch ops" if args.no_fuse else "folded into the kernel epilogue",
-                                       "eager launches" if graphed is None else "one hipGraph replay per MC sample"),
+                                       "eager launches" if graphed is None else
+                                       "hipGraph replay, %d MC samples in flight (one stream each)" % graphed.lanes),
                        "global_batch": args.batch * world, "parallelism": "mc-sample-shard x%d" % world},
             "image_samples_per_s": args.batch * args.steps * world / elapsed,
             "kl": kl, "kl_rel_err": abs(kl - KL_KNOWN) / KL_KNOWN,

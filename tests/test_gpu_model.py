@@ -387,6 +387,15 @@ def test_graphed_mc_replays_equal_eager_samples():
             g.run(s_)
         torch.cuda.synchronize()
         got = g.packed.clone()
+        g2 = mc.GraphedMC(m, x, kl=0.5, lanes=3)   # three samples in flight per replay, one stream each: same statistics
+        g2.run_many(samples)
+        torch.cuda.synchronize()
+        got3 = g2.packed.clone()
+        g2.close()
+        assert torch.allclose(got3, eager, rtol=1e-6, atol=1e-6)  # same per-sample values, summed in a different order
+        for mod in m.modules():
+            if hasattr(mod, "_btx_layer_id"):
+                mod._btx_sample_dev = g.sample_dev
         with torch.no_grad():  # while the graph is alive the layers read the device word: set_sample_index keeps it in step
             bt.set_sample_index(m, 8)
             assert torch.equal(m(x).float(), singles[1])
