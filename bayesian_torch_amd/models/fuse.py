@@ -94,7 +94,13 @@ def fuse_resnet(model):
             x = pool(self.maxpool, self._stem(x, None, True))
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
             ap = self.avgpool
-            if (x.is_cuda and isinstance(ap, nn.AdaptiveAvgPool2d) and ap.output_size in (1, (1, 1)) and x.shape[1] % 8 == 0
+            # the reference's nn.AvgPool2d(7, stride=1) on a 7x7 map (resnet_large.py:125) and torchvision's
+            # AdaptiveAvgPool2d((1,1)) are both a global average
+            is_global = (isinstance(ap, nn.AdaptiveAvgPool2d) and ap.output_size in (1, (1, 1))) or (
+                isinstance(ap, nn.AvgPool2d) and ap.padding in (0, (0, 0)) and not ap.ceil_mode
+                and ap.divisor_override is None
+                and (ap.kernel_size if isinstance(ap.kernel_size, tuple) else (ap.kernel_size,) * 2) == tuple(x.shape[2:]))
+            if (x.is_cuda and is_global and x.shape[1] % 8 == 0
                     and x.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled()):
                 from .. import functional as BF
                 return self.fc(BF.avgpool_global_hip(x))
