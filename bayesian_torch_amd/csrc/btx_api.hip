@@ -358,11 +358,15 @@ int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, in
   return 0;
 }
 
-// workgroup slots the split-K cost model assumes for 4-wave blocks (two per CU); BTX_SLOTS4 overrides (measurements)
+// Workgroup slots the split-K cost model fills with 4-wave blocks.  512 (two per CU) minimises the latency of a single
+// launch on an otherwise idle GPU (ResNet18 layer3: 63.5 vs 69.8 us); 256 splits K half as often, which wins as soon as
+// several MC samples are in flight (mc.GraphedMC lanes, the bench default: 1.16 -> 1.22 k MC-samples/s) because the
+// partial sums cost HBM traffic and a reduce launch while the other samples fill the idle CUs anyway.  BTX_SLOTS4
+// overrides.
 static long long slots4() {
   static const char* e = getenv("BTX_SLOTS4");
-  static const long long v = e ? atoll(e) : 512;
-  return v > 0 ? v : 512;
+  static const long long v = e ? atoll(e) : 256;
+  return v > 0 ? v : 256;
 }
 
 // tiling plan shared by btx_contract_workspace_bytes and btx_contract_fwd
