@@ -23,9 +23,9 @@ model = bench.build_model("Flipout", dev, torch.bfloat16)
 x = torch.randn(8, 3, 224, 224).to(dev).to(torch.bfloat16)
 t = torch.ones(4, device=dev)
 dist.all_reduce(t)  # communicator + watchdog up before the capture
-g = mc.GraphedMC(model, x, kl=1.0)
-for s in range(6):
-    g.run(s)
+g = mc.GraphedMC(model, x, kl=1.0, lanes=3)  # bench.py's default: three samples in flight per replay
+for s in range(0, 6, 3):
+    g.run_many([s, s + 1, s + 2])
 dist.all_reduce(g.packed)
 dist.barrier()
 torch.cuda.synchronize()
