@@ -145,9 +145,13 @@ def main():
     else:
         # one MC sample (weight sampling + 21 fused contractions + pooling + accumulation) = one hipGraph replay;
         # the sample index is a device word the kernels read when they run (BtxRng.sample_idx_dev)
+        rest_graphs = {}
         try:
             graphed = mc.GraphedMC(model, x, kl=kl, lanes=max(1, args.lanes))
-            graphed1 = mc.GraphedMC(model, x, kl=kl, lanes=1) if graphed.lanes > 1 else None  # for a ragged last group
+            # ragged last groups (steps / warm-up not a multiple of the lane count): one smaller graph per remainder size
+            rest_graphs = {r: mc.GraphedMC(model, x, kl=kl, lanes=r)
+                           for r in sorted({args.steps % graphed.lanes, args.warmup % graphed.lanes,
+                                            PREWARM_STEPS % graphed.lanes, 1 if args.per_step else 0} - {0})}
         except Exception as e:  # a runtime that cannot capture: measure the eager path rather than nothing
             print("bench: hipGraph capture failed (%s: %s) - falling back to eager launches" % (type(e).__name__, e),
                   file=sys.stderr)
@@ -168,8 +172,10 @@ def main():
                     graphed.run(indices[i])
                 else:
                     graphed.run_many(indices[i:i + lanes])
-            for i in indices[full:]:
-                graphed1.run(i)
+            rest = indices[full:]
+            if rest:
+                gr = rest_graphs[len(rest)]
+                gr.run(rest[0]) if gr.lanes == 1 else gr.run_many(rest)
     elif not args.no_graph:
         packed = torch.zeros(mc.packed_numel(args.batch, 1000), dtype=torch.float32, device=dev)
 
@@ -196,8 +202,9 @@ def main():
         if world > 1:
             dist.all_reduce(packed)  # warm the communicator too
         packed.zero_()
-        if graphed is not None and graphed.lanes > 1:
-            graphed1.packed.zero_()
+        if graphed is not None:
+            for gr in rest_graphs.values():
+                gr.packed.zero_()
         if not args.no_launch_timing and graphed is None:
             BF.enable_launch_timing(True)
         barrier()
@@ -209,8 +216,9 @@ def main():
                 print("step %d: host %.3f ms (launch only, no sync)" % (k, 1e3 * (time.perf_counter() - ts)), file=sys.stderr)
         else:
             run_steps([k * world + rank for k in range(args.steps)])
-        if graphed is not None and graphed.lanes > 1:
-            packed.add_(graphed1.packed)  # the ragged rest of the last group
+        if graphed is not None:
+            for gr in rest_graphs.values():
+                packed.add_(gr.packed)  # the ragged rest of the last group
         if world > 1:
             dist.all_reduce(packed, op=dist.ReduceOp.SUM)
         barrier()
@@ -218,8 +226,8 @@ def main():
     stats = packed.clone()
     if graphed is not None:
         graphed.close()
-        if graphed.lanes > 1:
-            graphed1.close()
+        for gr in rest_graphs.values():
+            gr.close()
         if not args.no_launch_timing:
             # Kernel durations for the roofline: HIP events cannot bracket the nodes of a replayed graph, so the same
             # launches are issued once more eagerly, with an event pair around each, right after the timed region.
