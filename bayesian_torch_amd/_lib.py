@@ -9,7 +9,7 @@ _LIB = None
 KIND_REPARAM, KIND_FLIPOUT = 0, 1
 ACT_F32, ACT_BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
-FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16 = 1, 2, 4, 8, 16
+FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER = 1, 2, 4, 8, 16, 32
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
 ABI_VERSION = 2

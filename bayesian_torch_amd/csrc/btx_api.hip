@@ -480,7 +480,7 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   pt->NI = (pieces + pt->nw - 1) / pt->nw;
   if (pt->NI > (pt->mi == 4 ? 16 : PT_MAXNI)) return false;
   pt->astage = pieces * 1024;
-  int lds = 2 * pt->astage + 2 * (pt->astage / 16) + PT_WD * 8192;
+  int lds = 2 * pt->astage + 2 * (pt->astage / 16) + PT_WD * 8192 + 1024;  // + the scratch piece of btx_contract_taps.h
   const int ep = pt->nw * PT_EP_WAVE + 1024;
   if (lds < ep) lds = ep;
   if (lds > ((pt->nw == 4 && pt->mi == 2) ? 81920 : 163840)) return false;
@@ -605,9 +605,10 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   // fast (granule) paths need whole 16-byte granules everywhere; otherwise the element-wise gather path
   const int G = (prec == BTX_PREC_BF16) ? 8 : 4;
   const uintptr_t al = (uintptr_t)x | (uintptr_t)mu_w | (uintptr_t)rho_w | (uintptr_t)out |
-                       (uintptr_t)(noise && noise->eps_w ? noise->eps_w : nullptr) |
-                       (uintptr_t)(noise && noise->sign_in ? noise->sign_in : nullptr);
-  const bool explicit_kloop = noise && (noise->eps_w || noise->sign_in);  // parity mode runs the gather kernel
+                       (uintptr_t)(noise && noise->eps_w ? noise->eps_w : nullptr);
+  // Explicit noise (parity mode) runs on the same kernels as generated noise: eps_w enters the sampling pre-pass, the
+  // sign words are packed from sign_in / sign_out.  BTX_FLAG_GATHER forces the element-wise gather kernel (tests).
+  const bool explicit_kloop = (flags & BTX_FLAG_GATHER) != 0;
   const bool gen = (pl.Cg % G != 0) || (al & 15) || explicit_kloop;
   // LDS-DMA pipeline when the activations already have the contraction dtype (no conversion on the way to LDS);
   // BTX_NO_DMA=1 forces the register-staged kernel (A/B measurements).
@@ -618,7 +619,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     // one K-stage = one kernel row: the K walk sees KW*C "channels" per tap and a single tap per row
     const int esz = (act_dtype == BTX_ACT_BF16) ? 2 : 4;
     const int bk = NG * G;
-    const bool ok = !(al & 15) && !explicit_kloop && !no_dma && (prec == BTX_PREC_BF16) == (act_dtype == BTX_ACT_BF16) &&
+    const bool ok = !(al & 15) && !explicit_kloop && !(noise && noise->sign_in) && !no_dma && (prec == BTX_PREC_BF16) == (act_dtype == BTX_ACT_BF16) &&
                     g->groups == 1 && g->dw == 1 && g->pw == 0 && !(flags & BTX_FLAG_TRANSPOSED) &&
                     ((g->KW * g->C) % bk == 0) && ((g->sw * g->C * esz) % 16 == 0) && ((g->W * g->C * esz) % 16 == 0) &&
                     (g->C % G == 0 || G % g->C == 0);
@@ -739,6 +740,8 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.fd_ptWp = make_fastdiv((uint32_t)pt.Wp); p.fd_ptRp = make_fastdiv((uint32_t)pt.Rp); p.fd_ptR = make_fastdiv((uint32_t)pt.R);
     p.fd_rtiles = make_fastdiv((uint32_t)pt.rtiles);
     p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_mi = pt.mi; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
+    const bool no_taps = getenv("BTX_NO_TAPS") != nullptr;  // A/B: the run-time-tap patch kernel instead (read per call)
+    p.pt_taps = (!no_taps && pt.nw == 4 && pt.mi == 2 && pt.NI <= 6 && g->KH == 3 && g->KW == 3) ? 33 : 0;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg, st)
                                  : launch_contract_patch_f32(kind, p, pl.nwg, st);
   } else if (dma)

@@ -122,6 +122,7 @@ struct ContractParams {
   void* trace;  // BTX_PT_TRACE builds: per-wave phase timings (measurement only)
   int pt_nw, pt_astage, pt_lds;
   int pt_mi;      // patch variant: 32-pixel MFMA tiles per wave (2 | 4)
+  int pt_taps;    // 10*KH + KW when the tap-unrolled kernel (btx_contract_taps.h) takes the launch, else 0
   int st_sbytes;  // stem variant: bytes of the s_in word array in LDS  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off
   uint32_t wt_bytes, wt_delta_off;
@@ -238,6 +239,19 @@ __device__ __forceinline__ void apply_epilogue4(float* v, const ContractParams& 
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
   }
+}
+
+// The 32-sign word of elements [32*(off>>5), +32) built from an explicit +1/-1 tensor (BtxNoise.sign_in, parity mode) in
+// the bit order of btx_sign_word(); elements at or beyond `n` count as +1.  Slow on purpose (32 byte loads): tests only.
+__device__ __forceinline__ uint32_t sign_word_explicit(const int8_t* __restrict__ s, uint32_t off, uint32_t n) {
+  const uint32_t base = off & ~31u;
+  uint32_t w = 0;
+#pragma unroll 1
+  for (uint32_t e = 0; e < 32; ++e) {
+    const uint32_t i = base + e;
+    if (i < n && s[i] < 0) w |= 1u << btx_sign_bitpos(e);
+  }
+  return w;
 }
 
 // position of granule-local element e in the pre-shifted sign word (see btx_rng.h)

@@ -257,9 +257,11 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
       }
       // sign layout: element pair e>>1 sits at bit 15-(e>>1) (even e) / 31-(e>>1) (odd e) of its word, so a stage that
       // starts at element offset e0 inside the word needs the word shifted left by e0>>1 within each 16-bit half
-      uint32_t w = btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
+      const uint32_t n_in = p.x_bytes / (uint32_t)sizeof(ACT);
+      uint32_t w = p.sign_in ? sign_word_explicit(p.sign_in, off, n_in) : btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
       if (p.sign_unaligned) {  // uniform: the stage may run into the next word (row-fused stems)
-        const uint32_t w1 = btx_sign_word((off >> 5) + 1u, rl.kin_a, rl.kin_b);
+        const uint32_t w1 = p.sign_in ? sign_word_explicit(p.sign_in, off + 32u, n_in)
+                                      : btx_sign_word((off >> 5) + 1u, rl.kin_a, rl.kin_b);
         const uint32_t k = (off & 31u) >> 1;
         const uint32_t lo = ((w & 0xffffu) << 16) | (w1 & 0xffffu);
         const uint32_t hi = (w & 0xffff0000u) | (w1 >> 16);

@@ -13,7 +13,8 @@
 //     conflict-free for ANY window of 16 consecutive patch pixels, so shifted windows cost nothing;
 //   * s_in is hashed once per patch pixel per channel block (not once per tap), bounds are checked once per patch
 //     pixel per workgroup;
-//   * weights: unchanged (raw f32 (mu,rho) quads by DMA, sampled by the fetching wave, bf16/f32 tile in LDS).
+//   * weights: MFMA-ready tiles sampled once per launch / per MC sample (btx_presample.h), fetched by LDS-DMA into a
+//     four-slot ring three stages ahead.
 //
 // K order is (channel block, tap) instead of (tap, channel block); the element index k = tap*Cg + c used for the
 // weights and for BTX-RNG is the same, so the noise — and up to summation order the result — is identical to the
@@ -25,6 +26,7 @@
 #include "btx_epilogue.h"
 #include "btx_presample.h"
 #include "btx_mma.h"
+#include "btx_contract_taps.h"
 
 namespace btx {
 
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_ker
       for (int j = 0; j < SJ; ++j) {
         if (sg_ok[j]) {
           const uint32_t off = sg_off[j] + (uint32_t)((cb_begin + cbi) * BK);
-          uint32_t w = btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
+          uint32_t w = p.sign_in ? sign_word_explicit(p.sign_in, off, p.x_bytes / (uint32_t)esz)
+                                 : btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
           if constexpr (G == 4) w <<= 8 * ((off >> 4) & 1);
           *(uint32_t*)(ss + (tid + NT * j) * 4) = w;
         }
@@ -362,6 +365,22 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
   } while (0)
   int rc = launch_presample_impl<PREC>(kind, p, st);
   if (rc) return rc;
+  if (p.pt_taps == 33) {  // 3x3, 4-wave blocks: the tap-unrolled kernel (btx_contract_taps.h)
+#define BTX_LAUNCH_TP(KIND)                                                                                        \
+  do {                                                                                                            \
+    auto kfn = contract_taps_kernel<PREC, KIND, 3, 3>;                                                              \
+    static bool attr_done = false;                                                                                \
+    if (!attr_done) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);   \
+      if (e != hipSuccess) return (int)e;                                                                         \
+      attr_done = true;                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), p.pt_lds, st, p);                                               \
+  } while (0)
+    if (kind == 0) BTX_LAUNCH_TP(0); else BTX_LAUNCH_TP(1);
+#undef BTX_LAUNCH_TP
+    return (int)hipGetLastError();
+  }
   if (p.pt_mi == 4) { if (kind == 0) BTX_LAUNCH_PT(0, 4, 4); else BTX_LAUNCH_PT(1, 4, 4); }
   else if (p.pt_nw == 4) { if (kind == 0) BTX_LAUNCH_PT(0, 4, 2); else BTX_LAUNCH_PT(1, 4, 2); }
   else { if (kind == 0) BTX_LAUNCH_PT(0, 8, 2); else BTX_LAUNCH_PT(1, 8, 2); }

@@ -1,0 +1,330 @@
+// btx_contract_taps.h — tap-unrolled form of the patch kernel (btx_contract_patch.h) for stride-1 2-D convolutions whose
+// filter size is a compile-time constant (3x3: 13 of the 20 ResNet18 convolutions, 16 of the 53 ResNet50 ones).
+//
+// Same data structures as contract_patch_kernel (halo'd input patch of the tile in a two-slot LDS ring, pre-sampled
+// weight tiles in a four-slot ring, sign words per patch pixel, staged epilogue), same K order, same noise indices —
+// bit-identical results.  What changes is the instruction stream of the K loop.  Round-1 counters on the ResNet18 layer1
+// shape: 235 instructions per wave per K-stage for 16 MFMAs (~100 SALU: run-time tap/block bookkeeping, the vmcnt
+// decision tree, DMA schedule loops; ~100 VALU of which 48 are the s_in masks), the stage was ISSUE-bound (the kernel
+// without its MFMAs ran at 78 % of the time of the full kernel).  Here the taps of a channel block are unrolled:
+//
+//   * every per-stage decision is a compile-time constant: which tap, which patch/sign slot, which pieces of the next
+//     block's patch this stage fetches, how many VMEM operations may stay in flight at its end (`s_waitcnt vmcnt(n)`
+//     with an immediate) — the stage body has no branch except the wave-uniform "last block of the tile" test;
+//   * the DMA schedule is the same in every block: a patch piece that does not exist for this tile is fetched (as
+//     zeros, the descriptor's out-of-range rule) into a 1-KiB scratch area instead of being skipped, so the counts stay
+//     static;
+//   * weight-tile DMAs take their stage offset in the scalar offset operand: no VALU, no per-stage 64-bit address math;
+//   * the MC sample word (BtxRng.sample_idx_dev) is requested first and the sign keys are derived AFTER the first DMAs
+//     are in flight (contract_patch_kernel: a dependent scalar load + two Philox calls in front of everything).
+#pragma once
+#include <type_traits>
+#include "btx_contract.h"
+#include "btx_contract_dma.h"
+#include "btx_epilogue.h"
+#include "btx_mma.h"
+
+namespace btx {
+
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff,
+                                       unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
+                                           0, 0);
+}
+
+// end of a K-stage: at most N of this wave's VMEM operations stay in flight, its LDS reads are back, all waves meet
+template <int N>
+__device__ __forceinline__ void end_stage() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int TP_SCRATCH = 1024;  // LDS scratch behind the rings: destination of the pieces a tile does not have
+
+template <int PREC, int KIND, int KH, int KW>
+__global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractParams p) {
+  constexpr int NW = 4, NT = 256, MI = 2, T = KH * KW;
+  static_assert(T >= 5 && T <= 32, "tap-unrolled kernel: 5..32 taps");
+  constexpr int MAXNI = 6;  // 1-KiB patch pieces per wave: the 4-wave plan caps the patch at 22 pieces (btx_api.hip)
+  constexpr int PST = T - 3;                      // stages 0..T-4 of a block carry the next block's patch pieces
+  constexpr int PPS = (MAXNI + PST - 1) / PST;    // pieces per such stage
+  constexpr int WOPS = (KIND == 1) ? 2 : 1;       // weight DMA instructions per wave per stage
+  using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
+  constexpr int G = (PREC == 1) ? 8 : 4;
+  constexpr int BK = NG * G;
+  constexpr int ESZ = (int)sizeof(ACT);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  // the MC sample word first: its latency hides behind the index arithmetic and the first DMA issues
+  uint32_t smp = p.sample;
+  if (p.sample_ptr) smp = *p.sample_ptr;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+#ifdef BTX_PT_TRACE
+  const uint32_t tr_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+  uint32_t tr_t1 = 0, tr_t2 = 0;
+#endif
+  int logical;
+  {
+    const int nwg = gridDim.x, L = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
+  fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
+  fdivmod(u_rem, p.fd_ksplits, (uint32_t)p.ksplits, u_t, u_split);
+  fdivmod(u_t, p.fd_ntiles, (uint32_t)p.ntiles, u_group, u_ntile);
+  const int mtile = (int)u_mtile, split = (int)u_split, ntile = (int)u_ntile, group = (int)u_group;
+
+  uint32_t u_ig, u_rt;
+  fdivmod((uint32_t)mtile, p.fd_rtiles, (uint32_t)p.pt_rtiles, u_ig, u_rt);
+  const int img0 = (int)u_ig * p.pt_G, row0 = (int)u_rt * p.pt_R;
+  const int ncb_total = p.Cg / BK;
+  const int cb_per = p.kper / BK;
+  const int cb0 = split * cb_per;
+  const int ncb = min(ncb_total, cb0 + cb_per) - cb0;
+  const int a_stage = p.pt_astage, s_stage = p.pt_astage >> 4;
+  const int PT_A_OFF = 0, PT_S_OFF = 2 * a_stage, PT_W_OFF = 2 * a_stage + 2 * s_stage;
+  const int PT_X_OFF = PT_W_OFF + PT_WD * DW_STAGE;
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.wt_bytes, 0x00020000);
+
+  // ---- weight loader: wave w fetches row w of the stage's mu tile (+ row w of its delta tile): 1 KiB each.
+  //      byte offset = [tile base + k-granule row of the stage] (scalar) + [row w, lane] (vector, constant)
+  const uint32_t w_voff = (uint32_t)lane * 16u + (uint32_t)wave * 1024u;
+  const uint32_t w_sbase = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u;
+  const uint32_t CgG = (uint32_t)(p.Cg / G);
+  const int w_lds = PT_W_OFF + wave * 1024;
+  int wslot = 0;  // ring slot of the stage being multiplied
+  auto issue_w = [&](uint32_t tap, uint32_t cb, int slot) __attribute__((always_inline)) {
+    const uint32_t soff = w_sbase + (tap * CgG + cb * (uint32_t)NG) * 1024u;
+    unsigned char* ld = smem + w_lds + slot * DW_STAGE;
+    dma16s(wt_rsrc, w_voff, soff, ld);
+    if constexpr (KIND == 1) dma16s(wt_rsrc, w_voff, soff + p.wt_delta_off, ld + 4096);
+  };
+  if (ncb > 0) issue_w(0u, (uint32_t)cb0, 0);
+
+  // ---- patch loader: DMA instruction j of wave w moves patch pixels 16*(w + 4j) + (lane>>2), granule slot lane&3
+  const int g_lane = (lane & 3) ^ ((lane >> 4) & 3);
+  uint32_t pp_boff[MAXNI];
+  uint32_t pmask = 0;  // bit j: piece j of this wave exists
+#pragma unroll
+  for (int j = 0; j < MAXNI; ++j) {
+    const int q = 16 * (wave + NW * j) + (lane >> 2);
+    uint32_t bo = DMA_OOB;
+    if (j < p.pt_NI && q < p.pt_PP) {
+      uint32_t ut, upc, ugi, upr;
+      fdivmod((uint32_t)q, p.fd_ptWp, (uint32_t)p.pt_Wp, ut, upc);
+      fdivmod(ut, p.fd_ptRp, (uint32_t)p.pt_Rp, ugi, upr);
+      const int pc = (int)upc, pr = (int)upr, gi = (int)ugi;
+      const int img = img0 + gi, ih = row0 + pr - p.ph, iw = pc - p.pw;
+      if (img < p.NB && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+        bo = ((uint32_t)((img * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) *
+             (uint32_t)ESZ;
+    }
+    pp_boff[j] = bo;
+    if (j < p.pt_NI && 16 * (wave + NW * j) < p.pt_PP) {
+      pmask |= 1u << j;
+      if (ncb > 0)
+        dma16(x_rsrc, bo == DMA_OOB ? DMA_OOB : bo + (uint32_t)(cb0 * BK * ESZ), smem + PT_A_OFF + (wave + NW * j) * 1024);
+    }
+  }
+  pmask = __builtin_amdgcn_readfirstlane(pmask);
+  if (ncb > 0) {  // stages 1 and 2 (taps 1, 2 of the first block): not needed before the first barrier
+    issue_w(1u, (uint32_t)cb0, 1);
+    issue_w(2u, (uint32_t)cb0, 2);
+  }
+
+  // ---- the sign keys of this (sample, layer): needed by the sign words and by the epilogue
+  RngLive rl = {smp, p.kin_a, p.kin_b, p.kout_a, p.kout_b};
+  if (p.sample_ptr) {
+    rl.sample = __builtin_amdgcn_readfirstlane(smp);
+    if constexpr (KIND == 1) {
+      const BtxPhilox4 ki = btx_philox4x32_10(0u, rl.sample, p.layer, 2u, p.seed_lo, p.seed_hi);
+      const BtxPhilox4 ko = btx_philox4x32_10(0u, rl.sample, p.layer, 3u, p.seed_lo, p.seed_hi);
+      rl.kin_a = __builtin_amdgcn_readfirstlane(ki.x[0]); rl.kin_b = __builtin_amdgcn_readfirstlane(ki.x[1]);
+      rl.kout_a = __builtin_amdgcn_readfirstlane(ko.x[0]); rl.kout_b = __builtin_amdgcn_readfirstlane(ko.x[1]);
+    }
+  }
+
+  // ---- sign role: thread t owns the words of patch pixels t and t+256 (element offset of channel 0 of the group)
+  uint32_t sg_off[2];
+  bool sg_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = tid + NT * j;
+    sg_ok[j] = q < p.pt_PP;
+    const int qq = sg_ok[j] ? q : 0;
+    uint32_t ut, upc, ugi, upr;
+    fdivmod((uint32_t)qq, p.fd_ptWp, (uint32_t)p.pt_Wp, ut, upc);
+    fdivmod(ut, p.fd_ptRp, (uint32_t)p.pt_Rp, ugi, upr);
+    const int pc = (int)upc, pr = (int)upr, gi = (int)ugi;
+    const int img = img0 + gi, ih = row0 + pr - p.ph, iw = pc - p.pw;
+    sg_off[j] = (uint32_t)((img * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+    if (p.sign_in)  // explicit signs (parity mode) are read from memory: only pixels inside the input exist
+      sg_ok[j] = sg_ok[j] && img < p.NB && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+  }
+  auto write_signs = [&](int slot, int cb) __attribute__((always_inline)) {
+    if constexpr (KIND == 1) {
+      unsigned char* ss = smem + PT_S_OFF + slot * s_stage;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (sg_ok[j]) {
+          const uint32_t off = sg_off[j] + (uint32_t)(cb * BK);
+          uint32_t w;
+          if (p.sign_in) w = sign_word_explicit(p.sign_in, off, p.x_bytes / (uint32_t)ESZ);
+          else w = btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
+          if constexpr (G == 4) w <<= 8 * ((off >> 4) & 1);
+          *(uint32_t*)(ss + (tid + NT * j) * 4) = w;
+        }
+      }
+    }
+  };
+
+  // ---- MFMA role: wave owns output pixels [64*wave, +64) of the tile, flattened (image, row, col)
+  int q0[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int pl = wave * 64 + mi * 32 + l31;
+    uint32_t ut, uc, ugi, ur;
+    fdivmod((uint32_t)pl, p.fd_Wo, (uint32_t)p.Wo, ut, uc);
+    fdivmod(ut, p.fd_ptR, (uint32_t)p.pt_R, ugi, ur);
+    const int c = (int)uc, r = (int)ur, gi = (int)ugi;
+    const bool ok = (gi < p.pt_G) && (img0 + gi < p.NB) && (row0 + r < p.Ho);
+    q0[mi] = ok ? (gi * p.pt_Rp + r) * p.pt_Wp + c : 0;
+  }
+  const int row_step = p.dh * p.pt_Wp;  // patch-pixel offset of tap (kh, kw) = kh*row_step + kw*dw (wave-uniform)
+
+  f32x16 accm[MI][2], accd[MI][2];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
+
+  using Frag = StageFragT<MI>;
+  auto load_frag = [&](Frag& f, int aslot, int toffv, int wsl) __attribute__((always_inline)) {
+    const unsigned char* as = smem + PT_A_OFF + aslot * a_stage;
+    const unsigned char* ss = smem + PT_S_OFF + aslot * s_stage;
+    const unsigned char* ws = smem + PT_W_OFF + wsl * DW_STAGE;
+    int q[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) q[mi] = q0[mi] + toffv;
+#pragma unroll
+    for (int kk = 0; kk < NG / 2; ++kk) {
+      const int row = 2 * kk + h;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) f.a[kk][mi] = *(const u32x4*)(as + q[mi] * 64 + ((row ^ ((q[mi] >> 2) & 3)) * 16));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) f.wm[kk][ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
+    }
+    if constexpr (KIND == 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) f.sw[mi] = *(const uint32_t*)(ss + q[mi] * 4);
+    }
+  };
+
+  if (ncb > 0) {
+    write_signs(0, cb0);
+    // patch of the first block and W(0) landed (W(1), W(2) were issued after them and may still be in flight)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * WOPS) : "memory");
+    Frag fa, fb;
+    load_frag(fa, 0, 0, 0);
+#ifdef BTX_PT_TRACE
+    tr_t1 = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+    // One channel block = T unrolled stages.  PAR = parity of the block = its patch / sign slot; the fragment register
+    // sets alternate per stage, T may be odd, hence two instantiations.  `last` (wave-uniform): no next block to fetch.
+    auto block = [&](auto par_tag, int cbi, bool last) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_tag)::value;
+      static_for<0, T>([&](auto t_tag) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_tag)::value;
+        constexpr int sp = (PAR * T + t) & 1;
+        Frag& cur = sp ? fb : fa;
+        Frag& nxt = sp ? fa : fb;
+        // keep the per-tap LDS addresses out of long-lived registers: without this the compiler precomputes the address
+        // vectors of all T taps outside the block loop (~40 VGPRs) and spills; a reload is a VMEM load, and its
+        // compiler-inserted vmcnt(0) drains the DMA pipeline
+        asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
+        // 1. W(s+3)
+        constexpr int t3 = (t + 3) % T, c3 = (t + 3) / T;
+        if constexpr (c3 == 0) {
+          issue_w((uint32_t)t3, (uint32_t)(cb0 + cbi), (wslot + 3) & 3);
+        } else {
+          if (!last) issue_w((uint32_t)t3, (uint32_t)(cb0 + cbi + 1), (wslot + 3) & 3);
+        }
+        // 2. this stage's share of the next block's patch (+ its sign words at the first stage)
+        constexpr int KP = (t < PST) ? ((t + PST * (PPS - 1) < MAXNI) ? PPS : PPS - 1) : 0;
+        if constexpr (t < PST) {
+          if (!last) {
+            const uint32_t cboff = (uint32_t)((cb0 + cbi + 1) * BK * ESZ);
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+              const int j = t + PST * i;
+              const uint32_t bo = pp_boff[j];
+              unsigned char* dst = ((pmask >> j) & 1u) ? smem + PT_A_OFF + (PAR ^ 1) * a_stage + (wave + NW * j) * 1024
+                                                        : smem + PT_X_OFF;
+              dma16(x_rsrc, bo == DMA_OOB ? DMA_OOB : bo + cboff, dst);
+            }
+            if constexpr (t == 0) write_signs(PAR ^ 1, cb0 + cbi + 1);
+          }
+        }
+        // 3. delta weights of this stage, then the fragments of the next one
+        DeltaFrag df;
+        load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
+        constexpr int t1 = (t + 1) % T, c1 = (t + 1) / T;
+        load_frag(nxt, PAR ^ c1, (t1 / KW) * row_step + (t1 % KW) * p.dw, (wslot + 1) & 3);
+        // 4. multiply
+        stage_mma<PREC, KIND, MI>(cur, df, accm, accd, l31, h);
+        // 5. W(s+2) — and, from stage T-3 on, every piece of the next patch — landed; meet the other waves
+        if (!last) end_stage<WOPS + KP>();
+        else end_stage<(c3 == 0) ? WOPS : 0>();
+        wslot = (wslot + 1) & 3;
+      });
+    };
+    int cbi = 0;
+    for (; cbi + 2 <= ncb; cbi += 2) {
+      block(std::integral_constant<int, 0>{}, cbi, false);
+      block(std::integral_constant<int, 1>{}, cbi + 1, cbi + 2 == ncb);
+    }
+    if (cbi < ncb) block(std::integral_constant<int, 0>{}, cbi, true);
+  }
+#ifdef BTX_PT_TRACE
+  tr_t2 = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+
+  // =================== epilogue (btx_epilogue.h) ============================================================
+  {
+    const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
+    const int nvalid = nimg * nrow * p.Wo;
+    const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
+    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+  }
+#ifdef BTX_PT_TRACE
+  if (p.trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t tr_t3 = (uint32_t)__builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      uint32_t* tr = (uint32_t*)p.trace + (size_t)(blockIdx.x * NW + wave) * 8;
+      tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = 0; tr[3] = 0; tr[4] = tr_t3 - tr_t2; tr[5] = tr_t3 - tr_t0;
+      tr[6] = tr_t0; tr[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+  }
+#endif
+}
+
+}  // namespace btx

@@ -20,7 +20,7 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
                                                unsigned char* __restrict__ wt, uint32_t delta_off, int Ng, int K,
                                                int ntiles, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
                                                uint32_t sample, uint32_t layer, int Cp = 0, int KWp = 0, int src_KW = 0,
-                                               int src_C = 0) {
+                                               int src_C = 0, const float* __restrict__ eps_w = nullptr) {
   constexpr int G = (PREC == 1) ? 8 : 4;
   // t enumerates the OUTPUT image linearly — (tile, k-granule, channel, quad of the granule), quad fastest — so a wave
   // writes 512 (bf16) / 1024 (f32) contiguous bytes; its reads are 32-byte (bf16) / 16-byte runs, one per channel
@@ -53,7 +53,12 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
       }
     }
     float eps[4];
-    btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
+    if (eps_w) {  // BtxNoise.eps_w (parity mode): same [N][K] layout as mu
+      const f32x4 e4 = *(const f32x4*)(eps_w + e0);
+      eps[0] = e4[0]; eps[1] = e4[1]; eps[2] = e4[2]; eps[3] = e4[3];
+    } else {
+      btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float sg = btx_softplus_hw(rho4[e]);
@@ -78,10 +83,12 @@ __global__ __launch_bounds__(256) void presample_kernel(const float* __restrict_
                                                         unsigned char* __restrict__ wt, uint32_t delta_off, int Ng,
                                                         int K, int ntiles, uint32_t nquads_total, uint32_t seed_lo,
                                                         uint32_t seed_hi, uint32_t sample, uint32_t layer,
-                                                        const uint32_t* __restrict__ sample_ptr) {
+                                                        const uint32_t* __restrict__ sample_ptr,
+                                                        const float* __restrict__ eps_w) {
   if (sample_ptr) sample = __builtin_amdgcn_readfirstlane(*sample_ptr);
   for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < nquads_total; t += gridDim.x * 256u)
-    presample_quad<PREC>(KIND, mu, rho, wt, delta_off, Ng, K, ntiles, t, seed_lo, seed_hi, sample, layer);
+    presample_quad<PREC>(KIND, mu, rho, wt, delta_off, Ng, K, ntiles, t, seed_lo, seed_hi, sample, layer, 0, 0, 0, 0,
+                         eps_w);
 }
 
 // Batched form (btx_sample_weights): the weights of up to PRESAMPLE_MAX_ITEMS layers in ONE launch — a model's
@@ -122,10 +129,10 @@ static int launch_presample_impl(int kind, const ContractParams& p, hipStream_t 
   if (blocks > 4096u) blocks = 4096u;
   if (kind == 0)
     hipLaunchKernelGGL((presample_kernel<PREC, 0>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
-                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer, p.sample_ptr);
+                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer, p.sample_ptr, p.eps_w);
   else
     hipLaunchKernelGGL((presample_kernel<PREC, 1>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
-                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer, p.sample_ptr);
+                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer, p.sample_ptr, p.eps_w);
   return (int)hipGetLastError();
 }
 

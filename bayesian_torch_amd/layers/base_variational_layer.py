@@ -3,8 +3,8 @@
 API mirror of reference `layers/base_variational_layer.py:35-68` (get_kernel_size, dnn_to_bnn_flag, kl_div) plus
 `_VariationalNd`, the one implementation behind the 14 public classes (Linear / Conv{1,2,3}d / ConvTranspose{1,2,3}d
 x Reparameterization / Flipout).  On a CUDA tensor `forward` is ONE call into libbtx.so (fused sampling +
-implicit-GEMM contraction) and `kl_loss` is the HIP KL reduction, cached per parameter version; on a CPU tensor it
-is the ATen op chain of the cited reference method with the reference's torch-generator draw order.
+implicit-GEMM contraction) and `kl_loss` is the HIP KL reduction (recomputed on every call: RNG-free, 8 B/element);
+on a CPU tensor it is the ATen op chain of the cited reference method with the reference's torch-generator draw order.
 """
 import collections
 import warnings
@@ -251,7 +251,7 @@ class _VariationalNd(BaseVariationalLayer_):
             return pre[1]
         return None
 
-    def _forward_hip(self, x, noise=None, sample_idx=None, epilogue=None):
+    def _forward_hip(self, x, noise=None, sample_idx=None, epilogue=None, gather=False):
         mu, rho = self._w()
         mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
         if sample_idx is None:
@@ -291,7 +291,8 @@ class _VariationalNd(BaseVariationalLayer_):
             pre = self._take_presampled(sample_idx, self.precision or BF.get_precision(), tag)
         return BF.contract_hip(kind, x, mu_p, rho_p, mb, rb, op, _rng.seed(), sample_idx,
                                self._btx_layer_id, prec=self.precision, noise=noise, epilogue=epilogue, sampled_w=pre,
-                               sample_dev=getattr(self, "_btx_sample_dev", None))
+                               sample_dev=getattr(self, "_btx_sample_dev", None),
+                               extra_flags=_lib.FLAG_GATHER if gather else 0)
 
     def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False):
         """`relu?(forward(x) * scale[c] + shift[c] (+ residual))` with the affine / residual / ReLU

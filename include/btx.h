@@ -67,6 +67,9 @@ extern "C" {
                                      returns BTX_E_UNSUPPORTED otherwise. */
 #define BTX_FLAG_OUT_F32      8u  /* store the output as f32 / bf16 regardless of act_dtype (LDS-DMA kernels only: lets */
 #define BTX_FLAG_OUT_BF16    16u  /* a caller that had to copy the input anyway keep "f32 in/out, bf16 MFMA" semantics) */
+#define BTX_FLAG_GATHER      32u  /* force the element-wise gather kernel (any shape / alignment; samples in registers).
+                                     The library picks it by itself whenever a fast kernel does not apply; the flag
+                                     exists so tests can exercise it on shapes the fast kernels would take. */
 
 /* RNG streams of BTX-RNG v1 */
 #define BTX_STREAM_EPS_W    0u

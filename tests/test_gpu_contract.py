@@ -43,24 +43,27 @@ def _noise_from(d, dev):
     return nz
 
 
+@pytest.mark.parametrize("gather", [False, True])
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_explicit_noise_vs_reference_outputs(golden, prec):
-    """the reference's own noise + parameters + inputs -> must reproduce the reference's own outputs"""
+def test_explicit_noise_vs_reference_outputs(golden, prec, gather):
+    """the reference's own noise + parameters + inputs -> must reproduce the reference's own outputs.
+    gather=False: the kernel the library picks for the shape (tap-unrolled patch / patch / LDS-DMA / register-staged /
+    gather); gather=True: the element-wise gather kernel on every shape (BTX_FLAG_GATHER)."""
     dev = _dev()
     for name, (meta, d) in golden["cases"].items():
         layer = _layer_from_meta(meta, dev)
         layer.precision = prec
         x = torch.from_numpy(d["x"]).to(dev)
         with torch.no_grad():
-            out = layer._forward_hip(x, noise=_noise_from(d, dev), sample_idx=0).float().cpu().numpy()
+            out = layer._forward_hip(x, noise=_noise_from(d, dev), sample_idx=0, gather=gather).float().cpu().numpy()
         assert out.shape == d["out"].shape, name
         err = rel_l2(out, d["out"])
-        assert err < (TOL_F32 if prec == "f32" else TOL_BF16_REF), (name, prec, err)
+        assert err < (TOL_F32 if prec == "f32" else TOL_BF16_REF), (name, prec, gather, err)
         if prec == "bf16":
             geo = case_geometry(meta)
             ob = oracle_forward(geo, d["x"], d["mu_w"], d["rho_w"], d.get("mu_b"), d.get("rho_b"), d["eps_w"],
                                 d.get("eps_b"), d.get("sign_in"), d.get("sign_out"), bf16=True)
-            assert rel_l2(out, ob) < TOL_BF16_ORACLE, (name, rel_l2(out, ob))
+            assert rel_l2(out, ob) < TOL_BF16_ORACLE, (name, gather, rel_l2(out, ob))
 
 
 # (class, kwargs, x shape) — channel counts that take the FAST granule kernels (C/groups % 8 == 0)

@@ -68,6 +68,16 @@ CASES = [
      dict(in_channels=6, out_channels=10, kernel_size=3, stride=3, padding=0), (2, 6, 9)),
     ("convT3d_reparam", "ConvTranspose3dReparameterization",
      dict(in_channels=4, out_channels=4, kernel_size=2, stride=2, padding=0), (1, 4, 3, 3, 3)),
+    # round 2: shapes the FAST kernels take (C/groups % 32 == 0), so the reference's own noise reaches the tap-unrolled
+    # patch kernel, the run-time-tap patch kernel and the LDS-DMA kernel (explicit eps_w / sign_in / sign_out)
+    ("conv2d_reparam_c32_3x3", "Conv2dReparameterization",
+     dict(in_channels=32, out_channels=64, kernel_size=3, stride=1, padding=1), (2, 32, 10, 10)),
+    ("conv2d_flipout_c32_3x3_s2", "Conv2dFlipout",
+     dict(in_channels=32, out_channels=32, kernel_size=3, stride=2, padding=1), (2, 32, 11, 11)),
+    ("conv2d_flipout_c32_5x5", "Conv2dFlipout",
+     dict(in_channels=32, out_channels=32, kernel_size=5, stride=1, padding=2, bias=False), (1, 32, 8, 8)),
+    ("conv2d_flipout_c64_3x3_multi", "Conv2dFlipout",
+     dict(in_channels=64, out_channels=96, kernel_size=3, stride=1, padding=1), (3, 64, 13, 9)),
 ]
 
 
