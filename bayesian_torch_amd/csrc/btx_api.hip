@@ -747,9 +747,13 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   } else if (dma)
     rc = (prec == BTX_PREC_BF16) ? launch_contract_dma_bf16(kind, p, pl.nwg, st)
                                  : launch_contract_dma_f32(kind, p, pl.nwg, st);
-  else
-    rc = (prec == BTX_PREC_BF16) ? launch_contract_bf16(kind, act_dtype == BTX_ACT_BF16, gen, p, pl.nwg, st)
-                                 : launch_contract_f32(kind, act_dtype == BTX_ACT_BF16, gen, p, pl.nwg, st);
+  else {
+    // the register-staged fast kernel samples in registers and hashes its own s_in: explicit eps_w / sign_in need either
+    // the LDS-DMA family above (pre-pass sampling, packed sign words) or the gather kernel
+    const bool gen2 = gen || (noise && (noise->eps_w || noise->sign_in));
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_bf16(kind, act_dtype == BTX_ACT_BF16, gen2, p, pl.nwg, st)
+                                 : launch_contract_f32(kind, act_dtype == BTX_ACT_BF16, gen2, p, pl.nwg, st);
+  }
   if (rc) return rc;
   if (pl.ksplits > 1) {
     const long long total = (long long)pl.M * g->N;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractPar
     }
   }
   pmask = __builtin_amdgcn_readfirstlane(pmask);
-  if (ncb > 0) {  // stages 1 and 2 (taps 1, 2 of the first block): not needed before the first barrier
+  if (ncb > 0) {  // stages 1 and 2 (taps 1, 2 of the first block); W(2) is not needed before the second barrier
     issue_w(1u, (uint32_t)cb0, 1);
     issue_w(2u, (uint32_t)cb0, 2);
   }
@@ -240,8 +240,9 @@ __global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractPar
 
   if (ncb > 0) {
     write_signs(0, cb0);
-    // patch of the first block and W(0) landed (W(1), W(2) were issued after them and may still be in flight)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * WOPS) : "memory");
+    // patch of the first block, W(0) and W(1) landed — iteration 0 reads the fragments of stage 1; W(2), issued last,
+    // may still be in flight
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(WOPS) : "memory");
     Frag fa, fb;
     load_frag(fa, 0, 0, 0);
 #ifdef BTX_PT_TRACE
