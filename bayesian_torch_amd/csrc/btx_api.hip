@@ -429,6 +429,7 @@ static bool dma_shape_ok(const BtxGeom* g, int act_dtype, int prec, const Plan& 
 // activations already have the contraction dtype.  Returns false when the shape is not eligible.
 struct PatchPlan {
   int G, R, Rp, Wp, PP, NI, rtiles, nw, mi, astage, lds;
+  int taps, kg, lds_g;  // tap-unrolled kernel (btx_contract_taps.h): 10*KH+KW or 0; K-groups per workgroup; LDS per group
 };
 // tile of `tp` output pixels whose patch holds at most `ppcap` pixels
 static bool patch_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, PatchPlan* pt) {
@@ -485,29 +486,39 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   if (lds < ep) lds = ep;
   if (lds > ((pt->nw == 4 && pt->mi == 2) ? 81920 : 163840)) return false;
   pt->lds = lds;
+  pt->lds_g = (lds + 15) & ~15;
   // grid: m-tiles are (image group, row tile); split-K over the channel blocks
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   const int ncb = pl->Cg / bk;
   pl->mtiles = ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
   const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
+  const bool no_taps = getenv("BTX_NO_TAPS") != nullptr;  // A/B: the run-time-tap patch kernel instead (read per call)
+  pt->taps = (!no_taps && pt->nw == 4 && pt->mi == 2 && pt->NI <= 6 && g->KH == 3 && g->KW == 3) ? 33 : 0;
+  // Few pixel tiles (at most one 4-wave block per CU): 8-wave blocks of two K-groups — split-K inside the workgroup
+  // through LDS instead of through HBM, and two waves per SIMD.  BTX_NO_KG=1 disables (A/B).
+  const bool no_kg = getenv("BTX_NO_KG") != nullptr;
+  pt->kg = (pt->taps && !no_kg && base <= 256 && ncb >= 2 && (ncb % 2) == 0 && 2 * pt->lds_g <= 163840) ? 2 : 1;
+  const int units = ncb / pt->kg;  // channel blocks per K-group over the whole K
   int ks = 1;
   {
-    const long long slots = (pt->nw == 4 && pt->mi == 2) ? slots4() : 256;
+    const long long slots = (pt->kg == 2) ? 256 : ((pt->nw == 4 && pt->mi == 2) ? slots4() : 256);
     long long best = -1;
-    for (int c = 1; c <= ncb && c <= 32; ++c) {
-      const int per = (ncb + c - 1) / c;
+    for (int c = 1; c <= units && c <= 32; ++c) {
+      const int per = (units + c - 1) / c;
       if (c > 1 && per * T < 4) break;
+      if (pt->kg == 2 && units % c) continue;  // the 8-wave kernel wants every split full
       const long long rounds = (base * c + slots - 1) / slots;
       const long long cost = rounds * (per * T + 4) + (c > 1 ? 1 : 0);
       if (best < 0 || cost < best) { best = cost; ks = c; }
     }
   }
-  const int per = (ncb + ks - 1) / ks;
-  pl->kper = per * bk;
-  pl->ksplits = (ncb + per - 1) / per;
+  const int per = (units + ks - 1) / ks;
+  pl->kper = per * pt->kg * bk;
+  pl->ksplits = (units + per - 1) / per;
   const long long nwg = base * pl->ksplits;
   if (nwg > 0x7fffffffLL) return false;
   pl->nwg = (int)nwg;
+  if (pt->kg == 2) pt->lds = 2 * pt->lds_g;
   return true;
 }
 
@@ -740,8 +751,8 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.fd_ptWp = make_fastdiv((uint32_t)pt.Wp); p.fd_ptRp = make_fastdiv((uint32_t)pt.Rp); p.fd_ptR = make_fastdiv((uint32_t)pt.R);
     p.fd_rtiles = make_fastdiv((uint32_t)pt.rtiles);
     p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_mi = pt.mi; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
-    const bool no_taps = getenv("BTX_NO_TAPS") != nullptr;  // A/B: the run-time-tap patch kernel instead (read per call)
-    p.pt_taps = (!no_taps && pt.nw == 4 && pt.mi == 2 && pt.NI <= 6 && g->KH == 3 && g->KW == 3) ? 33 : 0;
+    { const char* tn = getenv("BTX_TAPS_TUNE"); p.pt_tune = tn ? atoi(tn) : 0; }
+    p.pt_taps = pt.taps; p.pt_kg = pt.kg; p.pt_lds_g = pt.lds_g;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg, st)
                                  : launch_contract_patch_f32(kind, p, pl.nwg, st);
   } else if (dma)

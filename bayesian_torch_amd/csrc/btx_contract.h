@@ -122,6 +122,9 @@ struct ContractParams {
   void* trace;  // BTX_PT_TRACE builds: per-wave phase timings (measurement only)
   int pt_nw, pt_astage, pt_lds;
   int pt_mi;      // patch variant: 32-pixel MFMA tiles per wave (2 | 4)
+  int pt_tune;    // BTX_PT_TRACE builds: bit 6 = report the per-stage split instead of the phase timers
+  int pt_kg;      // tap-unrolled kernel: K-groups per workgroup (1 | 2)
+  int pt_lds_g;   //                      LDS bytes of one K-group
   int pt_taps;    // 10*KH + KW when the tap-unrolled kernel (btx_contract_taps.h) takes the launch, else 0
   int st_sbytes;  // stem variant: bytes of the s_in word array in LDS  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off

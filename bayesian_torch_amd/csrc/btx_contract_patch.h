@@ -365,19 +365,20 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
   } while (0)
   int rc = launch_presample_impl<PREC>(kind, p, st);
   if (rc) return rc;
-  if (p.pt_taps == 33) {  // 3x3, 4-wave blocks: the tap-unrolled kernel (btx_contract_taps.h)
-#define BTX_LAUNCH_TP(KIND)                                                                                        \
+  if (p.pt_taps == 33) {  // 3x3, 4-wave K-groups: the tap-unrolled kernel (btx_contract_taps.h)
+#define BTX_LAUNCH_TP(KIND, KG)                                                                                    \
   do {                                                                                                            \
-    auto kfn = contract_taps_kernel<PREC, KIND, 3, 3>;                                                              \
+    auto kfn = contract_taps_kernel<PREC, KIND, 3, 3, KG>;                                                          \
     static bool attr_done = false;                                                                                \
     if (!attr_done) {                                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);   \
       if (e != hipSuccess) return (int)e;                                                                         \
       attr_done = true;                                                                                           \
     }                                                                                                             \
-    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), p.pt_lds, st, p);                                               \
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256 * KG), p.pt_lds, st, p);                                          \
   } while (0)
-    if (kind == 0) BTX_LAUNCH_TP(0); else BTX_LAUNCH_TP(1);
+    if (p.pt_kg == 2) { if (kind == 0) BTX_LAUNCH_TP(0, 2); else BTX_LAUNCH_TP(1, 2); }
+    else { if (kind == 0) BTX_LAUNCH_TP(0, 1); else BTX_LAUNCH_TP(1, 1); }
 #undef BTX_LAUNCH_TP
     return (int)hipGetLastError();
   }

@@ -3,10 +3,11 @@
 //
 // Same data structures as contract_patch_kernel (halo'd input patch of the tile in a two-slot LDS ring, pre-sampled
 // weight tiles in a four-slot ring, sign words per patch pixel, staged epilogue), same K order, same noise indices —
-// bit-identical results.  What changes is the instruction stream of the K loop.  Round-1 counters on the ResNet18 layer1
-// shape: 235 instructions per wave per K-stage for 16 MFMAs (~100 SALU: run-time tap/block bookkeeping, the vmcnt
-// decision tree, DMA schedule loops; ~100 VALU of which 48 are the s_in masks), the stage was ISSUE-bound (the kernel
-// without its MFMAs ran at 78 % of the time of the full kernel).  Here the taps of a channel block are unrolled:
+// bit-identical results (KG == 1).  What changes is the instruction stream of the K loop.  Round-1 counters on the
+// ResNet18 layer1 shape: 235 instructions per wave per K-stage for 16 MFMAs (~100 SALU: run-time tap/block bookkeeping,
+// the vmcnt decision tree, DMA schedule loops; ~100 VALU of which 48 are the s_in masks); the stage was ISSUE-bound
+// (the kernel without its MFMAs ran at 78 % of the time of the full kernel).  Here the taps of a channel block are
+// unrolled (~103 instructions per stage: 16 MFMA, 14 LDS, 3 DMA, ~49 VALU, ~6 SALU, the counted waits):
 //
 //   * every per-stage decision is a compile-time constant: which tap, which patch/sign slot, which pieces of the next
 //     block's patch this stage fetches, how many VMEM operations may stay in flight at its end (`s_waitcnt vmcnt(n)`
@@ -17,6 +18,9 @@
 //   * weight-tile DMAs take their stage offset in the scalar offset operand: no VALU, no per-stage 64-bit address math;
 //   * the MC sample word (BtxRng.sample_idx_dev) is requested first and the sign keys are derived AFTER the first DMAs
 //     are in flight (contract_patch_kernel: a dependent scalar load + two Philox calls in front of everything).
+//
+// Measured (tools/gpu_diag.py trace, ResNet18 layer1/2 shapes): 1115-1170 cycles per stage for two co-resident 4-wave
+// blocks (1024 = the matrix pipe's own time) against 1830 before.
 #pragma once
 #include <type_traits>
 #include "btx_contract.h"
@@ -46,35 +50,62 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int TP_SCRATCH = 1024;  // LDS scratch behind the rings: destination of the pieces a tile does not have
+constexpr int TP_MAXNI = 6;  // 1-KiB patch pieces per wave: the 4-wave plan caps the patch at 22 pieces (btx_api.hip)
 
-template <int PREC, int KIND, int KH, int KW>
-__global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractParams p) {
+// pieces of the next block's patch fetched in stage t of a block: stages 0..T-4 share the TP_MAXNI piece slots
+template <int T>
+constexpr int tp_pieces(int t) {
+  constexpr int PST = T - 3;
+  constexpr int PPS = (TP_MAXNI + PST - 1) / PST;
+  if (t < 0) t += T;
+  if (t >= PST) return 0;
+  int n = 0;
+  for (int i = 0; i < PPS; ++i)
+    if (t + PST * i < TP_MAXNI) ++n;
+  return n;
+}
+
+// KG = K-groups per workgroup.  KG == 1: 4 waves, two workgroups per CU (free-running against each other: one block's
+// load/issue phases fall beside the other's MFMAs — 93 % of the matrix pipe while both are in their K loops).
+// KG == 2 (layers with few pixel tiles, 14x14 and 7x7 maps: at most one 4-wave block per CU, whose single wave per
+// SIMD keeps the matrix pipe 57 % busy): 8 waves, one workgroup per CU; the two groups of 4 waves contract the two
+// halves of the workgroup's channel blocks on the SAME output tile, each with its own patch / sign / weight rings in its
+// own half of the LDS, and meet at the end: group 1 hands its accumulator registers over through LDS, group 0 stores
+// the tile.  Split-K without partial sums in HBM and without a reduce launch.  The two groups share every s_barrier,
+// and eight waves marching in lock-step issue their loads together and then queue for the matrix pipe together
+// (measured: 1800 cycles per stage), so a K-group's stage is two halves — H1: DMA issue + the LDS reads of THIS stage's
+// fragments, H2: the MFMAs — with a barrier after each, and group 1 runs half a stage behind group 0 (one extra barrier
+// before its first stage, group 0 one after its last): one group's MFMA half sits beside the other's load half.
+template <int PREC, int KIND, int KH, int KW, int KG>
+__global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const ContractParams p) {
   constexpr int NW = 4, NT = 256, MI = 2, T = KH * KW;
   static_assert(T >= 5 && T <= 32, "tap-unrolled kernel: 5..32 taps");
-  constexpr int MAXNI = 6;  // 1-KiB patch pieces per wave: the 4-wave plan caps the patch at 22 pieces (btx_api.hip)
+  constexpr int MAXNI = TP_MAXNI;
   constexpr int PST = T - 3;                      // stages 0..T-4 of a block carry the next block's patch pieces
-  constexpr int PPS = (MAXNI + PST - 1) / PST;    // pieces per such stage
   constexpr int WOPS = (KIND == 1) ? 2 : 1;       // weight DMA instructions per wave per stage
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
   constexpr int BK = NG * G;
   constexpr int ESZ = (int)sizeof(ACT);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
 
   // the MC sample word first: its latency hides behind the index arithmetic and the first DMA issues
   uint32_t smp = p.sample;
   if (p.sample_ptr) smp = *p.sample_ptr;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;  // thread / wave index inside the K-group
   const int lane = tid & 63;
   const int l31 = lane & 31;
   const int h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = wave_all & 3;
+  const int kg = (KG == 1) ? 0 : (wave_all >> 2);
+  unsigned char* const smem = smem_all + kg * p.pt_lds_g;
 
 #ifdef BTX_PT_TRACE
   const uint32_t tr_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
-  uint32_t tr_t1 = 0, tr_t2 = 0;
+  const uint32_t tr_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // constant 100 MHz reference clock
+  uint32_t tr_t1 = 0, tr_t2 = 0, tr_s[4] = {0, 0, 0, 0};
 #endif
   int logical;
   {
@@ -92,12 +123,12 @@ __global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractPar
   fdivmod((uint32_t)mtile, p.fd_rtiles, (uint32_t)p.pt_rtiles, u_ig, u_rt);
   const int img0 = (int)u_ig * p.pt_G, row0 = (int)u_rt * p.pt_R;
   const int ncb_total = p.Cg / BK;
-  const int cb_per = p.kper / BK;
-  const int cb0 = split * cb_per;
-  const int ncb = min(ncb_total, cb0 + cb_per) - cb0;
+  const int cb_per = p.kper / BK;  // channel blocks of this workgroup (host: a multiple of KG and every split full when KG > 1)
+  const int cb0 = split * cb_per + kg * (cb_per / KG);
+  const int ncb = (KG == 1) ? min(ncb_total, cb0 + cb_per) - cb0 : cb_per / KG;
   const int a_stage = p.pt_astage, s_stage = p.pt_astage >> 4;
   const int PT_A_OFF = 0, PT_S_OFF = 2 * a_stage, PT_W_OFF = 2 * a_stage + 2 * s_stage;
-  const int PT_X_OFF = PT_W_OFF + PT_WD * DW_STAGE;
+  const int PT_X_OFF = PT_W_OFF + PT_WD * DW_STAGE;  // 1-KiB scratch: destination of the pieces a tile does not have
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.wt_bytes, 0x00020000);
@@ -143,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractPar
     }
   }
   pmask = __builtin_amdgcn_readfirstlane(pmask);
-  if (ncb > 0) {  // stages 1 and 2 (taps 1, 2 of the first block); W(2) is not needed before the second barrier
+  if (ncb > 0) {  // stages 1 and 2 (taps 1, 2 of the first block)
     issue_w(1u, (uint32_t)cb0, 1);
     issue_w(2u, (uint32_t)cb0, 2);
   }
@@ -240,23 +271,24 @@ __global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractPar
 
   if (ncb > 0) {
     write_signs(0, cb0);
-    // patch of the first block, W(0) and W(1) landed — iteration 0 reads the fragments of stage 1; W(2), issued last,
-    // may still be in flight
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(WOPS) : "memory");
+    // KG == 1: patch of the first block, W(0) and W(1) landed — iteration 0 prefetches the fragments of stage 1; W(2),
+    // issued last, may still be in flight.  KG == 2: a stage reads its own fragments: W(1) may be in flight as well.
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(KG == 1 ? WOPS : 2 * WOPS) : "memory");
     Frag fa, fb;
-    load_frag(fa, 0, 0, 0);
+    if constexpr (KG == 1) load_frag(fa, 0, 0, 0);
 #ifdef BTX_PT_TRACE
     tr_t1 = (uint32_t)__builtin_amdgcn_s_memtime();
+    uint32_t tr_tA = tr_t1, tr_ab = 0, tr_lg = 0, tr_bc = 0, tr_cd = 0;
 #endif
     // One channel block = T unrolled stages.  PAR = parity of the block = its patch / sign slot; the fragment register
-    // sets alternate per stage, T may be odd, hence two instantiations.  `last` (wave-uniform): no next block to fetch.
+    // sets alternate per stage (KG == 1), T may be odd, hence two instantiations.  `last` (wave-uniform): no next block.
     auto block = [&](auto par_tag, int cbi, bool last) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par_tag)::value;
       static_for<0, T>([&](auto t_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value;
         constexpr int sp = (PAR * T + t) & 1;
-        Frag& cur = sp ? fb : fa;
-        Frag& nxt = sp ? fa : fb;
+        Frag& cur = (KG == 1 && sp) ? fb : fa;
+        Frag& nxt = (KG == 1 && sp) ? fa : fb;
         // keep the per-tap LDS addresses out of long-lived registers: without this the compiler precomputes the address
         // vectors of all T taps outside the block loop (~40 VGPRs) and spills; a reload is a VMEM load, and its
         // compiler-inserted vmcnt(0) drains the DMA pipeline
@@ -269,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractPar
           if (!last) issue_w((uint32_t)t3, (uint32_t)(cb0 + cbi + 1), (wslot + 3) & 3);
         }
         // 2. this stage's share of the next block's patch (+ its sign words at the first stage)
-        constexpr int KP = (t < PST) ? ((t + PST * (PPS - 1) < MAXNI) ? PPS : PPS - 1) : 0;
+        constexpr int KP = tp_pieces<T>(t);
         if constexpr (t < PST) {
           if (!last) {
             const uint32_t cboff = (uint32_t)((cb0 + cbi + 1) * BK * ESZ);
@@ -284,25 +316,65 @@ __global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractPar
             if constexpr (t == 0) write_signs(PAR ^ 1, cb0 + cbi + 1);
           }
         }
-        // 3. delta weights of this stage, then the fragments of the next one
         DeltaFrag df;
-        load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
-        constexpr int t1 = (t + 1) % T, c1 = (t + 1) / T;
-        load_frag(nxt, PAR ^ c1, (t1 / KW) * row_step + (t1 % KW) * p.dw, (wslot + 1) & 3);
-        // 4. multiply
-        stage_mma<PREC, KIND, MI>(cur, df, accm, accd, l31, h);
-        // 5. W(s+2) — and, from stage T-3 on, every piece of the next patch — landed; meet the other waves
-        if (!last) end_stage<WOPS + KP>();
-        else end_stage<(c3 == 0) ? WOPS : 0>();
+        if constexpr (KG == 1) {
+          // 3. delta weights of this stage, then the fragments of the next one
+          load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
+          constexpr int t1 = (t + 1) % T, c1 = (t + 1) / T;
+          load_frag(nxt, PAR ^ c1, (t1 / KW) * row_step + (t1 % KW) * p.dw, (wslot + 1) & 3);
+          // 4. multiply
+          stage_mma<PREC, KIND, MI>(cur, df, accm, accd, l31, h);
+          // 5. W(s+2) — and, from stage T-3 on, every piece of the next patch — landed; meet the other waves
+#ifdef BTX_PT_TRACE
+          {  // split the stage end: issue+MFMA | LDS reads back | VMEM wait | barrier
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t tB = (uint32_t)__builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint32_t tB2 = (uint32_t)__builtin_amdgcn_s_memtime();
+            if (!last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WOPS + KP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((c3 == 0) ? WOPS : 0) : "memory");
+            const uint32_t tC = (uint32_t)__builtin_amdgcn_s_memtime();
+            asm volatile("s_barrier" ::: "memory");
+            const uint32_t tD = (uint32_t)__builtin_amdgcn_s_memtime();
+            tr_ab += tB - tr_tA; tr_lg += tB2 - tB; tr_bc += tC - tB2; tr_cd += tD - tC; tr_tA = tD;
+          }
+#else
+          if (!last) end_stage<WOPS + KP>();
+          else end_stage<(c3 == 0) ? WOPS : 0>();
+#endif
+        } else {
+          // H1: this stage's own fragments (their latency hides behind the other group's MFMA half)
+          load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
+          load_frag(cur, PAR, (t / KW) * row_step + (t % KW) * p.dw, wslot);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_barrier" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          // H2: multiply
+          stage_mma<PREC, KIND, MI>(cur, df, accm, accd, l31, h);
+          __builtin_amdgcn_sched_barrier(0);
+          // W(s+1) — read by the next stage's H1 — and from stage T-1 on the next patch landed: everything issued before
+          // the last two iterations (the pieces of iteration s-2 were issued after its W)
+          if (!last) {
+            end_stage<2 * WOPS + KP + tp_pieces<T>(t - 1) + tp_pieces<T>(t - 2)>();
+          } else {
+            constexpr int a_ = (t + 3 < T) ? 1 : 0, b_ = (t == 0) ? 1 : ((t + 2 < T) ? 1 : 0);
+            end_stage<WOPS * (a_ + b_)>();
+          }
+        }
         wslot = (wslot + 1) & 3;
       });
     };
+    if (KG == 2 && kg == 1) asm volatile("s_barrier" ::: "memory");
     int cbi = 0;
     for (; cbi + 2 <= ncb; cbi += 2) {
       block(std::integral_constant<int, 0>{}, cbi, false);
       block(std::integral_constant<int, 1>{}, cbi + 1, cbi + 2 == ncb);
     }
     if (cbi < ncb) block(std::integral_constant<int, 0>{}, cbi, true);
+    if (KG == 2 && kg == 0) asm volatile("s_barrier" ::: "memory");
+#ifdef BTX_PT_TRACE
+    tr_s[0] = tr_ab; tr_s[1] = tr_lg; tr_s[2] = tr_bc; tr_s[3] = tr_cd;
+#endif
   }
 #ifdef BTX_PT_TRACE
   tr_t2 = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -313,16 +385,69 @@ __global__ __launch_bounds__(256, 2) void contract_taps_kernel(const ContractPar
     const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
     const int nvalid = nimg * nrow * p.Wo;
     const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
-    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    if constexpr (KG == 1) {
+      staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    } else {
+      // Every wave is behind the barrier of its last stage: the whole LDS is free.  Group 1 -> exchange area
+      // [chunk i][thread] x 16 B (a wave writes 1 KiB per instruction; 128 KiB Flipout, 64 KiB Reparameterization),
+      // group 0 adds and runs the store.  The per-channel constants sit behind both the exchange area and the 68-KiB
+      // staging area of the store.
+      float* ba_lds = (float*)(smem_all + 131072);
+      const bool to_partial = p.ksplits > 1;
+      const bool has_bias = (split == 0) && (p.mu_b != nullptr);
+      const bool has_aff = !to_partial && ((p.ep_scale != nullptr) || (p.ep_shift != nullptr));
+      if (kg == 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int i = (mi * 2 + ni) * 4 + c;
+              *(f32x4*)(smem_all + (i * 256 + tid) * 16) =
+                  (f32x4){accm[mi][ni][4 * c], accm[mi][ni][4 * c + 1], accm[mi][ni][4 * c + 2], accm[mi][ni][4 * c + 3]};
+              if constexpr (KIND == 1)
+                *(f32x4*)(smem_all + ((16 + i) * 256 + tid) * 16) =
+                    (f32x4){accd[mi][ni][4 * c], accd[mi][ni][4 * c + 1], accd[mi][ni][4 * c + 2], accd[mi][ni][4 * c + 3]};
+            }
+      } else if (has_bias || has_aff) {
+        ep_fill_constants<KIND>(p, rl, ba_lds, tid, ntile, group, has_bias, has_aff);
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int i = (mi * 2 + ni) * 4 + c;
+              const f32x4 v = *(const f32x4*)(smem_all + (i * 256 + tid) * 16);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) accm[mi][ni][4 * c + r] += v[r];
+              if constexpr (KIND == 1) {
+                const f32x4 w = *(const f32x4*)(smem_all + ((16 + i) * 256 + tid) * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accd[mi][ni][4 * c + r] += w[r];
+              }
+            }
+      }
+      __syncthreads();  // the staging area of the store overlaps the exchange area
+      if (kg == 0)
+        staged_epilogue<KIND, NW>(p, rl, accm, accd, smem_all, tid, wave, lane, ntile, group, split, m0, nvalid, nullptr,
+                                  -1, true, ba_lds);
+    }
   }
 #ifdef BTX_PT_TRACE
   if (p.trace) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t tr_t3 = (uint32_t)__builtin_amdgcn_s_memtime();
     if (lane == 0) {
-      uint32_t* tr = (uint32_t*)p.trace + (size_t)(blockIdx.x * NW + wave) * 8;
-      tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = 0; tr[3] = 0; tr[4] = tr_t3 - tr_t2; tr[5] = tr_t3 - tr_t0;
-      tr[6] = tr_t0; tr[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+      uint32_t* tr = (uint32_t*)p.trace + (size_t)(blockIdx.x * NW * KG + wave_all) * 8;
+      tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = (uint32_t)__builtin_amdgcn_s_memrealtime() - tr_r0; tr[3] = 0;
+      tr[4] = tr_t3 - tr_t2; tr[5] = tr_t3 - tr_t0;
+      if (p.pt_tune & 64) { tr[0] = tr_s[0]; tr[1] = tr_s[1]; tr[3] = tr_s[2]; tr[4] = tr_s[3]; }  // stage split instead
+      tr[6] = tr_t0; tr[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
     }
   }
 #endif

@@ -78,14 +78,38 @@ __device__ __forceinline__ void ep_store8(const ContractParams& p, const f32x4 l
   }
 }
 
+// per-channel constants of the tile in LDS: [bias_mean | bias_delta | scale | shift] x 64 (identity where absent);
+// written by threads t = 0..63 of the caller, who also provides the barrier before they are read
+template <int KIND>
+__device__ __forceinline__ void ep_fill_constants(const ContractParams& p, const RngLive& rl, float* ba_lds, int t,
+                                                  int ntile, int group, bool has_bias, bool has_aff) {
+  if (t < BN) {
+    const int col = ntile * BN + t;
+    const int gcol = group * p.Ng + (col < p.Ng ? col : 0);
+    float bm = 0.f, bdl = 0.f;
+    if (has_bias && col < p.Ng) {
+      const float eb = p.eps_b ? p.eps_b[gcol]
+                               : btx_normal1((unsigned long long)gcol, rl.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
+      const float sb_ = btx_softplus_fast(p.rho_b[gcol]);
+      if constexpr (KIND == 0) { bm = __builtin_fmaf(sb_, eb, p.mu_b[gcol]); }
+      else { bm = p.mu_b[gcol]; bdl = sb_ * eb; }
+    }
+    ba_lds[t] = bm;
+    ba_lds[BN + t] = bdl;
+    ba_lds[2 * BN + t] = (has_aff && p.ep_scale) ? p.ep_scale[gcol] : 1.f;
+    ba_lds[3 * BN + t] = (has_aff && p.ep_shift) ? p.ep_shift[gcol] : 0.f;
+  }
+}
+
 template <int KIND, int NW>
 __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
                                                 const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int wave,
                                                 int lane, int ntile, int group, int split, uint32_t m0, int nvalid,
-                                                uint32_t* ep_t = nullptr, int pwave = -1, bool first = true) {
+                                                uint32_t* ep_t = nullptr, int pwave = -1, bool first = true,
+                                                float* ba_ext = nullptr) {
   // pwave: index of the 64-pixel group of the tile these fragments hold (default: the wave index); `wave` selects the
   // wave-private staging area.  first == false: the per-channel constants are already in LDS (second half of a wave
-  // that owns 128 pixels).
+  // that owns 128 pixels).  ba_ext: the constants were written (and a barrier passed) by the caller, at this address.
   if (pwave < 0) pwave = wave;
   constexpr int EP_ROW = PT_EP_ROW;
   constexpr int EP_WAVE = PT_EP_WAVE;
@@ -94,25 +118,9 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
   const bool has_bias = (split == 0) && (p.mu_b != nullptr);
   const bool has_aff = !to_partial && ((p.ep_scale != nullptr) || (p.ep_shift != nullptr));
   const bool has_ba = has_bias || has_aff;
-  // per-channel constants of the tile in LDS: [bias_mean | bias_delta | scale | shift] x 64 (identity where absent)
-  float* ba_lds = (float*)(smem + NW * EP_WAVE);
-  if (has_ba && first) {
-    if (tid < BN) {
-      const int col = ntile * BN + tid;
-      const int gcol = group * p.Ng + (col < p.Ng ? col : 0);
-      float bm = 0.f, bdl = 0.f;
-      if (has_bias && col < p.Ng) {
-        const float eb = p.eps_b ? p.eps_b[gcol]
-                                 : btx_normal1((unsigned long long)gcol, rl.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
-        const float sb_ = btx_softplus_fast(p.rho_b[gcol]);
-        if constexpr (KIND == 0) { bm = __builtin_fmaf(sb_, eb, p.mu_b[gcol]); }
-        else { bm = p.mu_b[gcol]; bdl = sb_ * eb; }
-      }
-      ba_lds[tid] = bm;
-      ba_lds[BN + tid] = bdl;
-      ba_lds[2 * BN + tid] = (has_aff && p.ep_scale) ? p.ep_scale[gcol] : 1.f;
-      ba_lds[3 * BN + tid] = (has_aff && p.ep_shift) ? p.ep_shift[gcol] : 0.f;
-    }
+  float* ba_lds = ba_ext ? ba_ext : (float*)(smem + NW * EP_WAVE);
+  if (has_ba && first && !ba_ext) {
+    ep_fill_constants<KIND>(p, rl, ba_lds, tid, ntile, group, has_bias, has_aff);
     __syncthreads();
   }
   unsigned char* ep = smem + wave * EP_WAVE;

@@ -153,7 +153,7 @@ def gtime(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64, rep
     return us, fl / (us * 1e-6) / 1e12
 
 
-def trace(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64):
+def trace(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64, warm=3):
     """per-wave phase timings of the patch kernel (needs a libbtx built with -DBTX_PT_TRACE, see BTX_LIB)"""
     import os
     import numpy as np
@@ -166,19 +166,23 @@ def trace(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64):
     x = torch.randn(bs, cin, hw, hw, device=dev).to(act).contiguous(memory_format=torch.channels_last)
     buf = torch.zeros(1 << 22, dtype=torch.int32, device=dev)
     with torch.no_grad():
-        for i in range(3):
+        for i in range(warm):  # many launches: the traced one runs at the clock the GPU settles to under this load
             layer._forward_hip(x, sample_idx=i)
-        torch.cuda.synchronize()
         os.environ["BTX_TRACE_PTR"] = hex(buf.data_ptr())
         layer._forward_hip(x, sample_idx=7)
         torch.cuda.synchronize()
         del os.environ["BTX_TRACE_PTR"]
     t = buf.cpu().numpy().view(np.uint32).reshape(-1, 8)
     t = t[t[:, 5] != 0]
+    if os.environ.get("BTX_TRACE_DUMP"):
+        np.save(os.environ["BTX_TRACE_DUMP"], t)
     print("waves traced: %d" % len(t))
     if not len(t):
         return
-    names = ["prologue", "A->B issue+mma", "B->C vmcnt", "C->D barrier", "epilogue", "total"]
+    names = ["prologue", "A->B issue+mma", "B->C vmcnt|100MHz ticks", "C->D barrier", "epilogue", "total"]
+    if t[:, 2].astype(np.float64).mean() > 0 and t[:, 3].astype(np.float64).mean() == 0:
+        print("  shader clock while the blocks ran: %.3f GHz (s_memtime / s_memrealtime)" % (
+            t[:, 5].astype(np.float64).mean() / t[:, 2].astype(np.float64).mean() * 0.1))
     for i, n in enumerate(names):
         c = t[:, i].astype(np.float64)
         print("  %-16s mean %9.0f  min %9.0f  max %9.0f  (clock ticks)" % (n, c.mean(), c.min(), c.max()))
@@ -198,6 +202,7 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shape", default="64,64,56,1,3")
     ap.add_argument("--bs", type=int, default=64)
+    ap.add_argument("--warm", type=int, default=3)
     a = ap.parse_args()
     if "one" in a.what or "timeone" in a.what:
         c = [int(v) for v in a.shape.split(",")]
@@ -210,7 +215,7 @@ if __name__ == "__main__":
         print("shape %s bs %d: %.1f us / call  %.1f TFLOP/s" % (a.shape, a.bs, us, tf))
     if "trace" in a.what:
         c = [int(v) for v in a.shape.split(",")]
-        trace(a.prec.split(",")[0], *c, bs=a.bs)
+        trace(a.prec.split(",")[0], *c, bs=a.bs, warm=a.warm)
     if "parity" in a.what:
         parity()
     if "perf" in a.what:
