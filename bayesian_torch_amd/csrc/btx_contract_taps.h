@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
       for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
 
   using Frag = StageFragT<MI>;
-  auto load_frag = [&](Frag& f, int aslot, int toffv, int wsl) __attribute__((always_inline)) {
+  auto load_frag = [&](Frag& f, int aslot, int toffv, int wsl, auto mia_tag) __attribute__((always_inline)) {
+    constexpr int MIA = decltype(mia_tag)::value;
     const unsigned char* as = smem + PT_A_OFF + aslot * a_stage;
     const unsigned char* ss = smem + PT_S_OFF + aslot * s_stage;
     const unsigned char* ws = smem + PT_W_OFF + wsl * DW_STAGE;
@@ -259,13 +260,13 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     for (int kk = 0; kk < NG / 2; ++kk) {
       const int row = 2 * kk + h;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) f.a[kk][mi] = *(const u32x4*)(as + q[mi] * 64 + ((row ^ ((q[mi] >> 2) & 3)) * 16));
+      for (int mi = 0; mi < MIA; ++mi) f.a[kk][mi] = *(const u32x4*)(as + q[mi] * 64 + ((row ^ ((q[mi] >> 2) & 3)) * 16));
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) f.wm[kk][ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
     }
     if constexpr (KIND == 1) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) f.sw[mi] = *(const uint32_t*)(ss + q[mi] * 4);
+      for (int mi = 0; mi < MIA; ++mi) f.sw[mi] = *(const uint32_t*)(ss + q[mi] * 4);
     }
   };
 
@@ -275,7 +276,14 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     // issued last, may still be in flight.  KG == 2: a stage reads its own fragments: W(1) may be in flight as well.
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(KG == 1 ? WOPS : 2 * WOPS) : "memory");
     Frag fa, fb;
-    if constexpr (KG == 1) load_frag(fa, 0, 0, 0);
+    // The wave's second 32-pixel tile may be pure tile padding (224-pixel tiles: 4 rows of 56, wave 3; 196-pixel tiles:
+    // wave 3 as well): its MFMAs, fragment reads and sign masks are skipped — an eighth of the block's matrix work.  The
+    // choice is wave-uniform, so the K loop exists in two instantiations and every wave still meets every barrier.
+    const int nvalid_px = min(p.pt_G, p.NB - img0) * min(p.pt_R, p.Ho - row0) * p.Wo;
+    const bool mi1_dead = wave * 64 + 32 >= nvalid_px;
+    auto kloop = [&](auto mia_tag) __attribute__((always_inline)) {
+    constexpr int MIA = decltype(mia_tag)::value;
+    if constexpr (KG == 1) load_frag(fa, 0, 0, 0, mia_tag);
 #ifdef BTX_PT_TRACE
     tr_t1 = (uint32_t)__builtin_amdgcn_s_memtime();
     uint32_t tr_tA = tr_t1, tr_ab = 0, tr_lg = 0, tr_bc = 0, tr_cd = 0;
@@ -321,9 +329,9 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
           // 3. delta weights of this stage, then the fragments of the next one
           load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
           constexpr int t1 = (t + 1) % T, c1 = (t + 1) / T;
-          load_frag(nxt, PAR ^ c1, (t1 / KW) * row_step + (t1 % KW) * p.dw, (wslot + 1) & 3);
+          load_frag(nxt, PAR ^ c1, (t1 / KW) * row_step + (t1 % KW) * p.dw, (wslot + 1) & 3, mia_tag);
           // 4. multiply
-          stage_mma<PREC, KIND, MI>(cur, df, accm, accd, l31, h);
+          stage_mma<PREC, KIND, MI, MIA>(cur, df, accm, accd, l31, h);
           // 5. W(s+2) — and, from stage T-3 on, every piece of the next patch — landed; meet the other waves
 #ifdef BTX_PT_TRACE
           {  // split the stage end: issue+MFMA | LDS reads back | VMEM wait | barrier
@@ -345,12 +353,12 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
         } else {
           // H1: this stage's own fragments (their latency hides behind the other group's MFMA half)
           load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
-          load_frag(cur, PAR, (t / KW) * row_step + (t % KW) * p.dw, wslot);
+          load_frag(cur, PAR, (t / KW) * row_step + (t % KW) * p.dw, wslot, mia_tag);
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_barrier" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           // H2: multiply
-          stage_mma<PREC, KIND, MI>(cur, df, accm, accd, l31, h);
+          stage_mma<PREC, KIND, MI, MIA>(cur, df, accm, accd, l31, h);
           __builtin_amdgcn_sched_barrier(0);
           // W(s+1) — read by the next stage's H1 — and from stage T-1 on the next patch landed: everything issued before
           // the last two iterations (the pieces of iteration s-2 were issued after its W)
@@ -372,6 +380,9 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     }
     if (cbi < ncb) block(std::integral_constant<int, 0>{}, cbi, true);
     if (KG == 2 && kg == 0) asm volatile("s_barrier" ::: "memory");
+    };  // kloop
+    if (mi1_dead) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 2>{});
 #ifdef BTX_PT_TRACE
     tr_s[0] = tr_ab; tr_s[1] = tr_lg; tr_s[2] = tr_bc; tr_s[3] = tr_cd;
 #endif

@@ -41,7 +41,8 @@ __device__ __forceinline__ void load_delta(DeltaFrag& d, const unsigned char* ws
 // follow.  The caller issues load_delta() BEFORE any LDS read it wants to stay in flight across this call (the fragment
 // prefetch of the next stage): LDS returns in order, so delta fragments queued behind a prefetch would make the delta
 // MFMAs wait for data they do not need.
-template <int PREC, int KIND, int MI = 2>
+// MIA = the wave's 32-pixel tiles that hold real pixels (<= MI): the tiles behind them are tile padding and are skipped.
+template <int PREC, int KIND, int MI = 2, int MIA = MI>
 __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& dfrag, f32x16 (&accm)[MI][2],
                                           f32x16 (&accd)[MI][2], int l31, int h) {
     const u32x4 (&wd)[NG / 2][2] = dfrag.w;
@@ -52,7 +53,7 @@ __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& df
     for (int kk = 0; kk < NG / 2; ++kk) {
       if constexpr (PREC == 1) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MIA; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(f.wm[kk][ni]), "v"(f.a[kk][mi])); accm[mi][ni][0] += 1.f; }
@@ -63,7 +64,7 @@ __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& df
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+          for (int mi = 0; mi < MIA; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
               accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(f.wm[kk][ni][e]), u2f(f.a[kk][mi][e]), accm[mi][ni], 0, 0, 0);
@@ -76,14 +77,14 @@ __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& df
         if constexpr (PREC == 1) {
           if constexpr (!(BTX_PT_ABL & 16)) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
+            for (int mi = 0; mi < MIA; ++mi) {
               const uint32_t swr = f.sw[mi] << (4 * row);
 #pragma unroll
               for (int d = 0; d < 4; ++d) f.a[kk][mi][d] ^= ((swr << d) & 0x80008000u);
             }
           }
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+          for (int mi = 0; mi < MIA; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
               if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(wd[kk][ni]), "v"(f.a[kk][mi])); accd[mi][ni][0] += 1.f; }
@@ -92,7 +93,7 @@ __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& df
             }
         } else {
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
+          for (int mi = 0; mi < MIA; ++mi) {
             const uint32_t swr = f.sw[mi] << (2 * row);
 #pragma unroll
             for (int e = 0; e < 4; ++e) f.a[kk][mi][e] ^= ((swr << ((e >> 1) + ((e & 1) ? 0 : 16))) & 0x80000000u);
@@ -100,7 +101,7 @@ __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& df
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MIA; ++mi)
 #pragma unroll
               for (int ni = 0; ni < 2; ++ni)
                 accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2f(wd[kk][ni][e]), u2f(f.a[kk][mi][e]), accd[mi][ni], 0, 0, 0);
