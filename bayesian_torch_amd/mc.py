@@ -130,13 +130,16 @@ class GraphedMC:
 
     The parameters must not be re-allocated while the graph is alive (in-place updates are seen by the replays)."""
 
-    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1):
+    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1, keep_logits=False):
         """lanes > 1: one replay evaluates `lanes` MC samples, each on its own stream inside the graph (independent noise:
         the same results as one at a time) — the kernels of one sample fill the GPU while those of another are in their
         ramp-up / tail; use run_many()."""
         if not x.is_cuda:
             raise ValueError("GraphedMC needs CUDA (ROCm) tensors")
         self.model, self.x, self.kl, self.lanes = model, x, float(kl), int(lanes)
+        # keep_logits: lane_logits[k] is the (static) logits tensor of lane k — after a replay it holds the logits of the
+        # sample that lane just evaluated (parity tests of the graphed configuration)
+        self.keep_logits, self.lane_logits = bool(keep_logits), [None] * int(lanes)
         dev = x.device
         self.sample_devs = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(self.lanes)]
         self.sample_dev = self.sample_devs[0]
@@ -187,6 +190,8 @@ class GraphedMC:
             if k == 0:
                 self.packed = self._lane_packed[0]
         accumulate(self._lane_packed[k], logits, self.kl)
+        if self.keep_logits:
+            self.lane_logits[k] = logits
 
     def run(self, sample_idx):
         if self.lanes != 1:

@@ -157,11 +157,14 @@ def convert_for_baseline(model):
             kind = "Flipout" if getattr(child, "_family", "") == "flipout" else "Reparameterization"
             if child.mu_bias is not None or child.groups != 1 or child.dilation not in (1, (1, 1)):
                 raise NotImplementedError("baseline converter covers the bias-free ResNet convs")
-            setattr(model, name, RefVariationalConv2d(child.mu_kernel.detach(), child.rho_kernel.detach(), child.stride,
+            # plain row-major copies: the product stores its parameters GEMM-major (a strided view), the reference hands
+            # F.conv2d a contiguous [Cout, Cin, kh, kw] weight — same tensor layout => same MKLDNN path as the reference
+            plain = lambda t: t.detach().clone(memory_format=torch.contiguous_format)  # noqa: E731
+            setattr(model, name, RefVariationalConv2d(plain(child.mu_kernel), plain(child.rho_kernel), child.stride,
                                                       child.padding, kind))
         elif hasattr(child, "mu_weight") and hasattr(child, "rho_weight"):
             kind = "Flipout" if getattr(child, "_family", "") == "flipout" else "Reparameterization"
-            setattr(model, name, RefVariationalLinear(child.mu_weight.detach(), child.rho_weight.detach(),
+            setattr(model, name, RefVariationalLinear(child.mu_weight.detach().clone(), child.rho_weight.detach().clone(),
                                                       child.mu_bias.detach(), child.rho_bias.detach(), kind))
         else:
             convert_for_baseline(child)

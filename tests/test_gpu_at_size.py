@@ -1,0 +1,236 @@
+"""GPU: parity AT THE BASELINE.json SIZES (cfg3, cfg4, cfg5) — every variational layer of the converted model against
+the reference op chain (oracle/bt_ref.py, evaluated by torch on the GPU in f32) fed with the noise BTX-RNG v1 defines
+for that (layer, sample), in both precisions; the benched configuration end to end; the batched-MC mode and the
+distribution of MC samples against fixtures generated from the reference itself.
+
+Tolerances (also in DESIGN.md §2):
+  f32 parity mode   per layer rel-L2 <= 1e-4 (north_star's output bar)
+  bf16 throughput   per layer rel-L2 <= 1e-2 against the f32 chain on the same (bf16-valued) input: operands rounded to 8
+                    mantissa bits, f32 accumulation; logits of the 21-layer ResNet18 <= 3e-2, of ResNet50+MOPED <= 3e-2
+"""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore")
+
+PRIOR = dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, moped_delta=0.5)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _build(arch, typ, moped, dev, bf16):
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models import resnet
+    torch.manual_seed(0)
+    m = getattr(resnet, arch)()
+    bt.dnn_to_bnn(m, dict(PRIOR, type=typ, moped_enable=moped))
+    m = m.to(dev).eval()
+    if bf16:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.to(torch.bfloat16)
+    bt.assign_layer_ids(m)
+    return m
+
+
+def _check_every_layer(model, x, typ, sample, tol):
+    """forward hooks compare each variational layer with the reference chain AS IT RUNS (nothing is kept: ResNet50 at
+    batch 128 moves 11 GB of activations); returns (worst rel-L2, number of layers, logits)"""
+    import bayesian_torch_amd as bt
+    from oracle import bt_ref
+    worst = [0.0, 0]
+
+    def hook(mod, inp, out):
+        xin = inp[0].detach()
+        nz = mod.materialize_noise(sample, tuple(xin.shape), tuple(out.shape), xin.dtype)
+        mu, rho = mod._w()
+        if mod._op.nd == 0:
+            op = dict(kind="linear")
+        else:
+            op = dict(kind="conv", nd=2, stride=mod._op.stride[1:], padding=mod._op.padding[1:],
+                      dilation=mod._op.dilation[1:], groups=mod._op.groups)
+        xf = xin.float()
+        if typ == "Flipout":
+            ref = bt_ref.flipout_forward(xf, mu, rho, mod.mu_bias, mod.rho_bias, nz["eps_w"], nz.get("eps_b"),
+                                         nz["sign_in"].float(), nz["sign_out"].float(), op)
+        else:
+            ref = bt_ref.reparam_forward(xf, mu, rho, mod.mu_bias, mod.rho_bias, nz["eps_w"], nz.get("eps_b"), op)
+        err = float((out.detach().float() - ref).norm() / ref.norm())
+        worst[0] = max(worst[0], err)
+        worst[1] += 1
+        assert err < tol, (mod.__class__.__name__, tuple(xin.shape), mod._op.kernel, mod._op.stride, err)
+    hs = [mod.register_forward_hook(hook) for mod in model.modules() if hasattr(mod, "kl_loss")]
+    try:
+        with torch.no_grad():
+            bt.set_sample_index(model, sample)
+            logits = model(x)
+    finally:
+        for h in hs:
+            h.remove()
+    return worst[0], worst[1], logits
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 1e-2)])
+@pytest.mark.parametrize("typ", ["Reparameterization", "Flipout"])
+def test_resnet18_bs64_every_layer(typ, prec, tol):
+    """BASELINE cfg3 (Reparameterization) / cfg4 (Flipout): dnn_to_bnn(ResNet18), 224^2, batch 64"""
+    import bayesian_torch_amd as bt
+    dev = _dev()
+    bt.manual_seed(2024)
+    bt.set_precision(prec)
+    try:
+        m = _build("resnet18", typ, False, dev, prec == "bf16")
+        torch.manual_seed(1234)
+        x = torch.randn(64, 3, 224, 224, device=dev).to(torch.bfloat16 if prec == "bf16" else torch.float32)
+        worst, n, logits = _check_every_layer(m, x, typ, 5, tol)
+        assert n == 21 and logits.shape == (64, 1000) and torch.isfinite(logits).all()
+        print("resnet18 %s %s bs64: worst per-layer rel-L2 %.3g" % (typ, prec, worst))
+    finally:
+        bt.set_precision("f32")
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 1e-2)])
+def test_resnet50_moped_bs128_every_layer(prec, tol):
+    """BASELINE cfg5 (per-GPU shard): dnn_to_bnn(ResNet50) Flipout with moped_enable=True (delta 0.5), batch 128"""
+    import bayesian_torch_amd as bt
+    dev = _dev()
+    bt.manual_seed(2024)
+    bt.set_precision(prec)
+    try:
+        m = _build("resnet50", "Flipout", True, dev, prec == "bf16")
+        torch.manual_seed(1234)
+        x = torch.randn(128, 3, 224, 224, device=dev).to(torch.bfloat16 if prec == "bf16" else torch.float32)
+        worst, n, logits = _check_every_layer(m, x, "Flipout", 2, tol)
+        assert n == 54 and logits.shape == (128, 1000) and torch.isfinite(logits).all()
+        kat = json.load(open(os.path.join(HERE, "golden", "kat.json")))["models"].get("resnet50_Flipout_moped")
+        if kat:
+            with torch.no_grad():
+                kl = float(bt.get_kl_loss(m))
+            assert abs(kl - kat["kl"]) <= 1e-5 * abs(kat["kl"]), (kl, kat["kl"])
+        print("resnet50+MOPED Flipout %s bs128: worst per-layer rel-L2 %.3g" % (prec, worst))
+    finally:
+        bt.set_precision("f32")
+
+
+@pytest.mark.parametrize("arch,typ,moped,bs,tol", [("resnet18", "Flipout", False, 64, 3e-2),
+                                                    ("resnet18", "Reparameterization", False, 64, 3e-2),
+                                                    ("resnet50", "Flipout", True, 128, 3e-2)])
+def test_benched_configuration_end_to_end(arch, typ, moped, bs, tol):
+    """bench.py's configuration — bf16, eval-BN/ReLU/residual folded into the epilogues (fuse_resnet), one weight
+    sampling launch per sample, hipGraph replay with 3 MC samples in flight — against the UNFUSED f32-parity-mode op
+    chain of the same parameters evaluated eagerly with the same sample indices (same BTX-RNG noise)."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    dev = _dev()
+    bt.manual_seed(2024)
+    samples = [11, 12, 13]
+    try:
+        bt.set_precision("f32")
+        ref_m = _build(arch, typ, moped, dev, False)
+        torch.manual_seed(1234)
+        x = torch.randn(bs, 3, 224, 224, device=dev)
+        refs = []
+        with torch.no_grad():
+            for s in samples:
+                bt.set_sample_index(ref_m, s)
+                refs.append(ref_m(x).float().clone())
+        del ref_m
+        bt.set_precision("bf16")
+        m = _build(arch, typ, moped, dev, True)
+        fuse_resnet(m)
+        g = mc.GraphedMC(m, x.to(torch.bfloat16), kl=0.0, lanes=3, keep_logits=True)
+        g.run_many(samples)
+        torch.cuda.synchronize()
+        errs = [float((g.lane_logits[k].float() - refs[k]).norm() / refs[k].norm()) for k in range(3)]
+        g.close()
+        assert not torch.equal(refs[0], refs[1])
+        print("%s %s%s bs%d: logits rel-L2 of the graphed bf16 configuration vs the unfused f32 chain: %s" % (
+            arch, typ, "+MOPED" if moped else "", bs, ", ".join("%.3g" % e for e in errs)))
+        assert max(errs) < tol, errs
+    finally:
+        bt.set_precision("f32")
+
+
+def test_batched_mc_matches_reference_chain():
+    """mc_forward_batched = the reference's `torch.cat([data]*S)` trick.  One shared weight perturbation
+    and per-example signs per chunk: its packed statistics must equal those computed from the reference op chain
+    (oracle/bt_ref.py) applied layer by layer to the concatenated batch with the noise of that chunk."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from oracle import bt_ref
+    dev = _dev()
+    bt.manual_seed(31)
+    torch.manual_seed(2)
+    net = torch.nn.Sequential(torch.nn.Linear(96, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, 10))
+    bt.dnn_to_bnn(net, dict(PRIOR, type="Flipout", moped_enable=False))
+    net = net.to(dev).eval()
+    bt.assign_layer_ids(net)
+    bt.set_precision("f32")
+    x = torch.randn(16, 96, device=dev)
+    S, chunk = 6, 4
+    packed = mc.mc_forward_batched(net, x, S, chunk=chunk)
+    want = torch.zeros_like(packed)
+    done, cid = 0, 0
+    layers = [m for m in net if hasattr(m, "kl_loss")]
+    with torch.no_grad():
+        while done < S:
+            c = min(chunk, S - done)
+            h = torch.cat([x] * c, 0)
+            for i, mod in enumerate(layers):
+                out_shape = (h.shape[0], mod.out_features)
+                nz = mod.materialize_noise(cid, tuple(h.shape), out_shape, h.dtype)
+                h = bt_ref.flipout_forward(h, mod.mu_weight, mod.rho_weight, mod.mu_bias, mod.rho_bias, nz["eps_w"],
+                                           nz["eps_b"], nz["sign_in"].float(), nz["sign_out"].float(), dict(kind="linear"))
+                if i + 1 < len(layers):
+                    h = torch.relu(h)
+            for r in range(c):
+                mc.accumulate(want, h[r * 16:(r + 1) * 16].contiguous(), 0.0)
+            done += c
+            cid += 1
+    assert torch.allclose(packed, want, rtol=1e-4, atol=1e-5), float((packed - want).abs().max())
+
+
+def test_mc_distribution_matches_reference_fixture():
+    """the noise streams differ from the reference's by construction, so the comparison is
+    distributional: per-logit mean / variance of S = 256 MC samples of the cfg2 MLP (same init draws, same input)
+    against the statistics of 256 MC samples of the REFERENCE run on torch-CPU (tests/golden/mc_stats.npz, written by
+    tools/make_golden.py).  |mean - mean_ref| <= 5 * sqrt((var + var_ref) / S); variance ratio in [0.6, 1.6]."""
+    import bayesian_torch_amd as bt
+    dev = _dev()
+    fx = np.load(os.path.join(HERE, "golden", "mc_stats.npz"))
+    S, rows = int(fx["S"]), int(fx["rows"])
+    bt.manual_seed(77)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(784, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                              torch.nn.Linear(512, 10))
+    bt.dnn_to_bnn(net, dict(PRIOR, type="Flipout", moped_enable=False))
+    net = net.to(dev).eval()
+    bt.assign_layer_ids(net)
+    bt.set_precision("f32")
+    torch.manual_seed(1234)
+    x = torch.randn(256, 784).to(dev)
+    ys = []
+    with torch.no_grad():
+        for s in range(S):
+            bt.set_sample_index(net, s)
+            ys.append(net(x)[:rows].float().cpu().numpy())
+    y = np.stack(ys).astype(np.float64)
+    mean, var = y.mean(0), y.var(0)
+    mref, vref = fx["mean"].astype(np.float64), fx["var"].astype(np.float64)
+    z = np.abs(mean - mref) / np.sqrt((var + vref) / S)
+    ratio = var / vref
+    print("MC distribution vs reference: max |z| %.2f, variance ratio %.2f..%.2f" % (z.max(), ratio.min(), ratio.max()))
+    assert z.max() < 5.0, z.max()
+    assert ratio.min() > 0.6 and ratio.max() < 1.6, (ratio.min(), ratio.max())

@@ -157,7 +157,7 @@ def main():
     base = dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0,
                 moped_enable=False, moped_delta=0.5)
     for arch, typ, moped in (("resnet18", "Reparameterization", False), ("resnet18", "Flipout", False),
-                             ("resnet18", "Flipout", True), ("resnet50", "Flipout", False)):
+                             ("resnet18", "Flipout", True), ("resnet50", "Flipout", False), ("resnet50", "Flipout", True)):
         torch.manual_seed(0)
         m = getattr(ref_resnet, arch)()
         p = dict(base, type=typ, moped_enable=moped)
@@ -173,6 +173,23 @@ def main():
 
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
+
+    # distribution of the reference's MC samples: BASELINE cfg2 MLP, 256 stochastic forwards of the
+    # reference on torch-CPU; per-logit mean / variance of the first 32 batch rows
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(784, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                              torch.nn.Linear(512, 10))
+    ref_dnn_to_bnn(net, dict(base, type="Flipout"))
+    net.eval()
+    torch.manual_seed(1234)
+    xm = torch.randn(256, 784)
+    S, rows = 256, 32
+    torch.manual_seed(4321)
+    with torch.no_grad():
+        ys = torch.stack([net(xm)[:rows] for _ in range(S)]).double()
+    np.savez_compressed(os.path.join(gdir, "mc_stats.npz"), mean=ys.mean(0).numpy(), var=ys.var(0, unbiased=False).numpy(),
+                        S=S, rows=rows)
+    print("mc_stats: mean |logit| %.3g, mean std %.3g" % (float(ys.mean(0).abs().mean()), float(ys.std(0).mean())))
     np.savez_compressed(os.path.join(gdir, "layers.npz"), **out)
     with open(os.path.join(gdir, "kat.json"), "w") as f:
         json.dump(dict(layers=meta, signatures=sigs, models=kat,
