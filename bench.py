@@ -420,7 +420,7 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
         res["per_launch"] = table
         res["gflop_per_step"] = sum(r["gflop"] for r in table)
         res["kernel_us_per_step"] = sum(r["us"] for r in table)
-        res["dominant_tflops"] = sum(r["gflop"] for r in dom) / sum(r["us"] for r in dom) * 1e-3
+        res["dominant_tflops"] = sum(r["gflop"] for r in dom) / sum(r["us"] for r in dom) * 1e3  # GFLOP/us = 1e15 FLOP/s
         res["dominant_avg_us"] = sum(r["us"] for r in dom) / len(dom)
         res["dominant_n"] = len(dom)
         res["achieved_e2e_tflops"] = res["gflop_per_step"] / res["ms_per_step"]
@@ -615,7 +615,7 @@ def main():
                           "reduce where the plan splits K)" % (args.prec, args.type, head["dominant_n"]),
                 "avg_launch_us": head["dominant_avg_us"], "launches_per_step": len(head["per_launch"]),
                 "algorithmic_gflop_per_step": head["gflop_per_step"], "kernel_us_per_step": head["kernel_us_per_step"],
-                "achieved_all_launches": head["gflop_per_step"] / head["kernel_us_per_step"] * 1e-3,
+                "achieved_all_launches": head["gflop_per_step"] / head["kernel_us_per_step"] * 1e3,
                 "achieved_e2e": head["achieved_e2e_tflops"], "frac_e2e": head["achieved_e2e_tflops"] / peak,
                 "measured": "every contraction launch of a step re-issued 10x inside a hipGraph, HIP events on the launch "
                             "stream around 2 replays (GPU time, no host gaps); achieved_e2e = algorithmic FLOP of a step / "

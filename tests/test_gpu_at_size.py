@@ -6,7 +6,8 @@ distribution of MC samples against fixtures generated from the reference itself.
 Tolerances (also in DESIGN.md §2):
   f32 parity mode   per layer rel-L2 <= 1e-4 (north_star's output bar)
   bf16 throughput   per layer rel-L2 <= 1e-2 against the f32 chain on the same (bf16-valued) input: operands rounded to 8
-                    mantissa bits, f32 accumulation; logits of the 21-layer ResNet18 <= 3e-2, of ResNet50+MOPED <= 3e-2
+                    mantissa bits, f32 accumulation (measured 2.4-2.7e-3); logits of the graphed + fused configuration
+                    <= 1e-2 for ResNet18 and ResNet50+MOPED (measured 3.8-5.5e-3)
 """
 import json
 import os
@@ -122,9 +123,9 @@ def test_resnet50_moped_bs128_every_layer(prec, tol):
         bt.set_precision("f32")
 
 
-@pytest.mark.parametrize("arch,typ,moped,bs,tol", [("resnet18", "Flipout", False, 64, 3e-2),
-                                                    ("resnet18", "Reparameterization", False, 64, 3e-2),
-                                                    ("resnet50", "Flipout", True, 128, 3e-2)])
+@pytest.mark.parametrize("arch,typ,moped,bs,tol", [("resnet18", "Flipout", False, 64, 1e-2),
+                                                    ("resnet18", "Reparameterization", False, 64, 1e-2),
+                                                    ("resnet50", "Flipout", True, 128, 1e-2)])
 def test_benched_configuration_end_to_end(arch, typ, moped, bs, tol):
     """bench.py's configuration — bf16, eval-BN/ReLU/residual folded into the epilogues (fuse_resnet), one weight
     sampling launch per sample, hipGraph replay with 3 MC samples in flight — against the UNFUSED f32-parity-mode op
