@@ -10,6 +10,17 @@
 #include "btx_presample.h"
 namespace btx { constexpr int DBM = 512; }  // pixels per tile of the LDS-DMA variant (btx_contract_dma.h)
 
+// A/B knobs of the measurement builds (tools/build_variants.sh ... "-DBTX_TUNING", tools/kbench.py): the shipped library
+// reads no environment variable — every dispatch decision is a function of the call's arguments.
+static inline const char* tune_env(const char* name) {
+#if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 using namespace btx;
 
 // ========================================================================================================
@@ -364,7 +375,7 @@ int btx_out_shape(const BtxGeom* g, uint32_t flags, int32_t* Do, int32_t* Ho, in
 // partial sums cost HBM traffic and a reduce launch while the other samples fill the idle CUs anyway.  BTX_SLOTS4
 // overrides.
 static long long slots4() {
-  static const char* e = getenv("BTX_SLOTS4");
+  static const char* e = tune_env("BTX_SLOTS4");
   static const long long v = e ? atoll(e) : 256;
   return v > 0 ? v : 256;
 }
@@ -467,10 +478,10 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   if (T < 2 || T > 64) return false;
   // 4-wave blocks, two per CU: 2 patch slots + 2 sign slots + 4 weight tiles within 80 KiB -> 22 pieces = 352 pixels;
   // 8-wave blocks, one per CU: 60 pieces = 960 pixels.  BTX_PATCH_NW=8 forces the latter (A/B measurements).
-  static const char* nw_env = getenv("BTX_PATCH_NW");
+  static const char* nw_env = tune_env("BTX_PATCH_NW");
   const bool force8 = nw_env && atoi(nw_env) == 8;
   // BTX_PATCH_MI=4: 4 waves x 128 pixels, one block per CU, 256 accumulators per wave (A/B measurements)
-  static const char* mi_env = getenv("BTX_PATCH_MI");
+  static const char* mi_env = tune_env("BTX_PATCH_MI");
   const bool want_mi4 = mi_env && atoi(mi_env) == 4;
   pt->mi = 2;
   if (want_mi4 && patch_tile(g, *pl, 512, 960, pt)) { pt->nw = 4; pt->mi = 4; }
@@ -492,11 +503,11 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   const int ncb = pl->Cg / bk;
   pl->mtiles = ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
   const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
-  const bool no_taps = getenv("BTX_NO_TAPS") != nullptr;  // A/B: the run-time-tap patch kernel instead (read per call)
+  const bool no_taps = tune_env("BTX_NO_TAPS") != nullptr;  // A/B: the run-time-tap patch kernel instead (read per call)
   pt->taps = (!no_taps && pt->nw == 4 && pt->mi == 2 && pt->NI <= 6 && g->KH == 3 && g->KW == 3) ? 33 : 0;
   // Few pixel tiles (at most one 4-wave block per CU): 8-wave blocks of two K-groups — split-K inside the workgroup
   // through LDS instead of through HBM, and two waves per SIMD.  BTX_NO_KG=1 disables (A/B).
-  const bool no_kg = getenv("BTX_NO_KG") != nullptr;
+  const bool no_kg = tune_env("BTX_NO_KG") != nullptr;
   pt->kg = (pt->taps && !no_kg && base <= 256 && ncb >= 2 && (ncb % 2) == 0 && 2 * pt->lds_g <= 163840) ? 2 : 1;
   const int units = ncb / pt->kg;  // channel blocks per K-group over the whole K
   int ks = 1;
@@ -533,7 +544,7 @@ static bool make_stem_plan(const BtxGeom* g, int act_dtype, int prec, const Plan
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   if ((g->KW * g->C) % bk || pl.K % bk) return false;
   const long long rowB = (long long)g->W * g->C * esz;
-  static const char* snw_env = getenv("BTX_STEM_NW");  // 8: skip the 4-wave plan (A/B measurements)
+  static const char* snw_env = tune_env("BTX_STEM_NW");  // 8: skip the 4-wave plan (A/B measurements)
   for (int nw = (snw_env && atoi(snw_env) == 8) ? 8 : 4; nw <= 8; nw += 4) {
     const int tp = 64 * nw;
     if (pl.Wo > tp) continue;
@@ -623,7 +634,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   const bool gen = (pl.Cg % G != 0) || (al & 15) || explicit_kloop;
   // LDS-DMA pipeline when the activations already have the contraction dtype (no conversion on the way to LDS);
   // BTX_NO_DMA=1 forces the register-staged kernel (A/B measurements).
-  static const bool no_dma = getenv("BTX_NO_DMA") != nullptr;
+  static const bool no_dma = tune_env("BTX_NO_DMA") != nullptr;
   const bool rowfuse = (flags & BTX_FLAG_ROWFUSE) != 0;
   bool dma = !gen && !no_dma && dma_shape_ok(g, act_dtype, prec, pl);
   if (rowfuse) {
@@ -638,14 +649,14 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     dma = true;
   }
   // LDS-DMA variant: 4-wave blocks on 256-pixel tiles (two per CU) unless BTX_DMA_NW=8 (A/B measurements)
-  static const char* dnw_env = getenv("BTX_DMA_NW");
+  static const char* dnw_env = tune_env("BTX_DMA_NW");
   const int dma_nw = (dnw_env && atoi(dnw_env) == 8) ? 8 : 4;
   if (dma) {
     rc = make_plan(g, prec, flags, 64 * dma_nw, &pl);
     if (rc) return rc;
   }
   // stem variant: row-fused small-C convolutions with the input rows of the tile resident in LDS (BTX_NO_STEM=1 disables)
-  static const bool no_stem = getenv("BTX_NO_STEM") != nullptr;
+  static const bool no_stem = tune_env("BTX_NO_STEM") != nullptr;
   StemPlan stp;
   bool stem = false;
   if (dma && rowfuse && !no_stem) {
@@ -657,7 +668,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     }
   }
   // patch variant: stride-1 2-D convolutions keep the halo'd input patch of the tile in LDS (BTX_NO_PATCH=1 disables)
-  static const bool no_patch = getenv("BTX_NO_PATCH") != nullptr;
+  static const bool no_patch = tune_env("BTX_NO_PATCH") != nullptr;
   PatchPlan pt;
   bool patch = false;
   if (dma && !rowfuse && !no_patch) {
@@ -728,7 +739,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.w_bytes = wb < 0xffffffffLL ? (uint32_t)wb : 0xffffffffu;
   }
 
-  if (const char* tp = getenv("BTX_TRACE_PTR")) p.trace = (void*)strtoull(tp, nullptr, 0);  // BTX_PT_TRACE builds only
+  if (const char* tp = tune_env("BTX_TRACE_PTR")) p.trace = (void*)strtoull(tp, nullptr, 0);  // BTX_PT_TRACE builds only
   p.pt_nw = dma_nw;
   p.fd_inner = make_fastdiv((uint32_t)(pl.ntiles * g->groups * pl.ksplits)); p.fd_ksplits = make_fastdiv((uint32_t)pl.ksplits);
   p.fd_ntiles = make_fastdiv((uint32_t)pl.ntiles); p.fd_rtiles = make_fastdiv(1u);
@@ -751,7 +762,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.fd_ptWp = make_fastdiv((uint32_t)pt.Wp); p.fd_ptRp = make_fastdiv((uint32_t)pt.Rp); p.fd_ptR = make_fastdiv((uint32_t)pt.R);
     p.fd_rtiles = make_fastdiv((uint32_t)pt.rtiles);
     p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_mi = pt.mi; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
-    { const char* tn = getenv("BTX_TAPS_TUNE"); p.pt_tune = tn ? atoi(tn) : 0; }
+    { const char* tn = tune_env("BTX_TAPS_TUNE"); p.pt_tune = tn ? atoi(tn) : 0; }
     p.pt_taps = pt.taps; p.pt_kg = pt.kg; p.pt_lds_g = pt.lds_g;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg, st)
                                  : launch_contract_patch_f32(kind, p, pl.nwg, st);
@@ -811,7 +822,7 @@ int btx_sample_weights(const BtxSampleItem* items, int n_items, const BtxRng* rn
       Plan pl;
       int rc = make_plan(s.geom, prec, 0, DBM, &pl);
       if (rc) return rc;
-      if (pl.K % 4) return BTX_E_UNSUPPORTED;
+      if (pl.K % (prec == BTX_PREC_BF16 ? 8 : 4)) return BTX_E_UNSUPPORTED;  // whole 16-byte granules of the tile image
       size_t one = 0;
       if (patch_wt_bytes(pl, s.geom, s.kind, prec, &one) >= 0xfff00000ULL) return BTX_E_UNSUPPORTED;
       PresampleItem& it = b.it[i];

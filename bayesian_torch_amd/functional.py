@@ -30,6 +30,20 @@ def get_precision():
     return _PRECISION
 
 
+_OUT_LAYOUT = "channels_last"
+
+
+def set_output_layout(layout):
+    """Memory format of the HIP path's convolution outputs.  "channels_last" (default): the kernels' native layout —
+    logical [N,C,*sp] shape with channels-last strides, zero extra passes, but `out.view(N, -1)` on a map with H,W > 1
+    raises like for any channels_last tensor (use `.reshape` / `.flatten`).  "contiguous": one extra HBM pass per layer
+    makes the outputs plain contiguous NCHW, for user code written against the reference that calls `.view`."""
+    global _OUT_LAYOUT
+    if layout not in ("channels_last", "contiguous"):
+        raise ValueError("layout must be 'channels_last' or 'contiguous'")
+    _OUT_LAYOUT = layout
+
+
 def _triple(v, nd, fill):
     """int or nd-tuple -> 3-tuple in (D, H, W) order, padded in front with `fill`."""
     if isinstance(v, int):
@@ -154,6 +168,9 @@ def _to_channels_last(x, op):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         return x2, x2.shape[0], (1, 1, 1), lambda o, sp: o.reshape(*lead, op.out_channels)
+    if x.dim() == op.nd + 1:  # unbatched [C,*sp], as ATen's convolutions accept
+        xp, nb, sp, restore = _to_channels_last(x.unsqueeze(0), op)
+        return xp, nb, sp, lambda o, s_: restore(o, s_).squeeze(0)
     if x.dim() != op.nd + 2:
         raise ValueError("expected %dD input, got %dD" % (op.nd + 2, x.dim()))
     nb = x.shape[0]
@@ -332,7 +349,8 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
                                                      "bf16" if act == _lib.ACT_BF16 else "f32", op.kernel[0],
                                                      op.kernel[1], op.kernel[2], op.in_channels, op.out_channels, m_rows)
         _LAUNCH_LOG.append((tag, flops, ev0, ev1))
-    return restore(out, out_sp)
+    res = restore(out, out_sp)
+    return res.contiguous() if (_OUT_LAYOUT == "contiguous" and op.nd > 0) else res
 
 
 def kl_hip(mu, rho, prior_mu, prior_sigma, prior_mu_t=None, prior_sigma_t=None, out=None, accumulate=False):

@@ -125,7 +125,6 @@ class _VariationalNd(BaseVariationalLayer_):
         self._btx_sample = 0
         self.precision = None  # None -> functional.get_precision(); or "f32" / "bf16"
         self.init_parameters()
-        self._btx_prior_versions = self._prior_versions()
         self.quant_prepare = False
 
     # ---- reference surface --------------------------------------------------------------------------------
@@ -152,11 +151,42 @@ class _VariationalNd(BaseVariationalLayer_):
             self.mu_bias.data.normal_(mean=mu0, std=0.1)
             self.rho_bias.data.normal_(mean=rho0, std=0.1)
 
-    def _prior_versions(self):
-        v = [self.prior_weight_mu._version, self.prior_weight_sigma._version]
-        if self.prior_bias_mu is not None:
-            v += [self.prior_bias_mu._version, self.prior_bias_sigma._version]
-        return tuple(v)
+    def _prior_key(self):
+        """identity + version of the prior buffers: changes on re-assignment (reference utils/util.py MOPED:
+        `layer.prior_weight_mu = det_layer.weight.data`), on `.to(device)` and on in-place writes (`fill_`, `copy_`)"""
+        bufs = [self.prior_weight_mu, self.prior_weight_sigma, self.prior_bias_mu, self.prior_bias_sigma]
+        return tuple((b.data_ptr(), b._version, tuple(b.shape)) if b is not None else None for b in bufs)
+
+    def _priors_are_scalar(self):
+        """True when every prior buffer still holds the constructor's scalars (the HIP KL then reads 8 B/element instead
+        of 16).  Verified against the buffers themselves whenever their identity/version changed — never inferred from
+        `_version` alone (a moved buffer restarts at 0, an in-place MOPED write can land on the old count).  `.data`
+        writes bump nothing: call `layer.refresh_priors()` after one."""
+        key = self._prior_key()
+        st = self.__dict__.get("_btx_prior_state")
+        if st is not None and st[0] == key:
+            return st[1]
+        ok = bool((self.prior_weight_mu == self.prior_mean).all()) and bool((self.prior_weight_sigma == self.prior_variance).all())
+        if ok and self.prior_bias_mu is not None:
+            ok = bool((self.prior_bias_mu == self.prior_mean).all()) and bool((self.prior_bias_sigma == self.prior_variance).all())
+        self.__dict__["_btx_prior_state"] = (key, ok)
+        return ok
+
+    def refresh_priors(self):
+        self.__dict__["_btx_prior_state"] = None
+
+    def __deepcopy__(self, memo):
+        """copies draw their OWN noise (the reference's copies advance the global generator independently): a deep copy
+        gets a fresh BTX-RNG layer id instead of sharing (seed, layer_id, sample) with its source"""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_btx_layer_id"] = _rng.next_layer_id()
+        for k in ("_btx_pre", "_btx_sample_dev", "_btx_prior_state", "_btx_plans"):
+            new.__dict__.pop(k, None)
+        return new
 
     def _use_hip(self, t):
         if _BACKEND == "torch" or not t.is_cuda:
@@ -189,7 +219,7 @@ class _VariationalNd(BaseVariationalLayer_):
             return kl
         # RNG-free and cheap (8 B/element, two launches per tensor): recomputed on every call rather than cached —
         # `param.data` mutations do not bump `_version`, so no cache key is trustworthy.
-        tens = self._prior_versions() != self._btx_prior_versions  # MOPED-style full-shape priors
+        tens = not self._priors_are_scalar()  # MOPED-style full-shape priors
         if tens:  # element order must match the logical prior tensors
             kl = BF.kl_hip(mu.contiguous(), rho.contiguous(), self.prior_mean, self.prior_variance,
                            self.prior_weight_mu, self.prior_weight_sigma)
@@ -235,6 +265,14 @@ class _VariationalNd(BaseVariationalLayer_):
             tag, op, src = ("plain",), op0, ()
         if src and op0.transposed:
             return None  # the transposed GEMM-major order is not [N][taps][C] of the padded geometry: per-launch sampling
+        # Only the LDS-DMA kernel family consumes pre-sampled tiles, and it takes a layer only when a K-stage (32 bf16 /
+        # 16 f32 channels) lies inside one filter tap; everything else (depthwise / odd grouped convolutions, C/groups
+        # not a multiple of the stage) samples in registers and would ignore — or, for K % 4 != 0, could not even
+        # produce — the tiles.
+        bk = 32 if (self.precision or prec) == "bf16" else 16
+        cg = op.in_channels // op.groups
+        if plan is None and cg % bk != 0:
+            return None
         kind = _lib.KIND_FLIPOUT if self._family == "flipout" else _lib.KIND_REPARAM
         key = (_rng.seed(), self._sample_key(sample_idx), self._btx_layer_id, self.precision or prec, tag)
         return key, (kind, op, mu_p, rho_p, self._btx_layer_id) + tuple(src)

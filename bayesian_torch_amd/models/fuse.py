@@ -2,8 +2,9 @@
 "the step either side of the path" (reference block structure: models/deterministic/resnet_large.py:46-62, 85-105,
 156-171).  `fuse_resnet(model)` rewrites, in place, every block that looks like a torchvision BasicBlock / Bottleneck
 (conv1,bn1,conv2,bn2[,conv3,bn3],downsample) whose convs are variational layers, and the stem (conv1,bn1,relu).
-BatchNorm statistics are folded ONCE into (scale, shift) buffers: call again after changing BN parameters.  Only for
-inference (`model.eval()`); the unfused model is the parity reference (tests/test_gpu_model.py).
+The module tree is untouched (state_dict keys of the fused and the unfused model are identical; checkpoints load either
+way) and the folded (scale, shift) follow the BatchNorm tensors.  Only for inference (`model.eval()`); the unfused model
+is the parity reference (tests/test_gpu_model.py).
 """
 import types
 
@@ -25,40 +26,47 @@ def _is_var(m):
     return hasattr(m, "forward_fused")
 
 
-class _Folded(nn.Module):
-    """conv (variational) + folded BN; keeps the BN module for state_dict compatibility but never calls it"""
+class _Folded:
+    """conv (variational) + eval-mode BN folded into the conv's store.  A plain object, NOT an nn.Module: it is attached
+    with object.__setattr__, so the module tree — and with it state_dict() / load_state_dict() keys, .to(), .parameters()
+    — is exactly that of the unfused model.  (scale, shift) are recomputed whenever the BN tensors change identity or
+    version (load_state_dict, .to(device), in-place edits)."""
 
     def __init__(self, conv, bn):
-        super().__init__()
         self.conv, self.bn = conv, bn
-        s, b = fold_bn(bn)
-        self.register_buffer("scale", s, persistent=False)
-        self.register_buffer("shift", b, persistent=False)
+        self._key, self._ss = None, None
 
-    def forward(self, x, residual=None, relu=False):
-        return self.conv.forward_fused(x, self.scale, self.shift, residual, relu)
+    def _scale_shift(self):
+        bn = self.bn
+        ts = [t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if key != self._key:
+            self._ss, self._key = fold_bn(bn), key
+        return self._ss
+
+    def __call__(self, x, residual=None, relu=False):
+        scale, shift = self._scale_shift()
+        return self.conv.forward_fused(x, scale, shift, residual, relu)
+
+
+def _downsample(self, x):
+    f = self.__dict__.get("_fds")
+    if f is not None:
+        return f(x)
+    return x if self.downsample is None else self.downsample(x)
 
 
 def _basic_forward(self, x):
-    idt = x if self.downsample is None else self.downsample(x)
+    idt = _downsample(self, x)
     y = self._f1(x, None, True)
     return self._f2(y, idt, True)
 
 
 def _bottleneck_forward(self, x):
-    idt = x if self.downsample is None else self.downsample(x)
+    idt = _downsample(self, x)
     y = self._f1(x, None, True)
     y = self._f2(y, None, True)
     return self._f3(y, idt, True)
-
-
-class _FoldedDownsample(nn.Module):
-    def __init__(self, seq):
-        super().__init__()
-        self.f = _Folded(seq[0], seq[1])
-
-    def forward(self, x):
-        return self.f(x)
 
 
 def fuse_resnet(model):
@@ -66,19 +74,20 @@ def fuse_resnet(model):
     for m in model.modules():
         names = [k for k in ("conv1", "bn1", "conv2", "bn2") if hasattr(m, k)]
         if len(names) == 4 and hasattr(m, "downsample") and _is_var(m.conv1) and _is_var(m.conv2):
-            m._f1, m._f2 = _Folded(m.conv1, m.bn1), _Folded(m.conv2, m.bn2)
+            object.__setattr__(m, "_f1", _Folded(m.conv1, m.bn1))
+            object.__setattr__(m, "_f2", _Folded(m.conv2, m.bn2))
             if hasattr(m, "conv3") and _is_var(m.conv3):
-                m._f3 = _Folded(m.conv3, m.bn3)
+                object.__setattr__(m, "_f3", _Folded(m.conv3, m.bn3))
                 m.forward = types.MethodType(_bottleneck_forward, m)
             else:
                 m.forward = types.MethodType(_basic_forward, m)
-            ds = m.downsample
+            ds = m.downsample  # stays the original nn.Sequential(conv, bn): same keys, the folded call goes beside it
             if isinstance(ds, nn.Sequential) and len(ds) == 2 and _is_var(ds[0]) and isinstance(ds[1], nn.BatchNorm2d):
-                m.downsample = _FoldedDownsample(ds)
+                object.__setattr__(m, "_fds", _Folded(ds[0], ds[1]))
             n += 1
     # stem: conv1 -> bn1 -> relu -> maxpool
     if hasattr(model, "conv1") and hasattr(model, "bn1") and hasattr(model, "maxpool") and _is_var(model.conv1):
-        model._stem = _Folded(model.conv1, model.bn1)
+        object.__setattr__(model, "_stem", _Folded(model.conv1, model.bn1))
 
         def pool(mp, y):
             """the stem's max-pool on the channels-last activations (own HBM-bound kernel when the geometry allows)"""

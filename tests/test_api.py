@@ -167,3 +167,94 @@ def test_batched_mc_flipout_mode_on_cpu():
     assert abs(float(u["samples"]) - 5) < 1e-6
     assert torch.allclose(u["mean_prob"].sum(1), torch.ones(4), atol=1e-5)
     assert abs(float(u["kl"]) - float(bt.get_kl_loss(net))) < 1e-4 * abs(float(bt.get_kl_loss(net)))
+
+
+# ---- round 2: advisor findings ----------------------------------------------------------------------------------
+def _small_net():
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 16, 3, stride=2, bias=False), torch.nn.Flatten(),
+                               torch.nn.Linear(16 * 7 * 7, 10))
+
+
+@pytest.mark.parametrize("typ", ["Reparameterization", "Flipout"])
+def test_moped_function_matches_reference_kl(golden, typ):
+    """utils.util.MOPED(): tensor priors + posterior init from a deterministic model; KL known answer from the reference"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.utils.util import MOPED
+    kat = golden["kat"]["models"]["moped_fn_" + typ]
+    torch.manual_seed(0)
+    det = _small_net()
+    det[1].running_mean.normal_()
+    det[1].running_var.uniform_(0.5, 2.0)
+    torch.manual_seed(1)
+    bnn = _small_net()
+    torch.manual_seed(1)
+    bnn = _small_net()
+    bt.dnn_to_bnn(bnn, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type=typ,
+                            moped_enable=False, moped_delta=0.5))
+    MOPED(bnn, _small_net(), det.state_dict(), kat["delta"])
+    assert float(bt.get_kl_loss(bnn)) == pytest.approx(kat["kl"], rel=1e-6)
+    assert float(bnn[1].running_mean.sum()) == pytest.approx(kat["bn_mean_sum"], rel=1e-6)
+    assert torch.equal(bnn[0].mu_kernel.data, det[0].weight.data) and torch.equal(bnn[0].prior_weight_mu, det[0].weight.data)
+
+
+def test_fuse_resnet_keeps_the_checkpoint_format():
+    """fuse_resnet must not change state_dict keys (advisor: 144 -> 263 keys, downsample entries lost)"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.resnet import resnet18
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    params = dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Flipout",
+                  moped_enable=False, moped_delta=0.5)
+    torch.manual_seed(0)
+    a = resnet18()
+    bt.dnn_to_bnn(a, params)
+    keys = list(a.state_dict().keys())
+    torch.manual_seed(1)
+    b = resnet18()
+    bt.dnn_to_bnn(b, params)
+    assert fuse_resnet(b) == 9
+    assert list(b.state_dict().keys()) == keys
+    b.load_state_dict(a.state_dict(), strict=True)     # unfused checkpoint -> fused model
+    a.load_state_dict(b.state_dict(), strict=True)     # and back
+    assert isinstance(b.layer2[0].downsample, torch.nn.Sequential)
+    x = torch.randn(1, 3, 224, 224)
+    torch.manual_seed(5)
+    ya = a.eval()(x)
+    torch.manual_seed(5)
+    yb = b.eval()(x)                                   # CPU: forward_fused == the same ATen chain + affine
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4 * float(ya.abs().max()))
+    b.bn1.running_var.mul_(4.0)                        # folded scale/shift follow the BN tensors
+    torch.manual_seed(5)
+    assert not torch.allclose(b(x), yb)
+
+
+def test_deepcopy_gets_its_own_noise_identity_and_prior_detection():
+    import copy
+    from bayesian_torch_amd import layers as L
+    a = L.Conv2dFlipout(8, 8, 3)
+    b = copy.deepcopy(a)
+    assert b._btx_layer_id != a._btx_layer_id
+    assert torch.equal(a.mu_kernel, b.mu_kernel) and b.mu_kernel.data_ptr() != a.mu_kernel.data_ptr()
+    m = copy.deepcopy(torch.nn.Sequential(a, torch.nn.ReLU()))
+    assert m[0]._btx_layer_id not in (a._btx_layer_id, b._btx_layer_id)
+    assert a._priors_are_scalar()
+    a.prior_weight_mu.copy_(torch.randn_like(a.prior_weight_mu))      # in-place MOPED-style write
+    assert not a._priors_are_scalar()
+    a.prior_weight_mu.fill_(a.prior_mean)
+    assert a._priors_are_scalar()
+    a.prior_weight_mu = torch.ones_like(a.prior_weight_mu)             # buffer re-assignment (reference MOPED)
+    assert not a._priors_are_scalar()
+
+
+def test_presample_skips_layers_the_dma_kernels_do_not_take():
+    """advisor: a depthwise / odd grouped conv queued for btx_sample_weights fails the whole batch (K % 4 != 0)"""
+    from bayesian_torch_amd import layers as L
+    dw = L.Conv2dFlipout(16, 16, 3, padding=1, groups=16)
+    dw._btx_last_xshape = (2, 16, 8, 8)
+    assert dw.presample_item(0, "bf16") is None and dw.presample_item(0, "f32") is None
+    g2 = L.Conv2dFlipout(48, 48, 3, padding=1, groups=2)                # C/groups = 24: register-staged kernel
+    g2._btx_last_xshape = (2, 48, 8, 8)
+    assert g2.presample_item(0, "bf16") is None
+    ok = L.Conv2dFlipout(64, 64, 3, padding=1)
+    ok._btx_last_xshape = (2, 64, 8, 8)
+    assert ok.presample_item(0, "bf16") is not None and ok.presample_item(0, "f32") is not None

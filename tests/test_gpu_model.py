@@ -413,3 +413,97 @@ def test_graphed_mc_replays_equal_eager_samples():
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_depthwise_and_grouped_layers_under_the_mc_driver():
+    """advisor (round 1): mc_forward / GraphedMC presample every CUDA layer; depthwise and odd grouped convolutions
+    (K % 4 != 0, C/groups % 8 != 0) used to fail the whole sampling batch from the second MC sample on"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    bt.manual_seed(4)
+    torch.manual_seed(3)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c0 = L.Conv2dFlipout(3, 32, 3, padding=1)
+            self.dw = L.Conv2dFlipout(32, 32, 3, padding=1, groups=32)      # depthwise: K = 9
+            self.pw = L.Conv2dFlipout(32, 48, 1)
+            self.g3 = L.Conv2dReparameterization(48, 48, 3, 1, 1, 1, 2)     # C/groups = 24
+            self.fc = L.LinearFlipout(48, 10)
+
+        def forward(self, x):
+            for c in (self.c0, self.dw, self.pw, self.g3):
+                x = torch.relu(c(x, return_kl=False))
+            return self.fc(x.mean((2, 3)), return_kl=False)
+
+    net = Net().to(dev).eval()
+    bt.assign_layer_ids(net)
+    x = torch.randn(4, 3, 12, 12, device=dev)
+    for prec in ("f32", "bf16"):
+        bt.set_precision(prec)
+        try:
+            packed = mc.mc_forward(net, x, 4)
+            ys = []
+            with torch.no_grad():
+                for s in range(4):
+                    bt.set_sample_index(net, s)
+                    ys.append(torch.softmax(net(x).float(), 1))
+            u = mc.unpack(packed, 4, 10)
+            assert torch.allclose(u["mean_prob"], torch.stack(ys).mean(0), atol=1e-5), prec
+            g = mc.GraphedMC(net, x, kl=0.0)
+            for s in range(4):
+                g.run(s)
+            torch.cuda.synchronize()
+            assert torch.allclose(g.packed, packed, atol=1e-5), prec
+            g.close()
+        finally:
+            bt.set_precision("f32")
+
+
+def test_moped_function_tensor_priors_on_the_gpu(golden):
+    """utils.util.MOPED() + HIP KL with full-shape prior tensors == the reference's KL"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.utils.util import MOPED
+    from test_api import _small_net
+    dev = _dev()
+    kat = golden["kat"]["models"]["moped_fn_Flipout"]
+    torch.manual_seed(0)
+    det = _small_net()
+    det[1].running_mean.normal_()
+    det[1].running_var.uniform_(0.5, 2.0)
+    torch.manual_seed(1)
+    bnn = _small_net()
+    torch.manual_seed(1)
+    bnn = _small_net()
+    bt.dnn_to_bnn(bnn, dict(PRIOR, type="Flipout", moped_enable=False))
+    bnn = bnn.to(dev)
+    kl_scalar = float(bt.get_kl_loss(bnn))
+    MOPED(bnn, _small_net().to(dev), {k: v.to(dev) for k, v in det.state_dict().items()}, kat["delta"])
+    with torch.no_grad():
+        kl = float(bt.get_kl_loss(bnn))
+    assert abs(kl - kat["kl"]) <= 1e-5 * kat["kl"], (kl, kat["kl"])
+    assert abs(kl_scalar - kl) > 1.0  # the tensor prior really was used
+
+
+def test_unbatched_input_and_contiguous_output_layout():
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    torch.manual_seed(0)
+    layer = L.Conv2dFlipout(16, 32, 3, padding=1).to(dev)
+    x = torch.randn(2, 16, 9, 9, device=dev)
+    with torch.no_grad():
+        y = layer._forward_hip(x, sample_idx=3)
+        y1 = layer._forward_hip(x[0], sample_idx=3)          # unbatched [C,H,W], as F.conv2d accepts
+        assert y1.shape == (32, 9, 9)
+        bt.set_output_layout("contiguous")
+        try:
+            yc = layer._forward_hip(x, sample_idx=3)
+            assert yc.is_contiguous() and torch.equal(yc, y)
+            assert yc.view(2, -1).shape == (2, 32 * 81)      # user code written against the reference
+        finally:
+            bt.set_output_layout("channels_last")
+        assert not y.is_contiguous()

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""In-process A/B of kernel variants on the ResNet18 / ResNet50 convolution shapes: GPU time of one layer call (all its
+"""(needs a library built with -DBTX_TUNING: `bash tools/build_variants.sh tune "-DBTX_TUNING"`, then
+BTX_LIB=build_variants/libbtx_tune.so — the shipped libbtx.so ignores the A/B environment variables)
+
+In-process A/B of kernel variants on the ResNet18 / ResNet50 convolution shapes: GPU time of one layer call (all its
 kernels), `reps` calls captured in a hipGraph and replayed (no host launch overhead), interleaved rounds.
 
 usage: python tools/kbench.py [--shapes s1 ...] [--env "A=1,B=2" ...] [--rounds 3] [--typ Flipout] [--prec bf16]

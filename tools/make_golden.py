@@ -171,6 +171,31 @@ def main():
     w = torch.linspace(-0.3, 0.3, 13)
     kat["get_rho"] = dict(w=w.tolist(), delta=0.5, rho=ref_get_rho(w, 0.5).tolist())
 
+    # utils.util.MOPED(): tensor-valued priors + posterior init from a deterministic model (reference utils/util.py:72-136)
+    import tempfile
+    from bayesian_torch.utils.util import MOPED as ref_MOPED
+
+    def small_net():
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                                   torch.nn.Conv2d(8, 16, 3, stride=2, bias=False), torch.nn.Flatten(),
+                                   torch.nn.Linear(16 * 7 * 7, 10))
+    torch.manual_seed(0)
+    det = small_net()
+    det[1].running_mean.normal_()
+    det[1].running_var.uniform_(0.5, 2.0)
+    torch.manual_seed(1)
+    bnn = small_net()
+    for typ in ("Reparameterization", "Flipout"):
+        torch.manual_seed(1)
+        bnn = small_net()
+        ref_dnn_to_bnn(bnn, dict(base, type=typ))
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            torch.save(det.state_dict(), f.name)
+            ref_MOPED(bnn, small_net(), f.name, 0.1)
+        kat["moped_fn_" + typ] = dict(kl=float(ref_get_kl_loss(bnn)), delta=0.1,
+                                      bn_mean_sum=float(bnn[1].running_mean.sum()))
+        print("MOPED()", typ, "kl =", repr(kat["moped_fn_" + typ]["kl"]))
+
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
 
