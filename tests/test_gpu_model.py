@@ -305,7 +305,10 @@ def test_presample_of_padded_layouts_is_bit_identical():
                 bt.set_sample_index(net, 6)
                 y0 = net(x)
                 bt.set_sample_index(net, 6, presample=True)
-                assert sum(1 for mod in net.modules() if getattr(mod, "_btx_pre", None) is not None) == 5
+                # only the layers the LDS-DMA kernel family takes are sampled ahead (the register-staged kernel samples in
+                # registers and ignores tiles): the row-fused stem, and in f32 the 720-wide Linear (720 % 16 == 0)
+                n_pre = sum(1 for mod in net.modules() if getattr(mod, "_btx_pre", None) is not None)
+                assert n_pre == (2 if prec == "f32" else 1), (prec, n_pre)
                 y1 = net(x)
             assert torch.equal(y0, y1), prec
         finally:
