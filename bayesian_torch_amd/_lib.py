@@ -9,10 +9,10 @@ _LIB = None
 KIND_REPARAM, KIND_FLIPOUT = 0, 1
 ACT_F32, ACT_BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
-FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER = 1, 2, 4, 8, 16, 32
+FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER, FLAG_SWAP_SIGNS = 1, 2, 4, 8, 16, 32, 64
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class BtxError(RuntimeError):
@@ -46,7 +46,14 @@ class SampleItem(ctypes.Structure):
                 ("src_KW", ctypes.c_int32), ("src_C", ctypes.c_int32)]
 
 
-EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss",
+class KlItem(ctypes.Structure):
+    _fields_ = [("mu", ctypes.c_void_p), ("rho", ctypes.c_void_p), ("prior_mu_t", ctypes.c_void_p),
+                ("prior_sigma_t", ctypes.c_void_p), ("dmu", ctypes.c_void_p), ("drho", ctypes.c_void_p),
+                ("prior_mu", ctypes.c_float), ("prior_sigma", ctypes.c_float), ("n", ctypes.c_size_t)]
+
+
+EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss", "btx_kl_model_workspace_bytes",
+           "btx_kl_gauss_model", "btx_kl_gauss_model_bwd",
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
            "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
 
@@ -75,6 +82,12 @@ def lib():
     L.btx_kl_workspace_bytes.argtypes = [sz]
     L.btx_kl_gauss.restype = i32
     L.btx_kl_gauss.argtypes = [vp, vp, sz, vp, vp, f32, f32, vp, u32, vp, sz, vp]
+    L.btx_kl_model_workspace_bytes.restype = sz
+    L.btx_kl_model_workspace_bytes.argtypes = [i32]
+    L.btx_kl_gauss_model.restype = i32
+    L.btx_kl_gauss_model.argtypes = [ctypes.POINTER(KlItem), i32, vp, vp, sz, vp]
+    L.btx_kl_gauss_model_bwd.restype = i32
+    L.btx_kl_gauss_model_bwd.argtypes = [ctypes.POINTER(KlItem), i32, vp, vp]
     L.btx_contract_workspace_bytes.restype = sz
     L.btx_contract_workspace_bytes.argtypes = [ctypes.POINTER(Geom), i32, i32, i32, u32]
     L.btx_contract_fwd.restype = i32

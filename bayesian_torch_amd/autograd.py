@@ -1,0 +1,194 @@
+"""Training path of the variational layers on the HIP backend (reference README.md:114-125:
+`output = model(x); kl = get_kl_loss(model); loss = ce(output, y) + kl / batch_size; loss.backward()`).
+
+BTX-RNG noise is a pure function of (seed, sample_idx, layer_id, element index), so nothing but (x, mu, rho) is saved for
+the backward: eps and the Flipout signs are regenerated.
+
+  forward        the fused HIP contraction (btx_contract_fwd), unchanged
+  dx             ALSO btx_contract_fwd: the data gradient of  y = conv(x, mu) + s_out * conv(x * s_in, sigma*eps)  is
+                 dx = convT(dy, mu) + s_in * convT(dy * s_out, sigma*eps)  — the same Flipout-shaped contraction on the
+                 transposed geometry (stride-1 2-D convolutions: on the flipped kernel, which the tap-unrolled kernel
+                 takes) with the two sign streams exchanged (BTX_FLAG_SWAP_SIGNS) and the forward's eps passed explicitly
+  KL, dKL        btx_kl_gauss_model / btx_kl_gauss_model_bwd (one launch for the whole model)
+  dmu, drho      dW = corr(x, dy) [and corr(x*s_in, dy*s_out) for Flipout] is computed by ATen (MIOpen / rocBLAS) in this
+                 round — a pixel-reduction GEMM with both operands transposed relative to the channels-last storage, the
+                 one contraction libbtx does not have yet; dmu = dW, drho = dW_delta * eps * sigmoid(rho) follow here.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from . import functional as BF
+from . import rng as _rng
+
+
+def _weight_grad(x, dy, w_shape, op):
+    """corr(x, dy) in the layer's logical weight layout (ATen)"""
+    nd = op.nd
+    if nd == 0:
+        return dy.reshape(-1, dy.shape[-1]).t().float() @ x.reshape(-1, x.shape[-1]).float()
+    st, pd, dl = op.stride[3 - nd:], op.padding[3 - nd:], op.dilation[3 - nd:]
+    if not op.transposed:
+        fn = {1: torch.nn.grad.conv1d_weight, 2: torch.nn.grad.conv2d_weight, 3: torch.nn.grad.conv3d_weight}[nd]
+        return fn(x, w_shape, dy, st, pd, dl, op.groups).float()
+    w = torch.zeros(w_shape, dtype=x.dtype, device=x.device, requires_grad=True)
+    with torch.enable_grad():
+        out = BF.contract_aten(x, w, None, op)
+    return torch.autograd.grad(out, w, dy)[0].float()
+
+
+def _data_grad_hip(layer, dy, x_shape, nz, sample_idx, hashed_signs):
+    """dx through libbtx: the contraction of dy with the layer's own (mu, sigma*eps) on the transposed geometry"""
+    op = layer._op
+    mu, rho = layer._w()
+    mu, rho, eps = mu.detach(), rho.detach(), nz["eps_w"]
+    kind = _lib.KIND_FLIPOUT if layer._family == "flipout" else _lib.KIND_REPARAM
+    nd = op.nd
+    if nd == 0:
+        opT = BF.OpDesc(0, op.out_channels, op.in_channels)
+        w_mu, w_rho, w_eps = mu.t(), rho.t(), eps.t()
+    elif op.transposed:
+        # forward was a transposed convolution: its data gradient is the plain convolution with the same weight tensor
+        opT = BF.OpDesc(nd, op.out_channels, op.in_channels, op.kernel[3 - nd:], op.stride[3 - nd:], op.padding[3 - nd:],
+                        op.dilation[3 - nd:], op.groups)
+        w_mu, w_rho, w_eps = mu, rho, eps
+    elif nd == 2 and op.groups == 1 and op.stride == (1, 1, 1):
+        # stride 1: convT(dy, W) == conv(dy, flip(W)^T) with padding d*(k-1) - p: a plain 3x3 again (tap-unrolled kernel)
+        pad = tuple(d * (k - 1) - p for d, k, p in zip(op.dilation[1:], op.kernel[1:], op.padding[1:]))
+        if min(pad) < 0:
+            raise _lib.BtxError("data gradient: padding larger than the dilated kernel extent is not supported")
+        opT = BF.OpDesc(2, op.out_channels, op.in_channels, op.kernel[1:], 1, pad, op.dilation[1:], 1)
+        tr = lambda t: t.transpose(0, 1).flip(2, 3)  # noqa: E731
+        w_mu, w_rho, w_eps = tr(mu), tr(rho), tr(eps)
+    else:
+        outpad = tuple((i + 2 * p - d * (k - 1) - 1) % s for i, p, d, k, s in
+                       zip(x_shape[2:], op.padding[3 - nd:], op.dilation[3 - nd:], op.kernel[3 - nd:], op.stride[3 - nd:]))
+        opT = BF.OpDesc(nd, op.out_channels, op.in_channels, op.kernel[3 - nd:], op.stride[3 - nd:], op.padding[3 - nd:],
+                        op.dilation[3 - nd:], op.groups, transposed=True, output_padding=outpad)
+        w_mu, w_rho, w_eps = mu, rho, eps
+    noise = {"eps_w": w_eps}
+    flags = 0
+    if kind == _lib.KIND_FLIPOUT:
+        if hashed_signs:
+            flags = _lib.FLAG_SWAP_SIGNS
+        else:  # padded forward layouts (C % 8 != 0, row-fused stems): the signs as tensors
+            noise["sign_in"], noise["sign_out"] = nz["sign_out"], nz["sign_in"]
+    dx = BF.contract_hip(kind, dy, BF.pack_gemm_major(w_mu.float(), opT), BF.pack_gemm_major(w_rho.float(), opT), None, None,
+                         opT, _rng.seed(), sample_idx, layer._btx_layer_id, prec=layer.precision, noise=noise,
+                         extra_flags=flags)
+    return dx.reshape(x_shape) if nd == 0 else dx
+
+
+class ContractFn(torch.autograd.Function):
+    """y = layer(x) on the HIP backend with gradients w.r.t. x, mu, rho, mu_b, rho_b"""
+
+    @staticmethod
+    def forward(ctx, layer, sample_idx, x, mu, rho, mu_b, rho_b):
+        with torch.no_grad():
+            out = layer._forward_hip(x, sample_idx=sample_idx)
+        ctx.layer, ctx.sample_idx = layer, sample_idx
+        ctx.save_for_backward(x, rho, rho_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer, s = ctx.layer, ctx.sample_idx
+        x, rho, rho_b = ctx.saved_tensors
+        op = layer._op
+        flip = layer._family == "flipout"
+        dy = dy.contiguous() if op.nd == 0 else dy
+        with torch.no_grad():
+            nz = layer.materialize_noise(s, tuple(x.shape), tuple(dy.shape), x.dtype)
+            eps = nz["eps_w"]
+            dsig = torch.sigmoid(rho.detach())
+            w_shape = tuple(rho.shape)
+            dx = dmu = drho = dmu_b = drho_b = None
+            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+                dW = _weight_grad(x, dy, w_shape, op)
+                if flip:
+                    si = nz["sign_in"].to(x.dtype)
+                    so = nz["sign_out"].to(dy.dtype)
+                    dWd = _weight_grad(x * si.reshape(x.shape), dy * so.reshape(dy.shape), w_shape, op)
+                else:
+                    dWd = dW
+                dmu = dW
+                drho = dWd * eps * dsig
+            if rho_b is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]):
+                red = tuple(i for i in range(dy.dim()) if i != (dy.dim() - 1 if op.nd == 0 else 1))
+                db = dy.float().sum(red)
+                dbd = (dy.float() * nz["sign_out"].reshape(dy.shape).float()).sum(red) if flip else db
+                dmu_b = db
+                drho_b = dbd * nz["eps_b"] * torch.sigmoid(rho_b.detach())
+            if ctx.needs_input_grad[2]:
+                plan = layer._rowfuse_plan(x) if op.nd == 2 else None
+                hashed = flip and layer._btx_cpad is None and plan is None
+                dx = _data_grad_hip(layer, dy, tuple(x.shape), nz, s, hashed)
+                if dx.dtype != x.dtype:
+                    dx = dx.to(x.dtype)
+        return None, None, dx, dmu, drho, dmu_b, drho_b
+
+
+class KlFn(torch.autograd.Function):
+    """sum of the per-tensor mean KLs of `n` (mu, rho) pairs on the HIP backend, with gradients"""
+
+    @staticmethod
+    def forward(ctx, meta, *params):
+        # meta: per pair (prior_mu, prior_sigma, prior_mu_t | None, prior_sigma_t | None, op | None)
+        ctx.meta = meta
+        ctx.save_for_backward(*params)
+        return BF.kl_model_hip(_entries(meta, params))
+
+    @staticmethod
+    def backward(ctx, g):
+        params = ctx.saved_tensors
+        meta = ctx.meta
+        entries = _entries(meta, params)
+        grads, outs = [], []
+        for i, (pm, ps, pmt, pst, op) in enumerate(meta):
+            mu, rho = params[2 * i], params[2 * i + 1]
+            if pmt is None and op is not None:  # storage-order views: gradients share the parameter's strides
+                gm, gr = torch.empty_like(mu), torch.empty_like(rho)
+                grads.append((BF.gemm_major_view(gm, op), BF.gemm_major_view(gr, op)))
+            else:
+                gm = torch.empty(mu.shape, dtype=torch.float32, device=mu.device)
+                gr = torch.empty(rho.shape, dtype=torch.float32, device=rho.device)
+                grads.append((gm, gr))
+            outs += [gm, gr]
+        BF.kl_model_bwd_hip(entries, grads, g)
+        return (None,) + tuple(outs)
+
+
+def _entries(meta, params):
+    out = []
+    for i, (pm, ps, pmt, pst, op) in enumerate(meta):
+        mu, rho = params[2 * i].detach(), params[2 * i + 1].detach()
+        if pmt is None and op is not None:
+            out.append((BF.gemm_major_view(mu, op), BF.gemm_major_view(rho, op), pm, ps, None, None))
+        else:  # element order must match the logical prior tensors
+            out.append((mu.contiguous(), rho.contiguous(), pm, ps,
+                        pmt.detach().contiguous() if pmt is not None else None,
+                        pst.detach().contiguous() if pst is not None else None))
+    return out
+
+
+def kl_pairs(layer):
+    """[(mu, rho, meta)] of one variational layer for KlFn / kl_model_hip"""
+    mu, rho = layer._w()
+    tens = not layer._priors_are_scalar()
+    pairs = [(mu, rho, (layer.prior_mean, layer.prior_variance, layer.prior_weight_mu if tens else None,
+                        layer.prior_weight_sigma if tens else None, layer._op))]
+    if layer.mu_bias is not None:
+        pairs.append((layer.mu_bias, layer.rho_bias, (layer.prior_mean, layer.prior_variance,
+                                                      layer.prior_bias_mu if tens else None,
+                                                      layer.prior_bias_sigma if tens else None, None)))
+    return pairs
+
+
+def kl_of_layers(layers):
+    """get_kl_loss on the HIP backend: one launch for every tensor of every layer; differentiable when needed"""
+    pairs = [pr for layer in layers for pr in kl_pairs(layer)]
+    params = [t for mu, rho, _ in pairs for t in (mu, rho)]
+    meta = tuple(m for _, _, m in pairs)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in params):
+        return KlFn.apply(meta, *params)
+    return BF.kl_model_hip(_entries(meta, params))

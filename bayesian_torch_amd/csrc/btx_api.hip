@@ -87,6 +87,77 @@ __global__ __launch_bounds__(64) void kl_final_kernel(const double* __restrict__
   }
 }
 
+// Batched form: every parameter tensor of a model in ONE launch (+ one final reduce).  get_kl_loss() of ResNet18 is 22
+// tensors; launched one by one (2 launches each) the reduction ran at ~3 % of the HBM roofline, launch-bound.
+constexpr int KL_MAX_ITEMS = 48;
+struct KlItemDev {
+  const float* mu; const float* rho; const float* pmu_t; const float* psig_t;
+  float* dmu; float* drho;  // backward only
+  float pmu, psig;
+  uint32_t n, first_block;
+};
+struct KlBatchDev {
+  KlItemDev it[KL_MAX_ITEMS];
+  int n;
+  uint32_t total_blocks;
+};
+__global__ __launch_bounds__(KL_BLOCK) void kl_model_partial_kernel(const KlBatchDev b, double* __restrict__ partials) {
+  int i = 0;
+  for (int j = 1; j < b.n; ++j)
+    if (blockIdx.x >= b.it[j].first_block) i = j;
+  const KlItemDev& it = b.it[i];
+  const uint32_t nblk = (i + 1 < b.n ? b.it[i + 1].first_block : b.total_blocks) - it.first_block;
+  const size_t nthreads = (size_t)nblk * KL_BLOCK;
+  const size_t t = (size_t)(blockIdx.x - it.first_block) * KL_BLOCK + threadIdx.x;
+  double acc = 0.0;
+  const bool vec_ok = ((((uintptr_t)it.mu | (uintptr_t)it.rho) & 15) == 0) && !it.pmu_t && !it.psig_t;
+  const size_t n = it.n, n4 = n >> 2;
+  if (vec_ok) {
+    for (size_t k = t; k < n4; k += nthreads) {
+      const f32x4 m = ((const f32x4*)it.mu)[k];
+      const f32x4 r = ((const f32x4*)it.rho)[k];
+      float s_ = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_ += kl_term(m[e], r[e], it.pmu, it.psig);
+      acc += (double)s_;
+    }
+    for (size_t k = (n4 << 2) + t; k < n; k += nthreads) acc += (double)kl_term(it.mu[k], it.rho[k], it.pmu, it.psig);
+  } else {
+    for (size_t k = t; k < n; k += nthreads)
+      acc += (double)kl_term(it.mu[k], it.rho[k], it.pmu_t ? it.pmu_t[k] : it.pmu, it.psig_t ? it.psig_t[k] : it.psig);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double wsum[KL_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s_ = 0.0;
+#pragma unroll
+    for (int w = 0; w < KL_BLOCK / 64; ++w) s_ += wsum[w];
+    // the reference takes the MEAN of each tensor, rounds it to f32 and sums the means: keep the mean scaling per tensor
+    partials[blockIdx.x] = s_ / (double)n;
+  }
+}
+// d(mean KL)/d(mu, rho) of every tensor, scaled by the upstream gradient (a device scalar: no host sync)
+__global__ __launch_bounds__(KL_BLOCK) void kl_model_bwd_kernel(const KlBatchDev b, const float* __restrict__ gout) {
+  int i = 0;
+  for (int j = 1; j < b.n; ++j)
+    if (blockIdx.x >= b.it[j].first_block) i = j;
+  const KlItemDev& it = b.it[i];
+  const uint32_t nblk = (i + 1 < b.n ? b.it[i + 1].first_block : b.total_blocks) - it.first_block;
+  const float g = gout[0] / (float)it.n;
+  for (size_t k = (size_t)(blockIdx.x - it.first_block) * KL_BLOCK + threadIdx.x; k < it.n; k += (size_t)nblk * KL_BLOCK) {
+    const float mu = it.mu[k], rho = it.rho[k];
+    const float pm = it.pmu_t ? it.pmu_t[k] : it.pmu, ps = it.psig_t ? it.psig_t[k] : it.psig;
+    const float sig = log1pf(expf(rho));
+    const float dsig = 1.0f / (1.0f + expf(-rho));  // d softplus / d rho
+    const float ips2 = 1.0f / (ps * ps);
+    it.dmu[k] = g * (mu - pm) * ips2;
+    it.drho[k] = g * (sig * ips2 - 1.0f / sig) * dsig;
+  }
+}
+
 // ========================================================================================================
 // noise materialisation (BTX-RNG v1)
 // ========================================================================================================
@@ -346,6 +417,63 @@ int btx_kl_gauss(const float* mu, const float* rho, size_t n, const float* prior
                      prior_mu, prior_sigma, (double*)ws);
   hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblocks, 1.0 / (double)n, kl_out,
                      (flags & BTX_FLAG_KL_ACCUM) ? 1 : 0);
+  return (int)hipGetLastError();
+}
+
+static int kl_fill_batch(const BtxKlItem* items, int base, int n_items, bool bwd, KlBatchDev* b) {
+  memset(b, 0, sizeof(*b));
+  b->n = n_items - base < KL_MAX_ITEMS ? n_items - base : KL_MAX_ITEMS;
+  uint32_t blocks = 0;
+  for (int i = 0; i < b->n; ++i) {
+    const BtxKlItem& s = items[base + i];
+    if (!s.mu || !s.rho || (bwd && (!s.dmu || !s.drho))) return BTX_E_NULL;
+    if (s.n == 0 || s.n > 0xffffffffull) return BTX_E_SHAPE;
+    KlItemDev& it = b->it[i];
+    it.mu = s.mu; it.rho = s.rho; it.pmu_t = s.prior_mu_t; it.psig_t = s.prior_sigma_t; it.dmu = s.dmu; it.drho = s.drho;
+    it.pmu = s.prior_mu; it.psig = s.prior_sigma; it.n = (uint32_t)s.n; it.first_block = blocks;
+    uint32_t nb = (uint32_t)((s.n + (size_t)KL_BLOCK * 8 - 1) / ((size_t)KL_BLOCK * 8));
+    if (nb < 1) nb = 1;
+    if (nb > 256u) nb = 256u;
+    blocks += nb;
+  }
+  b->total_blocks = blocks;
+  return 0;
+}
+
+size_t btx_kl_model_workspace_bytes(int n_items) {
+  if (n_items <= 0) return 0;
+  return (size_t)((n_items + KL_MAX_ITEMS - 1) / KL_MAX_ITEMS) * KL_MAX_ITEMS * 256 * sizeof(double);
+}
+
+int btx_kl_gauss_model(const BtxKlItem* items, int n_items, float* kl_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!items || !kl_out || !ws) return BTX_E_NULL;
+  if (n_items <= 0) return BTX_E_SHAPE;
+  if (ws_bytes < btx_kl_model_workspace_bytes(n_items)) return BTX_E_WORKSPACE;
+  if (((uintptr_t)ws & 7) != 0) return BTX_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)ws;
+  int total = 0;
+  for (int base = 0; base < n_items; base += KL_MAX_ITEMS) {
+    KlBatchDev b;
+    int rc = kl_fill_batch(items, base, n_items, false, &b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kl_model_partial_kernel, dim3(b.total_blocks), dim3(KL_BLOCK), 0, st, b, part + total);
+    total += (int)b.total_blocks;
+  }
+  hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(64), 0, st, (const double*)part, total, 1.0, kl_out, 0);
+  return (int)hipGetLastError();
+}
+
+int btx_kl_gauss_model_bwd(const BtxKlItem* items, int n_items, const float* grad_out, void* stream) {
+  if (!items || !grad_out) return BTX_E_NULL;
+  if (n_items <= 0) return BTX_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < n_items; base += KL_MAX_ITEMS) {
+    KlBatchDev b;
+    int rc = kl_fill_batch(items, base, n_items, true, &b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kl_model_bwd_kernel, dim3(b.total_blocks), dim3(KL_BLOCK), 0, st, b, grad_out);
+  }
   return (int)hipGetLastError();
 }
 
@@ -730,8 +858,11 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   p.seed_lo = (uint32_t)rng->seed; p.seed_hi = (uint32_t)(rng->seed >> 32);
   p.sample = rng->sample_idx; p.layer = rng->layer_id;
   p.sample_ptr = rng->sample_idx_dev;
-  sign_keys(rng, BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
-  sign_keys(rng, BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
+  // BTX_FLAG_SWAP_SIGNS (data gradient of a Flipout layer): the op's input carries the forward's s_out, its output the
+  // forward's s_in
+  p.swap_signs = (flags & BTX_FLAG_SWAP_SIGNS) ? 1 : 0;
+  sign_keys(rng, p.swap_signs ? BTX_STREAM_SIGN_OUT : BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
+  sign_keys(rng, p.swap_signs ? BTX_STREAM_SIGN_IN : BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
   {
     const long long in_elems = (long long)g->NB * g->D * g->H * g->W * g->C;
     const long long xb = in_elems * (act_dtype == BTX_ACT_BF16 ? 2 : 4), wb = (long long)g->N * pl.K * 4;
@@ -743,6 +874,19 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   p.pt_nw = dma_nw;
   p.fd_inner = make_fastdiv((uint32_t)(pl.ntiles * g->groups * pl.ksplits)); p.fd_ksplits = make_fastdiv((uint32_t)pl.ksplits);
   p.fd_ntiles = make_fastdiv((uint32_t)pl.ntiles); p.fd_rtiles = make_fastdiv(1u);
+  p.fd_mtiles = make_fastdiv((uint32_t)(pl.mtiles > 0 ? pl.mtiles : 1));
+  {
+    // XCD affinity of the workgroup order (block b runs on XCD b % 8; the remap gives every XCD a contiguous range of
+    // logical ids): keep in one L2 whichever operand the neighbours would otherwise re-fetch more bytes of — the
+    // activations of a pixel tile (read by its ntiles*ksplits workgroups) or the sampled weights of an (n-tile, k-split)
+    // (read by its mtiles workgroups).  ResNet18 layer4 (7x7 maps, 512 channels): 9.4 MB of weight tiles against 3.2 MB
+    // of activations; measured HBM-side traffic of that launch in round 1 order: 92 MB for 25 MB algorithmic.
+    // Weight tiles up to ~2 MB stay resident in every XCD's 4-MB L2 whatever the order; beyond that the weight-major
+    // order is what keeps them on chip.
+    const double w_b = (prec == BTX_PREC_BF16 ? 2.0 : 4.0) * (double)g->N * pl.K * (kind == BTX_KIND_FLIPOUT ? 2 : 1);
+    p.wg_order = (dma && pl.mtiles > 1 && w_b >= 2.0 * 1048576.0) ? 1 : 0;
+    if (tune_env("BTX_WG_ORDER")) p.wg_order = atoi(tune_env("BTX_WG_ORDER"));
+  }
   p.fd_Wo = make_fastdiv((uint32_t)pl.Wo); p.fd_Ho = make_fastdiv((uint32_t)pl.Ho); p.fd_Do = make_fastdiv((uint32_t)pl.Do);
   if (dma) {
     p.wt = sampled_w ? (void*)sampled_w : (void*)((unsigned char*)ws + wt_off);

@@ -119,6 +119,10 @@ struct ContractParams {
   int pt_G, pt_R, pt_Rp, pt_Wp, pt_PP, pt_NI, pt_rtiles;
   FastDiv fd_Wo, fd_Ho, fd_Do, fd_ptWp, fd_ptRp, fd_ptR;
   FastDiv fd_inner, fd_ksplits, fd_ntiles, fd_Cg, fd_KW, fd_KH, fd_rtiles;  // wave-uniform index splits
+  FastDiv fd_mtiles;
+  int swap_signs;  // BTX_FLAG_SWAP_SIGNS: input signs from stream SIGN_OUT, output signs from SIGN_IN
+  int wg_order;  // 0: workgroups that share a pixel tile are neighbours (same XCD L2 holds the activations);
+                 // 1: workgroups that share a weight tile are (layers whose sampled weights outweigh their activations)
   void* trace;  // BTX_PT_TRACE builds: per-wave phase timings (measurement only)
   int pt_nw, pt_astage, pt_lds;
   int pt_mi;      // patch variant: 32-pixel MFMA tiles per wave (2 | 4)
@@ -144,8 +148,9 @@ __device__ __forceinline__ RngLive rng_live(const ContractParams& p) {
   if (p.sample_ptr) {
     r.sample = __builtin_amdgcn_readfirstlane(*p.sample_ptr);
     if constexpr (KIND == 1) {
-      const BtxPhilox4 ki = btx_philox4x32_10(0u, r.sample, p.layer, 2u, p.seed_lo, p.seed_hi);  // BTX_STREAM_SIGN_IN
-      const BtxPhilox4 ko = btx_philox4x32_10(0u, r.sample, p.layer, 3u, p.seed_lo, p.seed_hi);  // BTX_STREAM_SIGN_OUT
+      const uint32_t si = p.swap_signs ? 3u : 2u, so = p.swap_signs ? 2u : 3u;  // BTX_STREAM_SIGN_IN = 2, _OUT = 3
+      const BtxPhilox4 ki = btx_philox4x32_10(0u, r.sample, p.layer, si, p.seed_lo, p.seed_hi);
+      const BtxPhilox4 ko = btx_philox4x32_10(0u, r.sample, p.layer, so, p.seed_lo, p.seed_hi);
       r.kin_a = __builtin_amdgcn_readfirstlane(ki.x[0]); r.kin_b = __builtin_amdgcn_readfirstlane(ki.x[1]);
       r.kout_a = __builtin_amdgcn_readfirstlane(ko.x[0]); r.kout_b = __builtin_amdgcn_readfirstlane(ko.x[1]);
     }

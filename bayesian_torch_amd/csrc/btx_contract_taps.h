@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
   uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
-  fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
+  if (p.wg_order) fdivmod((uint32_t)logical, p.fd_mtiles, (uint32_t)p.mtiles, u_rem, u_mtile);  // weight-major (btx_api.hip)
+  else fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
   fdivmod(u_rem, p.fd_ksplits, (uint32_t)p.ksplits, u_t, u_split);
   fdivmod(u_t, p.fd_ntiles, (uint32_t)p.ntiles, u_group, u_ntile);
   const int mtile = (int)u_mtile, split = (int)u_split, ntile = (int)u_ntile, group = (int)u_group;
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   if (p.sample_ptr) {
     rl.sample = __builtin_amdgcn_readfirstlane(smp);
     if constexpr (KIND == 1) {
-      const BtxPhilox4 ki = btx_philox4x32_10(0u, rl.sample, p.layer, 2u, p.seed_lo, p.seed_hi);
-      const BtxPhilox4 ko = btx_philox4x32_10(0u, rl.sample, p.layer, 3u, p.seed_lo, p.seed_hi);
+      const uint32_t si = p.swap_signs ? 3u : 2u, so = p.swap_signs ? 2u : 3u;  // BTX_STREAM_SIGN_IN = 2, _OUT = 3
+      const BtxPhilox4 ki = btx_philox4x32_10(0u, rl.sample, p.layer, si, p.seed_lo, p.seed_hi);
+      const BtxPhilox4 ko = btx_philox4x32_10(0u, rl.sample, p.layer, so, p.seed_lo, p.seed_hi);
       rl.kin_a = __builtin_amdgcn_readfirstlane(ki.x[0]); rl.kin_b = __builtin_amdgcn_readfirstlane(ki.x[1]);
       rl.kout_a = __builtin_amdgcn_readfirstlane(ko.x[0]); rl.kout_b = __builtin_amdgcn_readfirstlane(ko.x[1]);
     }

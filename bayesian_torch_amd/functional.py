@@ -373,6 +373,40 @@ def kl_hip(mu, rho, prior_mu, prior_sigma, prior_mu_t=None, prior_sigma_t=None, 
     return out
 
 
+def _kl_items(entries, grads=None):
+    """entries = [(mu, rho, prior_mu, prior_sigma, prior_mu_t|None, prior_sigma_t|None)] of same-order f32 tensors"""
+    arr = (_lib.KlItem * len(entries))()
+    for i, (mu, rho, pm, ps, pmt, pst) in enumerate(entries):
+        arr[i].mu, arr[i].rho, arr[i].n = mu.data_ptr(), rho.data_ptr(), mu.numel()
+        arr[i].prior_mu, arr[i].prior_sigma = float(pm), float(ps)
+        arr[i].prior_mu_t = pmt.data_ptr() if pmt is not None else None
+        arr[i].prior_sigma_t = pst.data_ptr() if pst is not None else None
+        if grads is not None:
+            arr[i].dmu, arr[i].drho = grads[i][0].data_ptr(), grads[i][1].data_ptr()
+    return arr
+
+
+def kl_model_hip(entries):
+    """sum over tensors of the mean Gaussian KL, ONE launch + one final reduce (btx_kl_gauss_model) -> 0-d f32"""
+    L = _lib.lib()
+    dev = entries[0][0].device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = _workspace(dev, L.btx_kl_model_workspace_bytes(len(entries)), stream)
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    _lib.check(L.btx_kl_gauss_model(_kl_items(entries), len(entries), out.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+    return out
+
+
+def kl_model_bwd_hip(entries, grads, grad_out):
+    """d(kl)/d(mu, rho) of every tensor into `grads` [(dmu, drho)] (same element order), scaled by the device scalar
+    `grad_out` (btx_kl_gauss_model_bwd)"""
+    L = _lib.lib()
+    dev = entries[0][0].device
+    g = grad_out.detach().reshape(()).to(device=dev, dtype=torch.float32).contiguous()
+    _lib.check(L.btx_kl_gauss_model_bwd(_kl_items(entries, grads), len(entries), g.data_ptr(),
+                                        torch.cuda.current_stream(dev).cuda_stream))
+
+
 def rowfuse_plan(op, x_shape):
     """Geometry of the row-fused execution of a small-C 2-D stem conv (BTX_FLAG_ROWFUSE), or None.  Decided by the
     layer geometry ONLY (never by dtypes), because the BTX-RNG index space of the layer follows this layout.

@@ -18,8 +18,7 @@ from .. import _lib
 from .. import functional as BF
 from .. import rng as _rng
 
-_BACKEND = "auto"  # "auto": CUDA+no-grad -> hip, CPU or autograd -> aten ; "hip": strict ; "torch": always aten
-_warned_autograd = False
+_BACKEND = "auto"  # "auto": CUDA -> hip (with or without autograd), CPU -> aten ; "hip": CUDA only ; "torch": always aten
 
 
 def set_backend(name):
@@ -189,24 +188,19 @@ class _VariationalNd(BaseVariationalLayer_):
         return new
 
     def _use_hip(self, t):
+        """CUDA (ROCm) tensors run on libbtx — with autograd too (bayesian_torch_amd/autograd.py); CPU tensors and
+        backend "torch" take the ATen chain."""
         if _BACKEND == "torch" or not t.is_cuda:
             if _BACKEND == "hip" and not t.is_cuda:
                 raise _lib.BtxError("backend 'hip' needs CUDA (ROCm) tensors")
             return False
-        mu, rho = self._w()
-        needs_grad = torch.is_grad_enabled() and (mu.requires_grad or rho.requires_grad or
-                                                  (t.requires_grad if t.is_floating_point() else False))
-        if needs_grad:
-            if _BACKEND == "hip":
-                raise _lib.BtxError("autograd through the HIP forward is not implemented; wrap the call in "
-                                    "torch.no_grad() or set_backend('torch')")
-            global _warned_autograd
-            if not _warned_autograd:
-                warnings.warn("bayesian_torch_amd: autograd requested — this call uses the ATen op chain; the fused "
-                              "HIP kernels are forward-only (use torch.no_grad() for MC inference).")
-                _warned_autograd = True
-            return False
         return True
+
+    def _needs_grad(self, t):
+        mu, rho = self._w()
+        return torch.is_grad_enabled() and (mu.requires_grad or rho.requires_grad or
+                                            (self.mu_bias is not None and self.mu_bias.requires_grad) or
+                                            (t is not None and t.is_floating_point() and t.requires_grad))
 
     def kl_loss(self):
         mu, rho = self._w()
@@ -217,26 +211,23 @@ class _VariationalNd(BaseVariationalLayer_):
                 kl = kl + self.kl_div(self.mu_bias, BF.softplus_naive(self.rho_bias), self.prior_bias_mu,
                                       self.prior_bias_sigma)
             return kl
-        # RNG-free and cheap (8 B/element, two launches per tensor): recomputed on every call rather than cached —
-        # `param.data` mutations do not bump `_version`, so no cache key is trustworthy.
-        tens = not self._priors_are_scalar()  # MOPED-style full-shape priors
-        if tens:  # element order must match the logical prior tensors
-            kl = BF.kl_hip(mu.contiguous(), rho.contiguous(), self.prior_mean, self.prior_variance,
-                           self.prior_weight_mu, self.prior_weight_sigma)
-        else:     # a mean over elements: storage order is irrelevant
-            kl = BF.kl_hip(BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op), self.prior_mean,
-                           self.prior_variance)
-        if self.mu_bias is not None:
-            BF.kl_hip(self.mu_bias, self.rho_bias, self.prior_mean, self.prior_variance,
-                      self.prior_bias_mu if tens else None, self.prior_bias_sigma if tens else None,
-                      out=kl, accumulate=True)
-        return kl
+        # RNG-free and cheap (8 B/element): recomputed on every call rather than cached — `param.data` mutations do not
+        # bump `_version`, so no cache key is trustworthy.  One launch for weight + bias; differentiable when needed.
+        from .. import autograd as _ag
+        return _ag.kl_of_layers([self])
 
     def forward(self, input, return_kl=True):
         if self.dnn_to_bnn_flag:
             return_kl = False
         if self._use_hip(input):
-            out = self._forward_hip(input)
+            if self._needs_grad(input):
+                from .. import autograd as _ag
+                s_idx = self._btx_sample
+                self.__dict__["_btx_sample"] = s_idx + 1
+                mu, rho = self._w()
+                out = _ag.ContractFn.apply(self, s_idx, input, mu, rho, self.mu_bias, self.rho_bias)
+            else:
+                out = self._forward_hip(input)
             if return_kl:
                 return out, self.kl_loss()
             return out

@@ -64,15 +64,18 @@ def dnn_to_bnn(m, bnn_prior_parameters):
 
 
 def get_kl_loss(m):
-    """Sum of `layer.kl_loss()` over every module that has one (None for a model without Bayesian layers)."""
-    terms = [layer.kl_loss() for layer in m.modules() if hasattr(layer, "kl_loss")]
-    if not terms:
+    """Sum of `layer.kl_loss()` over every module that has one (None for a model without Bayesian layers).  CUDA
+    models: ONE launch for all tensors of all layers (btx_kl_gauss_model), differentiable (btx_kl_gauss_model_bwd)."""
+    layers = [layer for layer in m.modules() if hasattr(layer, "kl_loss")]
+    if not layers:
         return None
+    if all(hasattr(layer, "_w") and layer._use_hip(layer._w()[0]) for layer in layers):
+        from .. import autograd as _ag
+        return _ag.kl_of_layers(layers)
+    terms = [layer.kl_loss() for layer in layers]
     if len(terms) == 1:
         return terms[0]
-    if not terms[0].is_cuda:  # CPU: the reference's sequential += chain, bit for bit
-        kl = terms[0]
-        for t in terms[1:]:
-            kl = kl + t
-        return kl
-    return torch.stack(terms).sum()
+    kl = terms[0]  # the reference's sequential += chain, bit for bit on CPU
+    for t in terms[1:]:
+        kl = kl + t
+    return kl

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BTX_ABI_VERSION 2
+#define BTX_ABI_VERSION 3
 
 /* argument-error codes (negative) */
 #define BTX_E_NULL        (-1)   /* required pointer is NULL */
@@ -67,6 +67,10 @@ extern "C" {
                                      returns BTX_E_UNSUPPORTED otherwise. */
 #define BTX_FLAG_OUT_F32      8u  /* store the output as f32 / bf16 regardless of act_dtype (LDS-DMA kernels only: lets */
 #define BTX_FLAG_OUT_BF16    16u  /* a caller that had to copy the input anyway keep "f32 in/out, bf16 MFMA" semantics) */
+#define BTX_FLAG_SWAP_SIGNS  64u  /* Flipout: hash the INPUT signs from stream SIGN_OUT and the OUTPUT signs from stream
+                                     SIGN_IN.  The data gradient of a Flipout layer is itself a Flipout-shaped contraction,
+                                     dx = convT(dy, mu) + s_in * convT(dy * s_out, sigma*eps): the same entry point computes
+                                     it on the transposed (or flipped) geometry with the two sign streams exchanged. */
 #define BTX_FLAG_GATHER      32u  /* force the element-wise gather kernel (any shape / alignment; samples in registers).
                                      The library picks it by itself whenever a fast kernel does not apply; the flag
                                      exists so tests can exercise it on shapes the fast kernels would take. */
@@ -130,6 +134,27 @@ int btx_kl_gauss(const float* mu, const float* rho, size_t n,
                  const float* prior_mu_t, const float* prior_sigma_t,
                  float prior_mu, float prior_sigma,
                  float* kl_out, uint32_t flags, void* ws, size_t ws_bytes, void* stream);
+
+/* K1b. KL of a whole model in one launch (+ one final reduce), and its gradient.
+ * Replaces get_kl_loss  models/dnn_to_bnn.py:157-165  (sum over modules of the per-tensor MEANS) and, for training
+ * (README.md:114-125: loss = ce + kl / batch_size), the autograd graph torch builds through base_variational_layer.py:53-68:
+ *   d kl / d mu  = (mu - mu_p) / (sigma_p^2 n)        d kl / d rho = (sigma / sigma_p^2 - 1 / sigma) * sigmoid(rho) / n
+ * items_host is a HOST array read before the call returns; mu/rho (and dmu/drho of the backward) are device pointers of
+ * n floats in any element order (the terms are elementwise), prior tensors optional as in btx_kl_gauss.
+ * grad_out: DEVICE pointer to the upstream gradient scalar (no host sync). */
+typedef struct BtxKlItem {
+  const float* mu;
+  const float* rho;
+  const float* prior_mu_t;     /* nullable */
+  const float* prior_sigma_t;  /* nullable */
+  float*       dmu;            /* backward only */
+  float*       drho;           /* backward only */
+  float        prior_mu, prior_sigma;
+  size_t       n;
+} BtxKlItem;
+size_t btx_kl_model_workspace_bytes(int n_items);
+int btx_kl_gauss_model(const BtxKlItem* items_host, int n_items, float* kl_out, void* ws, size_t ws_bytes, void* stream);
+int btx_kl_gauss_model_bwd(const BtxKlItem* items_host, int n_items, const float* grad_out, void* stream);
 
 /* K2-K5. Fused sample-and-contract forward of one variational layer.
  * Replaces the whole body of
