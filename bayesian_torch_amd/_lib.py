@@ -53,7 +53,7 @@ class KlItem(ctypes.Structure):
 
 
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss", "btx_kl_model_workspace_bytes",
-           "btx_kl_gauss_model", "btx_kl_gauss_model_bwd",
+           "btx_kl_gauss_model", "btx_kl_gauss_model_bwd", "btx_contract_wgrad",
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
            "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
 
@@ -88,6 +88,9 @@ def lib():
     L.btx_kl_gauss_model.argtypes = [ctypes.POINTER(KlItem), i32, vp, vp, sz, vp]
     L.btx_kl_gauss_model_bwd.restype = i32
     L.btx_kl_gauss_model_bwd.argtypes = [ctypes.POINTER(KlItem), i32, vp, vp]
+    L.btx_contract_wgrad.restype = i32
+    L.btx_contract_wgrad.argtypes = [i32, ctypes.POINTER(Geom), vp, vp, vp, vp, vp, vp, ctypes.POINTER(Rng),
+                                     ctypes.POINTER(Noise), i32, u32, vp]
     L.btx_contract_workspace_bytes.restype = sz
     L.btx_contract_workspace_bytes.argtypes = [ctypes.POINTER(Geom), i32, i32, i32, u32]
     L.btx_contract_fwd.restype = i32

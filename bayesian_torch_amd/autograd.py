@@ -10,9 +10,9 @@ the backward: eps and the Flipout signs are regenerated.
                  transposed geometry (stride-1 2-D convolutions: on the flipped kernel, which the tap-unrolled kernel
                  takes) with the two sign streams exchanged (BTX_FLAG_SWAP_SIGNS) and the forward's eps passed explicitly
   KL, dKL        btx_kl_gauss_model / btx_kl_gauss_model_bwd (one launch for the whole model)
-  dmu, drho      dW = corr(x, dy) [and corr(x*s_in, dy*s_out) for Flipout] is computed by ATen (MIOpen / rocBLAS) in this
-                 round — a pixel-reduction GEMM with both operands transposed relative to the channels-last storage, the
-                 one contraction libbtx does not have yet; dmu = dW, drho = dW_delta * eps * sigmoid(rho) follow here.
+  dmu, drho      btx_contract_wgrad: dW_mu = corr(x, dy) [and dW_delta = corr(x*s_in, dy*s_out) for Flipout] — a GEMM whose
+                 reduction axis is the pixel axis, on the exact-f32 MFMA (csrc/btx_wgrad.hip); dmu = dW_mu and
+                 drho = dW_delta * eps * sigmoid(rho) are elementwise follow-ups here.
 """
 import torch
 import torch.nn.functional as F
@@ -103,25 +103,38 @@ class ContractFn(torch.autograd.Function):
             dsig = torch.sigmoid(rho.detach())
             w_shape = tuple(rho.shape)
             dx = dmu = drho = dmu_b = drho_b = None
-            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-                dW = _weight_grad(x, dy, w_shape, op)
-                if flip:
-                    si = nz["sign_in"].to(x.dtype)
-                    so = nz["sign_out"].to(dy.dtype)
-                    dWd = _weight_grad(x * si.reshape(x.shape), dy * so.reshape(dy.shape), w_shape, op)
+            plan = layer._rowfuse_plan(x) if op.nd == 2 else None
+            padded = layer._btx_cpad is not None or plan is not None   # forward noise indices run over padded layouts
+            kind = _lib.KIND_FLIPOUT if flip else _lib.KIND_REPARAM
+            want_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+            want_b = rho_b is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6])
+            if want_w or want_b:
+                signs = (nz["sign_in"], nz["sign_out"]) if (flip and padded) else None
+                if not op.transposed:
+                    dW, dWd, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
+                                                    signs=signs, bias=want_b)
                 else:
-                    dWd = dW
-                dmu = dW
-                drho = dWd * eps * dsig
-            if rho_b is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]):
-                red = tuple(i for i in range(dy.dim()) if i != (dy.dim() - 1 if op.nd == 0 else 1))
-                db = dy.float().sum(red)
-                dbd = (dy.float() * nz["sign_out"].reshape(dy.shape).float()).sum(red) if flip else db
-                dmu_b = db
-                drho_b = dbd * nz["eps_b"] * torch.sigmoid(rho_b.detach())
+                    # y = convT(x, W): W is the weight of the plain convolution that maps y-space to x-space, so its
+                    # gradient is corr(dy, x) on that geometry — x and dy (and the two sign streams) exchange roles
+                    nd = op.nd
+                    opc = BF.OpDesc(nd, op.out_channels, op.in_channels, op.kernel[3 - nd:], op.stride[3 - nd:],
+                                    op.padding[3 - nd:], op.dilation[3 - nd:], op.groups)
+                    sw = (signs[1], signs[0]) if signs is not None else None
+                    dW, dWd, _, _ = BF.wgrad_hip(kind, dy, x, opc, _rng.seed(), s, layer._btx_layer_id, w_shape, signs=sw,
+                                                 swap=True)
+                    db = dbd = None
+                    if want_b:
+                        red = tuple(i for i in range(dy.dim()) if i != 1)
+                        db = dy.float().sum(red)
+                        dbd = (dy.float() * nz["sign_out"].reshape(dy.shape).float()).sum(red) if flip else None
+                if want_w:
+                    dmu = dW
+                    drho = (dWd if flip else dW) * eps * dsig
+                if want_b:
+                    dmu_b = db
+                    drho_b = (dbd if flip else db) * nz["eps_b"] * torch.sigmoid(rho_b.detach())
             if ctx.needs_input_grad[2]:
-                plan = layer._rowfuse_plan(x) if op.nd == 2 else None
-                hashed = flip and layer._btx_cpad is None and plan is None
+                hashed = flip and not padded
                 dx = _data_grad_hip(layer, dy, tuple(x.shape), nz, s, hashed)
                 if dx.dtype != x.dtype:
                     dx = dx.to(x.dtype)

@@ -1,0 +1,298 @@
+// btx_wgrad.hip — weight gradient of a variational contraction (gfx950): the one contraction of the training path that is
+// not Flipout-forward-shaped (the data gradient is: bayesian_torch_amd/autograd.py).
+//
+//   dW_mu   [n][tap][c] = sum over output pixels p of   dy[p][n]            * x[p @ tap][c]
+//   dW_delta[n][tap][c] = sum over output pixels p of  (dy[p][n] s_out[p][n]) * (x[p @ tap][c] s_in[p @ tap][c])   (Flipout)
+//
+// (reference: what torch autograd derives for F.conv*d / F.linear inside conv_flipout.py:376-417, conv_variational.py:379-380;
+// dmu = dW_mu, drho = dW_delta * eps * sigmoid(rho) follow elementwise on the host side.)
+//
+// A GEMM whose reduction axis is the PIXEL axis: both operands are stored channels-last, i.e. with the reduction index
+// slowest.  The exact-f32 MFMA v_mfma_f32_32x32x2_f32 takes ONE element per lane per operand (A[i = lane&31][k = lane>>5],
+// B[k][j]), so its fragments are plain 4-byte LDS reads of a pixel-major tile and no transpose is needed; gradients
+// accumulate in f32 whatever the activation dtype.  (157 TFLOP/s peak, 1/16 of the bf16 rate: a bf16 form needs
+// ds_read_b64_tr_b16 fragment loads — next.)
+//
+// Workgroup = 4 waves <-> (64 output channels, 64 input channels of ONE tap, a chunk of output pixels).  Per 64-pixel
+// step the tile dy[64 px][64 n] and the tap-shifted tile x[64 px][64 c] (zeros outside the input) are staged as f32,
+// for Flipout also their sign-flipped copies; wave w multiplies pixels {16w .. 16w+15}: 8 MFMA k-steps x 4 (8) output
+// tiles.  The four partial sums are added through LDS and leave with f32 atomics (dW must be zero on entry: the entry
+// point clears it).  Bias gradients (column sums of dy, of dy*s_out) ride along in the workgroups of tap 0 / channel
+// block 0.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/btx.h"
+#include "btx_contract.h"
+#include "btx_rng.h"
+
+using namespace btx;
+
+namespace {
+
+struct WgradParams {
+  const void* x;
+  const void* dy;
+  float* dwm;
+  float* dwd;
+  float* dbm;
+  float* dbd;
+  const int8_t* sign_in;
+  const int8_t* sign_out;
+  int NB, D, H, W, C, Cg, Do, Ho, Wo, N, Ng, KD, KH, KW;
+  int sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int M, K, T, groups, ntiles, ctiles, chunks, chunk_px;
+  uint32_t kin_a, kin_b, kout_a, kout_b;
+  FastDiv fd_Wo, fd_Ho, fd_Do, fd_T, fd_ctiles, fd_ntiles, fd_groups;
+};
+
+constexpr int WG_PX = 64;          // pixels per step
+constexpr int WG_ROW = 64 * 4 + 16;  // bytes per pixel row of a staged tile: 64 f32 + pad (conflict-free 16-B writes)
+constexpr int WG_TILE = WG_PX * WG_ROW;
+
+__device__ __forceinline__ float sgn_flip(float v, bool neg) { return neg ? -v : v; }
+
+template <typename ACT, int KIND>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // tiles: dy, x (+ signed copies for Flipout)
+  unsigned char* t_dy = smem;
+  unsigned char* t_x = smem + WG_TILE;
+  unsigned char* t_dys = smem + 2 * WG_TILE;
+  unsigned char* t_xs = smem + 3 * WG_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hk = lane >> 5;
+
+  uint32_t u, u_chunk, u_tap, u_ct, u_nt, u_g;
+  fdivmod(blockIdx.x, p.fd_T, (uint32_t)p.T, u, u_tap);
+  fdivmod(u, p.fd_ctiles, (uint32_t)p.ctiles, u, u_ct);
+  fdivmod(u, p.fd_ntiles, (uint32_t)p.ntiles, u, u_nt);
+  fdivmod(u, p.fd_groups, (uint32_t)p.groups, u_chunk, u_g);
+  const int tap = (int)u_tap, ct = (int)u_ct, nt = (int)u_nt, grp = (int)u_g, chunk = (int)u_chunk;
+  const int kw = tap % p.KW, kh = (tap / p.KW) % p.KH, kd = tap / (p.KW * p.KH);
+  const int m_begin = chunk * p.chunk_px, m_end = min(p.M, m_begin + p.chunk_px);
+  const bool do_bias = (tap == 0) && (ct == 0) && (p.dbm != nullptr);
+
+  // staging role: thread t loads 16 consecutive channels of pixel (t >> 2) of each tile: quarter q = t & 3
+  const int s_px = tid >> 2, s_q = tid & 3;
+  f32x16 acc_m[2][2], acc_d[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_m[a][b][r] = 0.f; acc_d[a][b][r] = 0.f; }
+  float bsum_m = 0.f, bsum_d = 0.f;  // threads 0..63: column n = tid of the dy tile
+
+  for (int m0 = m_begin; m0 < m_end; m0 += WG_PX) {
+    // ---- stage: dy[m0 + s_px][nt*64 + 16 s_q ..] and x[(m0 + s_px) @ tap][ct*64 + 16 s_q ..]
+    {
+      const int m = m0 + s_px;
+      const bool pix_ok = m < m_end;
+      uint32_t t1, uow, uoh, uod, unb;
+      fdivmod((uint32_t)(pix_ok ? m : 0), p.fd_Wo, (uint32_t)p.Wo, t1, uow);
+      fdivmod(t1, p.fd_Ho, (uint32_t)p.Ho, t1, uoh);
+      fdivmod(t1, p.fd_Do, (uint32_t)p.Do, unb, uod);
+      const int id = (int)uod * p.sd - p.pd + kd * p.dd, ih = (int)uoh * p.sh - p.ph + kh * p.dh,
+                iw = (int)uow * p.sw - p.pw + kw * p.dw;
+      const bool in_ok = pix_ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const long long xo = ((((long long)unb * p.D + id) * p.H + ih) * p.W + iw) * p.C + grp * p.Cg + ct * 64 + 16 * s_q;
+      const long long yo = (long long)m * p.N + grp * p.Ng + nt * 64 + 16 * s_q;
+      float xv[16], yv[16], xsv[16], ysv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const bool cok = in_ok && (ct * 64 + 16 * s_q + e < p.Cg);
+        const bool nok = pix_ok && (nt * 64 + 16 * s_q + e < p.Ng);
+        xv[e] = cok ? (float)((const ACT*)p.x)[xo + e] : 0.f;
+        yv[e] = nok ? (float)((const ACT*)p.dy)[yo + e] : 0.f;
+      }
+      if constexpr (KIND == 1) {
+        uint32_t cwi = 0xffffffffu, cw = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned long long i = (unsigned long long)(xo + e);
+          bool neg = false;
+          if (in_ok && (ct * 64 + 16 * s_q + e < p.Cg)) {
+            if (p.sign_in) neg = p.sign_in[i] < 0;
+            else {
+              const uint32_t wi = (uint32_t)(i >> 5);
+              if (wi != cwi) { cwi = wi; cw = btx_sign_word(wi, p.kin_a, p.kin_b); }
+              neg = (cw >> btx_sign_bitpos((uint32_t)i & 31u)) & 1u;
+            }
+          }
+          xsv[e] = sgn_flip(xv[e], neg);
+        }
+        cwi = 0xffffffffu;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned long long i = (unsigned long long)(yo + e);
+          bool neg = false;
+          if (pix_ok && (nt * 64 + 16 * s_q + e < p.Ng)) {
+            if (p.sign_out) neg = p.sign_out[i] < 0;
+            else {
+              const uint32_t wi = (uint32_t)(i >> 5);
+              if (wi != cwi) { cwi = wi; cw = btx_sign_word(wi, p.kout_a, p.kout_b); }
+              neg = (cw >> btx_sign_bitpos((uint32_t)i & 31u)) & 1u;
+            }
+          }
+          ysv[e] = sgn_flip(yv[e], neg);
+        }
+      }
+      unsigned char* rx = t_x + s_px * WG_ROW + s_q * 64;
+      unsigned char* ry = t_dy + s_px * WG_ROW + s_q * 64;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        *(f32x4*)(rx + 16 * v) = (f32x4){xv[4 * v], xv[4 * v + 1], xv[4 * v + 2], xv[4 * v + 3]};
+        *(f32x4*)(ry + 16 * v) = (f32x4){yv[4 * v], yv[4 * v + 1], yv[4 * v + 2], yv[4 * v + 3]};
+      }
+      if constexpr (KIND == 1) {
+        unsigned char* rxs = t_xs + s_px * WG_ROW + s_q * 64;
+        unsigned char* rys = t_dys + s_px * WG_ROW + s_q * 64;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          *(f32x4*)(rxs + 16 * v) = (f32x4){xsv[4 * v], xsv[4 * v + 1], xsv[4 * v + 2], xsv[4 * v + 3]};
+          *(f32x4*)(rys + 16 * v) = (f32x4){ysv[4 * v], ysv[4 * v + 1], ysv[4 * v + 2], ysv[4 * v + 3]};
+        }
+      }
+    }
+    __syncthreads();
+    // ---- multiply: wave w takes pixels 16w..16w+15 of the step, two per MFMA
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int px = 16 * wave + 2 * kk + hk;
+      float a[2], b[2], as_[2], bs_[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *(const float*)(t_dy + px * WG_ROW + (32 * i + l31) * 4);
+        b[i] = *(const float*)(t_x + px * WG_ROW + (32 * i + l31) * 4);
+        if constexpr (KIND == 1) {
+          as_[i] = *(const float*)(t_dys + px * WG_ROW + (32 * i + l31) * 4);
+          bs_[i] = *(const float*)(t_xs + px * WG_ROW + (32 * i + l31) * 4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc_m[i][j], 0, 0, 0);
+          if constexpr (KIND == 1) acc_d[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as_[i], bs_[j], acc_d[i][j], 0, 0, 0);
+        }
+    }
+    if (do_bias && tid < 64) {
+      for (int q = 0; q < WG_PX; ++q) {
+        bsum_m += *(const float*)(t_dy + q * WG_ROW + tid * 4);
+        if constexpr (KIND == 1) bsum_d += *(const float*)(t_dys + q * WG_ROW + tid * 4);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- reduce the four waves' partial tiles through LDS and add them to dW.
+  // C/D layout of 32x32 MFMAs: reg r of lane (l31, hk) = D[row = (r&3) + 8*(r>>2) + 4*hk][col = l31]; row = n, col = c.
+  float* red = (float*)smem;  // [wave][64 n][64 c]
+  auto reduce_store = [&](const f32x16 (&acc)[2][2], float* dst) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hk, c = 32 * j + l31;
+          red[(wave * 64 + n) * 64 + c] = acc[i][j][r];
+        }
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int n = e >> 6, c = e & 63;
+      const float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
+      const int ng = nt * 64 + n, cg = ct * 64 + c;
+      if (ng < p.Ng && cg < p.Cg)
+        atomicAdd(dst + ((size_t)(grp * p.Ng + ng) * p.T + tap) * p.Cg + cg, v);
+    }
+  };
+  reduce_store(acc_m, p.dwm);
+  if constexpr (KIND == 1) reduce_store(acc_d, p.dwd);
+  if (do_bias && tid < 64 && nt * 64 + tid < p.Ng) {
+    atomicAdd(p.dbm + grp * p.Ng + nt * 64 + tid, bsum_m);
+    if constexpr (KIND == 1) atomicAdd(p.dbd + grp * p.Ng + nt * 64 + tid, bsum_d);
+  }
+}
+
+void sign_keys_host(const BtxRng* rng, uint32_t stream, uint32_t* ka, uint32_t* kb) {
+  const BtxPhilox4 k = btx_philox4x32_10(0u, rng->sample_idx, rng->layer_id, stream, (uint32_t)rng->seed,
+                                         (uint32_t)(rng->seed >> 32));
+  *ka = k.x[0];
+  *kb = k.x[1];
+}
+
+}  // namespace
+
+extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta,
+                                  float* db_mu, float* db_delta, const BtxRng* rng, const BtxNoise* noise, int act_dtype,
+                                  uint32_t flags, void* stream) {
+  if (!g || !x || !dy || !dw_mu || !rng) return BTX_E_NULL;
+  if (kind != BTX_KIND_REPARAM && kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
+  if (kind == BTX_KIND_FLIPOUT && !dw_delta) return BTX_E_NULL;
+  if ((db_mu != nullptr) && kind == BTX_KIND_FLIPOUT && !db_delta) return BTX_E_NULL;
+  if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
+  if (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_ROWFUSE)) return BTX_E_UNSUPPORTED;  // transposed layers: swap x and dy (host)
+  if (rng->sample_idx_dev) return BTX_E_UNSUPPORTED;
+  int32_t Do, Ho, Wo;
+  int rc = btx_out_shape(g, 0, &Do, &Ho, &Wo);
+  if (rc) return rc;
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.dy = dy; p.dwm = dw_mu; p.dwd = dw_delta; p.dbm = db_mu; p.dbd = db_delta;
+  p.sign_in = noise ? noise->sign_in : nullptr;
+  p.sign_out = noise ? noise->sign_out : nullptr;
+  p.NB = g->NB; p.D = g->D; p.H = g->H; p.W = g->W; p.C = g->C; p.Cg = g->C / g->groups;
+  p.Do = Do; p.Ho = Ho; p.Wo = Wo; p.N = g->N; p.Ng = g->N / g->groups;
+  p.KD = g->KD; p.KH = g->KH; p.KW = g->KW;
+  p.sd = g->sd; p.sh = g->sh; p.sw = g->sw; p.pd = g->pd; p.ph = g->ph; p.pw = g->pw; p.dd = g->dd; p.dh = g->dh; p.dw = g->dw;
+  const long long M = (long long)g->NB * Do * Ho * Wo;
+  if (M > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
+  p.M = (int)M; p.T = g->KD * g->KH * g->KW; p.K = p.T * p.Cg; p.groups = g->groups;
+  p.ntiles = (p.Ng + 63) / 64; p.ctiles = (p.Cg + 63) / 64;
+  const long long base = (long long)p.groups * p.ntiles * p.ctiles * p.T;
+  long long chunks = (2048 + base - 1) / base;  // ~2048 workgroups in flight
+  const long long max_chunks = (M + WG_PX - 1) / WG_PX;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  long long cpx = ((M + chunks - 1) / chunks + WG_PX - 1) / WG_PX * WG_PX;
+  chunks = (M + cpx - 1) / cpx;
+  p.chunks = (int)chunks; p.chunk_px = (int)cpx;
+  if (base * chunks > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
+  const bool swap = (flags & BTX_FLAG_SWAP_SIGNS) != 0;  // transposed layers: the roles of x and dy are exchanged
+  sign_keys_host(rng, swap ? BTX_STREAM_SIGN_OUT : BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
+  sign_keys_host(rng, swap ? BTX_STREAM_SIGN_IN : BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
+  p.fd_Wo = make_fastdiv((uint32_t)Wo); p.fd_Ho = make_fastdiv((uint32_t)Ho); p.fd_Do = make_fastdiv((uint32_t)Do);
+  p.fd_T = make_fastdiv((uint32_t)p.T); p.fd_ctiles = make_fastdiv((uint32_t)p.ctiles);
+  p.fd_ntiles = make_fastdiv((uint32_t)p.ntiles); p.fd_groups = make_fastdiv((uint32_t)p.groups);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t wbytes = (size_t)g->N * p.K * sizeof(float);
+  hipError_t e = hipMemsetAsync(dw_mu, 0, wbytes, st);
+  if (e != hipSuccess) return (int)e;
+  if (kind == BTX_KIND_FLIPOUT) { e = hipMemsetAsync(dw_delta, 0, wbytes, st); if (e != hipSuccess) return (int)e; }
+  if (db_mu) {
+    e = hipMemsetAsync(db_mu, 0, (size_t)g->N * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (kind == BTX_KIND_FLIPOUT) { e = hipMemsetAsync(db_delta, 0, (size_t)g->N * sizeof(float), st); if (e != hipSuccess) return (int)e; }
+  }
+  const int nwg = (int)(base * chunks);
+  const int lds = (kind == BTX_KIND_FLIPOUT ? 4 : 2) * WG_TILE;
+  const int lds_need = lds > 65536 ? lds : 65536;  // the cross-wave reduction uses 64 KiB
+#define BTX_LAUNCH_WG(ACT, KIND)                                                                                    \
+  do {                                                                                                            \
+    auto kfn = wgrad_kernel<ACT, KIND>;                                                                            \
+    static bool attr_done = false;                                                                                \
+    if (!attr_done) {                                                                                             \
+      hipError_t e2 = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);  \
+      if (e2 != hipSuccess) return (int)e2;                                                                       \
+      attr_done = true;                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), lds_need, st, p);                                               \
+  } while (0)
+  if (act_dtype == BTX_ACT_F32) { if (kind == 0) BTX_LAUNCH_WG(float, 0); else BTX_LAUNCH_WG(float, 1); }
+  else { if (kind == 0) BTX_LAUNCH_WG(__bf16, 0); else BTX_LAUNCH_WG(__bf16, 1); }
+#undef BTX_LAUNCH_WG
+  return (int)hipGetLastError();
+}

@@ -353,6 +353,52 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     return res.contiguous() if (_OUT_LAYOUT == "contiguous" and op.nd > 0) else res
 
 
+def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, swap=False, bias=False):
+    """btx_contract_wgrad: (dW_mu, dW_delta | None, db_mu | None, db_delta | None) in the layer's LOGICAL weight layout
+    (f32).  `op` is a plain (non-transposed) contraction; `signs` = (sign_in, sign_out) logical +/-1 tensors for layers
+    whose forward ran on padded layouts, else the forward's hashed signs are regenerated."""
+    L = _lib.lib()
+    if op.transposed:
+        raise _lib.BtxError("wgrad_hip wants the plain-convolution geometry (exchange x and dy for transposed layers)")
+    xp, nb, spatial, _ = _to_channels_last(x, op)
+    yop = OpDesc(op.nd, op.out_channels, op.out_channels)
+    dy2 = dy.reshape(-1, op.out_channels) if op.nd == 0 else dy
+    dyp, _, _, _ = _to_channels_last(dy2, yop)
+    if xp.dtype != dyp.dtype:
+        dyp = dyp.to(xp.dtype)
+    act = _lib.ACT_BF16 if xp.dtype == torch.bfloat16 else _lib.ACT_F32
+    if xp.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.BtxError("activations must be float32 or bfloat16, got %s" % xp.dtype)
+    g = _lib.Geom()
+    g.NB, (g.D, g.H, g.W), g.C, g.N = nb, spatial, op.in_channels, op.out_channels
+    g.KD, g.KH, g.KW = op.kernel
+    g.sd, g.sh, g.sw = op.stride
+    g.pd, g.ph, g.pw = op.padding
+    g.dd, g.dh, g.dw = op.dilation
+    g.groups = op.groups
+    n, kred = op.out_channels, op.kernel[0] * op.kernel[1] * op.kernel[2] * (op.in_channels // op.groups)
+    dev = x.device
+    dwm = torch.empty(n * kred, dtype=torch.float32, device=dev)
+    flip = kind == _lib.KIND_FLIPOUT
+    dwd = torch.empty(n * kred, dtype=torch.float32, device=dev) if flip else None
+    dbm = torch.empty(n, dtype=torch.float32, device=dev) if bias else None
+    dbd = torch.empty(n, dtype=torch.float32, device=dev) if (bias and flip) else None
+    nz, keep = None, []
+    if signs is not None and flip:
+        nz = _lib.Noise()
+        si = _sign_to_int8_cl(signs[0].reshape(x.shape), op)
+        so = _sign_to_int8_cl(signs[1].reshape(dy2.shape), yop)
+        keep += [si, so]
+        nz.sign_in, nz.sign_out = si.data_ptr(), so.data_ptr()
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF, None)
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    _lib.check(L.btx_contract_wgrad(kind, ctypes.byref(g), xp.data_ptr(), dyp.data_ptr(), dwm.data_ptr(), ptr(dwd), ptr(dbm),
+                                    ptr(dbd), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None, act,
+                                    _lib.FLAG_SWAP_SIGNS if swap else 0, torch.cuda.current_stream(dev).cuda_stream))
+    un = lambda t: unpack_gemm_major(t, w_shape, op) if t is not None else None  # noqa: E731
+    return un(dwm), un(dwd), dbm, dbd
+
+
 def kl_hip(mu, rho, prior_mu, prior_sigma, prior_mu_t=None, prior_sigma_t=None, out=None, accumulate=False):
     """mean Gaussian KL of one parameter tensor on the GPU (btx_kl_gauss) -> 0-d f32 tensor."""
     L = _lib.lib()

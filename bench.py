@@ -467,6 +467,38 @@ def run_mlp_config(dev, steps=8):
             "logits_rel_l2_vs_f32_mode": float((y - ref).norm() / ref.norm())}
 
 
+def run_train_step(dev, steps=5):
+    """reference README.md:114-125 on the HIP backend: forward + cross-entropy + KL/batch + backward of
+    dnn_to_bnn(ResNet18) Flipout, batch 64, bf16 activations (eager launches; weight gradients on the exact-f32 MFMA)"""
+    import bayesian_torch_amd as bt
+    bt.manual_seed(2024)
+    bt.set_precision("bf16")
+    model = build_model("Flipout", dev, torch.bfloat16, fuse=False).train()
+    torch.manual_seed(1234)
+    x = torch.randn(64, 3, 224, 224, device=dev).to(torch.bfloat16)
+    y = torch.randint(0, 1000, (64,), device=dev)
+    def step():
+        for p_ in model.parameters():
+            p_.grad = None
+        out = model(x)
+        loss = torch.nn.functional.cross_entropy(out.float(), y) + bt.get_kl_loss(model) / 64
+        loss.backward()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    # forward 480 + data gradient 465 (no dx for the stem) + weight gradient 480 GFLOP (Flipout: two contractions each)
+    gflop = 480.2 + (480.2 - 46.0) + 480.2
+    return {"workload": "training step (README.md:114-125): dnn_to_bnn(ResNet18) Flipout bs64, bf16 activations, forward + "
+                        "CE + KL/B + backward through libbtx (f32-MFMA weight gradients), eager launches",
+            "ms_per_step": ms, "achieved_tflops": gflop / ms, "loss_finite": bool(torch.isfinite(loss))}
+
+
 def summarise_extra(name, r, prec):
     peak = MFMA_PEAK_TFLOPS[prec]
     out = {"workload": name, "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "MC-samples/s", "dtype": prec,
@@ -653,6 +685,7 @@ def main():
                 extra["cfg2"] = run_mlp_config(dev)
                 r = run_resnet_config("resnet50", "Flipout", "bf16", 128, True, 6, 2, args.lanes, dev, parity=True, prewarm=3)
                 extra["cfg5"] = summarise_extra("cfg5 shard: dnn_to_bnn(ResNet50) Flipout + MOPED(0.5) bs128 bf16", r, "bf16")
+                extra["train_step"] = run_train_step(dev)
             except Exception as e:  # noqa — the headline must survive a failing extra
                 extra["error"] = "%s: %s" % (type(e).__name__, e)
             out["extra"] = extra

@@ -194,6 +194,21 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g,
                         void* ws, size_t ws_bytes, void* stream,
                         const BtxEpilogue* epilogue /* nullable */);
 
+/* Weight gradient of one variational contraction (training; what autograd derives for the F.conv*d / F.linear calls of
+ * conv_flipout.py:376-417, conv_variational.py:379-380, linear_flipout.py:168-174):
+ *   dw_mu   [n][tap][c] = sum_p dy[p][n] * x[p @ tap][c]
+ *   dw_delta[n][tap][c] = sum_p (dy * s_out)[p][n] * (x * s_in)[p @ tap][c]                      (Flipout only)
+ *   db_mu[n] = sum_p dy[p][n],  db_delta[n] = sum_p (dy * s_out)[p][n]                            (optional, NULL = skip)
+ * in the GEMM-major layout of mu_w, f32 whatever the activation dtype (exact-f32 MFMA, f32 atomics: the summation order
+ * over pixel chunks is not fixed).  The outputs are cleared by the call.  x / dy: channels-last as in btx_contract_fwd,
+ * dy = gradient of its output.  The Flipout signs are those of the forward with the same BtxRng (or noise->sign_in /
+ * sign_out).  dmu = dw_mu and drho = dw_delta * eps * sigmoid(rho) (Reparameterization: dw_mu * eps * sigmoid(rho)) are
+ * elementwise follow-ups on the caller's side.  ConvTranspose layers: call it on the plain-convolution geometry with x and
+ * dy exchanged and BTX_FLAG_SWAP_SIGNS.  The data gradient needs no entry point of its own: see BTX_FLAG_SWAP_SIGNS. */
+int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta,
+                       float* db_mu, float* db_delta, const BtxRng* rng, const BtxNoise* noise /* nullable */,
+                       int act_dtype, uint32_t flags, void* stream);
+
 /* Sampling pre-pass, hoisted.  The LDS-DMA / patch kernels of btx_contract_fwd* first sample the layer's weights ONCE
  * into MFMA-ready tiles (W = mu + sigma*eps for Reparameterization; mu and sigma*eps for Flipout; reference:
  * conv_flipout.py:380-394, conv_variational.py:357-366 materialise the same tensors with ATen ops) and then contract.

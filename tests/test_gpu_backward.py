@@ -158,3 +158,36 @@ def test_readme_training_snippet_runs_on_the_hip_backend():
     assert losses[-1] < losses[0] - 0.2, losses
     for n, p in net.named_parameters():
         assert not torch.equal(p.detach(), before[n]), n
+
+
+def test_bf16_activations_train_with_f32_weight_gradients():
+    """throughput mode: bf16 activations + bf16 MFMA forward / data gradient, exact-f32 weight gradient — against the f32
+    reference chain on the same bf16-valued tensors (bound 1e-2: 8-bit mantissas in the forward / dx operands)"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    from bayesian_torch_amd import functional as BF
+    from oracle import bt_ref
+    dev = _dev()
+    bt.manual_seed(5)
+    bt.set_precision("bf16")
+    try:
+        torch.manual_seed(0)
+        layer = L.Conv2dFlipout(64, 64, 3, padding=1, bias=False).to(dev)
+        x = torch.randn(4, 64, 14, 14, device=dev).to(torch.bfloat16).requires_grad_(True)
+        bt.set_sample_index(layer, 2)
+        out = layer(x, return_kl=False)
+        gy = torch.randn_like(out)
+        (out.float() * gy.float()).sum().backward()
+        mu, rho = layer._w()
+        with torch.no_grad():
+            nz = layer.materialize_noise(2, tuple(x.shape), tuple(out.shape), x.dtype)
+        xr = x.detach().float().requires_grad_(True)
+        mur, rhor = BF.plain_layout(mu.detach()).requires_grad_(True), BF.plain_layout(rho.detach()).requires_grad_(True)
+        ref = bt_ref.flipout_forward(xr, mur, rhor, None, None, nz["eps_w"], None, nz["sign_in"].float(), nz["sign_out"].float(),
+                                     dict(kind="conv", nd=2, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1))
+        (ref * gy.float()).sum().backward()
+        assert _rel(out.float(), ref) < 1e-2
+        assert _rel(x.grad.float(), xr.grad) < 1e-2
+        assert _rel(mu.grad, mur.grad) < 1e-4 and _rel(rho.grad, rhor.grad) < 1e-4   # f32 MFMA on identical bf16-valued inputs
+    finally:
+        bt.set_precision("f32")
