@@ -9,7 +9,7 @@ _LIB = None
 KIND_REPARAM, KIND_FLIPOUT = 0, 1
 ACT_F32, ACT_BF16 = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
-FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER, FLAG_SWAP_SIGNS = 1, 2, 4, 8, 16, 32, 64
+FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER, FLAG_SWAP_SIGNS, FLAG_CONCURRENT = 1, 2, 4, 8, 16, 32, 64, 128
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
 ABI_VERSION = 3

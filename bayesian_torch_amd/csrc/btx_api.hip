@@ -540,6 +540,10 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* p
       const long long rounds = (base * c + ncu - 1) / ncu;
       const long long cost = rounds * ((stages + c - 1) / c + 4) + (c > 1 ? 1 : 0);  // +1: the reduce pass
       if (best < 0 || cost < best) { best = cost; ks = c; }
+      // BTX_FLAG_CONCURRENT: other launches fill the CUs this one leaves idle, so what counts is its CU-time, and that
+      // only grows with the split (fixed per-block cost, partial sums through HBM, the reduce launch): split just far
+      // enough that the launch is not a long thin tail of its own stream
+      if ((flags & BTX_FLAG_CONCURRENT) && base * c >= 64) { ks = c; break; }
     }
   }
   int per_stages = (stages + ks - 1) / ks;
@@ -649,6 +653,7 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
       const long long rounds = (base * c + slots - 1) / slots;
       const long long cost = rounds * (per * T + 4) + (c > 1 ? 1 : 0);
       if (best < 0 || cost < best) { best = cost; ks = c; }
+      if ((flags & BTX_FLAG_CONCURRENT) && base * c * pt->kg >= 64) { ks = c; break; }  // see make_plan
     }
   }
   const int per = (units + ks - 1) / ks;

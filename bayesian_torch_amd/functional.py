@@ -31,6 +31,26 @@ def get_precision():
 
 
 _OUT_LAYOUT = "channels_last"
+_CONCURRENT = False  # set by mc.GraphedMC(lanes > 1) while it captures: BTX_FLAG_CONCURRENT on every contraction launch
+
+
+class concurrent_plan:
+    """context manager: plan the contraction launches issued inside for device throughput (BTX_FLAG_CONCURRENT) — what
+    mc.GraphedMC(lanes > 1) does while it captures.  The K-split of small-map layers, hence the f32 summation order, can
+    differ from the default (latency) plan by rounding."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _CONCURRENT
+        self.prev, _CONCURRENT = _CONCURRENT, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _CONCURRENT
+        _CONCURRENT = self.prev
+        return False
 
 
 def set_output_layout(layout):
@@ -260,7 +280,7 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     out_sp = op.out_spatial(spatial)
     if min(out_sp) <= 0:
         raise ValueError("output size is too small")
-    flags = (_lib.FLAG_TRANSPOSED if op.transposed else 0) | extra_flags
+    flags = (_lib.FLAG_TRANSPOSED if op.transposed else 0) | extra_flags | (_lib.FLAG_CONCURRENT if _CONCURRENT else 0)
     if out_dtype is not None and out_dtype != x.dtype:
         flags |= _lib.FLAG_OUT_BF16 if out_dtype == torch.bfloat16 else _lib.FLAG_OUT_F32
     # the geometry struct and the workspace size depend on shapes only: built once per (op, batch, extent, modes)

@@ -130,7 +130,7 @@ class GraphedMC:
 
     The parameters must not be re-allocated while the graph is alive (in-place updates are seen by the replays)."""
 
-    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1, keep_logits=False):
+    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1, keep_logits=False, concurrent_hint=None):
         """lanes > 1: one replay evaluates `lanes` MC samples, each on its own stream inside the graph (independent noise:
         the same results as one at a time) — the kernels of one sample fill the GPU while those of another are in their
         ramp-up / tail; use run_many()."""
@@ -147,6 +147,10 @@ class GraphedMC:
         self.packed = None
         self._lane_packed = [None] * self.lanes
         self._streams = [torch.cuda.Stream(dev) for _ in range(self.lanes)] if self.lanes > 1 else []
+        from . import functional as BF
+        conc_prev = BF._CONCURRENT
+        # several samples in flight: plan every launch for device throughput (no split-K through HBM to fill idle CUs)
+        BF._CONCURRENT = (self.lanes > 1) if concurrent_hint is None else bool(concurrent_hint)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
@@ -172,6 +176,7 @@ class GraphedMC:
                 for k in range(1, self.lanes):  # fold the lanes' statistics into lane 0's buffer
                     self._lane_packed[0].add_(self._lane_packed[k])
                     self._lane_packed[k].zero_()
+        BF._CONCURRENT = conc_prev
         for pk in self._lane_packed:
             pk.zero_()
         for m in self._layers:

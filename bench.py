@@ -278,16 +278,16 @@ def measure_traffic(timeout_s=150):
 class Runner:
     """`steps` MC samples of `model` on `x`: hipGraph replays (`lanes` samples in flight) or eager launches"""
 
-    def __init__(self, model, x, kl, num_classes, lanes, graph, presample=True, sizes=()):
+    def __init__(self, model, x, kl, num_classes, lanes, graph, presample=True, sizes=(), concurrent_hint=None):
         from bayesian_torch_amd import mc
         import bayesian_torch_amd as bt
         self.model, self.x, self.kl, self.graphed, self.rest = model, x, kl, None, {}
         self.presample = presample
         if graph:
             try:
-                self.graphed = mc.GraphedMC(model, x, kl=kl, lanes=max(1, lanes))
+                self.graphed = mc.GraphedMC(model, x, kl=kl, lanes=max(1, lanes), concurrent_hint=concurrent_hint)
                 # ragged last groups (counts that are not a multiple of the lane count): one smaller graph per remainder
-                self.rest = {r: mc.GraphedMC(model, x, kl=kl, lanes=r)
+                self.rest = {r: mc.GraphedMC(model, x, kl=kl, lanes=r, concurrent_hint=concurrent_hint)
                              for r in sorted({s % self.graphed.lanes for s in sizes} - {0})}
             except Exception as e:  # a runtime that cannot capture: measure the eager path rather than nothing
                 print("bench: hipGraph capture failed (%s: %s) - falling back to eager launches" % (type(e).__name__, e),
@@ -382,7 +382,8 @@ def logits_parity(model_fn, x, prec, sample=3):
 
 
 def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, world=1, rank=0, graph=True, fuse=True,
-                      presample=True, scaling="weak", total=None, per_launch=True, parity=False, prewarm=PREWARM_STEPS):
+                      presample=True, scaling="weak", total=None, per_launch=True, parity=False, prewarm=PREWARM_STEPS,
+                      concurrent_hint=None):
     import bayesian_torch_amd as bt
     from bayesian_torch_amd import mc
     bt.manual_seed(2024)
@@ -400,7 +401,7 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
         mine = [k * world + rank for k in range(steps)]
         n_global = steps * world
     warm = [20_000_000 + w * world + rank for w in range(prewarm)] + [10_000_000 + w * world + rank for w in range(warmup)]
-    runner = Runner(model, x, kl, 1000, lanes, graph, presample, sizes=(len(mine), len(warm)))
+    runner = Runner(model, x, kl, 1000, lanes, graph, presample, sizes=(len(mine), len(warm)), concurrent_hint=concurrent_hint)
     elapsed = timed_mc(runner, mine, warm, world, dev)
     stats = runner.packed.clone()
     lanes_used = runner.graphed.lanes if runner.graphed is not None else 0
@@ -581,6 +582,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="MC samples evaluated concurrently (one stream each) inside one "
                     "hipGraph replay; independent noise, identical results to one at a time")
     ap.add_argument("--no-presample", action="store_true")
+    ap.add_argument("--latency-plan", action="store_true", help="A/B: plan every launch for its own latency (split-K to fill "
+                    "idle CUs) although several MC samples are in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg2/cfg3/cfg5/f32 sub-results")
@@ -622,6 +625,7 @@ def main():
                              dev, world, rank, graph=not args.no_graph, fuse=not args.no_fuse,
                              presample=not args.no_presample, scaling=args.scaling, total=args.total_samples,
                              per_launch=not args.no_launch_timing and rank == 0,
+                             concurrent_hint=False if args.latency_plan else None,
                              parity=(rank == 0 and world == 1 and not args.no_extras))
     if rank == 0:
         peak = MFMA_PEAK_TFLOPS[args.prec]

@@ -71,6 +71,9 @@ extern "C" {
                                      SIGN_IN.  The data gradient of a Flipout layer is itself a Flipout-shaped contraction,
                                      dx = convT(dy, mu) + s_in * convT(dy * s_out, sigma*eps): the same entry point computes
                                      it on the transposed (or flipped) geometry with the two sign streams exchanged. */
+#define BTX_FLAG_CONCURRENT 128u  /* hint: other launches run beside this one (several MC samples in flight on their own
+                                     streams): plan for device throughput — CU-time — rather than for the latency of this
+                                     launch, i.e. do not split K through HBM just to fill idle CUs */
 #define BTX_FLAG_GATHER      32u  /* force the element-wise gather kernel (any shape / alignment; samples in registers).
                                      The library picks it by itself whenever a fast kernel does not apply; the flag
                                      exists so tests can exercise it on shapes the fast kernels would take. */

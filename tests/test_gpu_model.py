@@ -395,7 +395,16 @@ def test_graphed_mc_replays_equal_eager_samples():
         torch.cuda.synchronize()
         got3 = g2.packed.clone()
         g2.close()
-        assert torch.allclose(got3, eager, rtol=1e-6, atol=1e-6)  # same per-sample values, summed in a different order
+        # several samples in flight are planned for throughput (BTX_FLAG_CONCURRENT: no split-K through HBM): the eager
+        # reference of that comparison runs under the same plan
+        from bayesian_torch_amd import functional as BF
+        eager3 = torch.zeros_like(eager)
+        with torch.no_grad(), BF.concurrent_plan():
+            for s_ in samples:
+                bt.set_sample_index(m, s_)
+                mc.accumulate(eager3, m(x), 0.5)
+        assert torch.allclose(got3, eager3, rtol=1e-6, atol=1e-6)  # same per-sample values, summed in a different order
+        assert torch.allclose(got3, eager, rtol=0, atol=2e-2)      # the two plans differ by bf16 rounding only
         for mod in m.modules():
             if hasattr(mod, "_btx_layer_id"):
                 mod._btx_sample_dev = g.sample_dev
