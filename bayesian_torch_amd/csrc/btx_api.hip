@@ -639,7 +639,10 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   pt->taps = (!no_taps && pt->nw == 4 && pt->mi == 2 && pt->NI <= 6 && g->KH == 3 && g->KW == 3) ? 33 : 0;
   // Few pixel tiles (at most one 4-wave block per CU): 8-wave blocks of two K-groups — split-K inside the workgroup
   // through LDS instead of through HBM, and two waves per SIMD.  BTX_NO_KG=1 disables (A/B).
-  const bool no_kg = tune_env("BTX_NO_KG") != nullptr;
+  // BTX_FLAG_CONCURRENT: plain 4-wave blocks — an 8-wave block takes the whole LDS of its CU, so two such launches of
+  // different MC samples cannot share a CU; 4-wave blocks of two launches pair up and free-run against each other
+  // (measured, ResNet18 bs 64, 3 / 4 / 6 samples in flight: 1340 / 1369 / 1346 -> 1382 / 1402 / 1378 MC-samples/s).
+  const bool no_kg = tune_env("BTX_NO_KG") != nullptr || (flags & BTX_FLAG_CONCURRENT);
   pt->kg = (pt->taps && !no_kg && base <= 256 && ncb >= 2 && (ncb % 2) == 0 && 2 * pt->lds_g <= 163840) ? 2 : 1;
   const int units = ncb / pt->kg;  // channel blocks per K-group over the whole K
   int ks = 1;

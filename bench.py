@@ -172,10 +172,17 @@ def record_launches(model, x, sample_idx):
         torch.cuda.synchronize()
     finally:
         BF.contract_hip = orig
-    return recs
+    # row-fused stems run on a zero-padded geometry (3 -> 4 channels, 7 -> 8 taps per kernel row): their ALGORITHMIC
+    # contraction length is the layer's own KH*KW*Cin, not the padded one
+    algo_k = {}
+    for m in model.modules():
+        for plan in (m.__dict__.get("_btx_plans") or {}).values():
+            if plan is not None:
+                algo_k[id(plan["op"])] = m._op.kernel[1] * plan["kw"] * plan["cin"]
+    return recs, algo_k
 
 
-def time_launches(recs, prec, reps=10):
+def time_launches(recs, prec, reps=10, algo_k=None):
     """-> list of dicts (one per contraction launch of the step), GPU time from `reps` re-issues inside one hipGraph"""
     from bayesian_torch_amd import functional as BF
     from bayesian_torch_amd import _lib
@@ -205,6 +212,7 @@ def time_launches(recs, prec, reps=10):
         us = e0.elapsed_time(e1) / (2 * reps) * 1e3
         m_rows = y.numel() // op.out_channels
         k_red = op.kernel[0] * op.kernel[1] * op.kernel[2] * (op.in_channels // op.groups)
+        k_red = (algo_k or {}).get(id(op), k_red)
         nmm = 2 if kind == _lib.KIND_FLIPOUT else 1
         flops = 2.0 * m_rows * op.out_channels * k_red * nmm
         ep = k.get("epilogue") or {}
@@ -415,8 +423,8 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
     if known:
         res["kl_rel_err"] = abs(kl - known) / known
     if per_launch and dev.type == "cuda":
-        recs = record_launches(model, x, 7)
-        table = time_launches(recs, prec)
+        recs, algo_k = record_launches(model, x, 7)
+        table = time_launches(recs, prec, algo_k=algo_k)
         dom = [r for r in table if r["dominant"]] or table
         res["per_launch"] = table
         res["gflop_per_step"] = sum(r["gflop"] for r in table)
@@ -493,8 +501,9 @@ def run_train_step(dev, steps=5):
         loss = step()
     torch.cuda.synchronize(dev)
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    # forward 480 + data gradient 465 (no dx for the stem) + weight gradient 480 GFLOP (Flipout: two contractions each)
-    gflop = 480.2 + (480.2 - 46.0) + 480.2
+    # forward 464.4 + data gradient 434.2 (no dx for the stem) + weight gradient 464.4 GFLOP (Flipout: two contractions
+    # each; the stem counted with its own 7x7x3 taps, not the padded row-fused geometry)
+    gflop = 464.4 + (464.4 - 30.2) + 464.4
     return {"workload": "training step (README.md:114-125): dnn_to_bnn(ResNet18) Flipout bs64, bf16 activations, forward + "
                         "CE + KL/B + backward through libbtx (f32-MFMA weight gradients), eager launches",
             "ms_per_step": ms, "achieved_tflops": gflop / ms, "loss_finite": bool(torch.isfinite(loss))}
@@ -567,7 +576,7 @@ def dry_run(args, world, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=21)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--type", default="Flipout", choices=["Flipout", "Reparameterization"])
     ap.add_argument("--arch", default="resnet18", choices=["resnet18", "resnet50"])
@@ -579,7 +588,7 @@ def main():
                     "(BASELINE cfg4: 32 over 8 GPUs)")
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/residual as separate torch ops")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every MC sample from Python")
-    ap.add_argument("--lanes", type=int, default=3, help="MC samples evaluated concurrently (one stream each) inside one "
+    ap.add_argument("--lanes", type=int, default=4, help="MC samples evaluated concurrently (one stream each) inside one "
                     "hipGraph replay; independent noise, identical results to one at a time")
     ap.add_argument("--no-presample", action="store_true")
     ap.add_argument("--latency-plan", action="store_true", help="A/B: plan every launch for its own latency (split-K to fill "
