@@ -12,7 +12,7 @@ PREC_F32, PREC_BF16 = 0, 1
 FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER, FLAG_SWAP_SIGNS, FLAG_CONCURRENT = 1, 2, 4, 8, 16, 32, 64, 128
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class BtxError(RuntimeError):
@@ -32,7 +32,7 @@ class Rng(ctypes.Structure):
 
 class Epilogue(ctypes.Structure):
     _fields_ = [("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("residual", ctypes.c_void_p),
-                ("relu", ctypes.c_int32)]
+                ("relu", ctypes.c_int32), ("pool", ctypes.c_int32)]
 
 
 class Noise(ctypes.Structure):
@@ -54,7 +54,7 @@ class KlItem(ctypes.Structure):
 
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss", "btx_kl_model_workspace_bytes",
            "btx_kl_gauss_model", "btx_kl_gauss_model_bwd", "btx_contract_wgrad",
-           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
+           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
            "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
 
 
@@ -98,6 +98,8 @@ def lib():
                                    ctypes.POINTER(Noise), i32, i32, u32, vp, sz, vp]
     L.btx_contract_fwd_ex.restype = i32
     L.btx_contract_fwd_ex.argtypes = L.btx_contract_fwd.argtypes + [ctypes.POINTER(Epilogue)]
+    L.btx_contract_pool_shape.restype = i32
+    L.btx_contract_pool_shape.argtypes = [ctypes.POINTER(Geom), i32, i32, u32] + [ctypes.POINTER(ctypes.c_int32)] * 2
     L.btx_out_shape.restype = i32
     L.btx_out_shape.argtypes = [ctypes.POINTER(Geom), u32] + [ctypes.POINTER(ctypes.c_int32)] * 3
     L.btx_fill_eps.restype = i32

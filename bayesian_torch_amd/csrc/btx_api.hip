@@ -708,6 +708,43 @@ static bool make_stem_plan(const BtxGeom* g, int act_dtype, int prec, const Plan
   return false;
 }
 
+// Plan of the stem + max-pool variant (btx_contract_stempool.h): 8-wave workgroups, one per CU, each walking a band of
+// `TB` four-row tiles of one image with all weight tiles resident in LDS.  bf16 only; the pool is 3x3 / stride 2 / pad 1.
+struct StemPoolPlan {
+  int TB, bands, Rp, astage, sbytes, lds, patch_bytes, nwg, Hq, Wq;
+};
+static bool make_stem_pool_plan(const BtxGeom* g, int act_dtype, int prec, const Plan& pl, StemPoolPlan* sp) {
+  if (prec != BTX_PREC_BF16 || act_dtype != BTX_ACT_BF16) return false;
+  if (g->D != 1 || g->KD != 1 || pl.Do != 1 || g->groups != 1) return false;
+  const int bk = NG * 8;
+  if ((g->KW * g->C) % bk || pl.K % bk || (g->N % 64)) return false;
+  const int nstages = pl.K / bk;
+  if (nstages < 1 || nstages > 7) return false;
+  if (2 * pl.Wo > 256 || pl.Ho < 1) return false;
+  const int Hq = (pl.Ho - 1) / 2 + 1, Wq = (pl.Wo - 1) / 2 + 1;
+  if (2 * Wq * 4 > 512) return false;
+  const long long rowB = (long long)g->W * g->C * 2;
+  const long long Rp = 3LL * g->sh + g->KH;
+  const long long pb = Rp * rowB;
+  const long long astage = (pb + 8191) / 8192 * 8192;
+  const long long sbytes = ((pb / 2 + 31) / 32 + 3) * 4;
+  const long long sb16 = (sbytes + 15) / 16 * 16;
+  const long long lds = (long long)nstages * 8192 + 2 * astage + 2 * sb16 + 6LL * pl.Wo * 64 + 1024;
+  if (lds > 163840) return false;
+  // bands: about one workgroup per CU, at least two tiles per band (every band pays one closing one-row tile)
+  const long long units = (long long)g->NB * pl.ntiles;
+  long long TB = ((long long)Hq * units) / 512;
+  const int tb_max = (Hq + 1) / 2;
+  if (TB < 2) TB = 2;
+  if (TB > tb_max) TB = tb_max;
+  const int bands = (Hq + 2 * (int)TB - 1) / (2 * (int)TB);
+  const long long nwg = units * bands;
+  if (nwg > 0x7fffffffLL) return false;
+  sp->TB = (int)TB; sp->bands = bands; sp->Rp = (int)Rp; sp->astage = (int)astage; sp->sbytes = (int)sb16;
+  sp->lds = (int)lds; sp->patch_bytes = (int)pb; sp->nwg = (int)nwg; sp->Hq = Hq; sp->Wq = Wq;
+  return true;
+}
+
 // workspace of the patch variant: split-K partials (256-byte padded), then the pre-sampled weight tiles
 static size_t patch_wt_bytes(const Plan& pl, const BtxGeom* g, int kind, int prec, size_t* one) {
   const size_t arr = (size_t)g->groups * pl.ntiles * 64 * (size_t)pl.K * (prec == BTX_PREC_BF16 ? 2 : 4);
@@ -718,6 +755,20 @@ static size_t pad256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t plan_ws(const Plan& pl, const BtxGeom* g) {
   return pl.ksplits > 1 ? (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
+}
+
+int btx_contract_pool_shape(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, int32_t* Hq, int32_t* Wq) {
+  if (!g || !(flags & BTX_FLAG_ROWFUSE) || (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_OUT_F32 | BTX_FLAG_SWAP_SIGNS | BTX_FLAG_GATHER)))
+    return 0;
+  Plan sp;
+  StemPlan stp;
+  StemPoolPlan spp;
+  if (make_plan(g, prec, flags, DBM, &sp) || !make_stem_plan(g, act_dtype, prec, sp, &stp) ||
+      !make_stem_pool_plan(g, act_dtype, prec, sp, &spp))
+    return 0;
+  if (Hq) *Hq = spp.Hq;
+  if (Wq) *Wq = spp.Wq;
+  return 1;
 }
 
 size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, int prec, uint32_t flags) {
@@ -802,6 +853,17 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
       pl = sp;
       stem = true;
     }
+  }
+  // stem + max-pool (BtxEpilogue.pool): the band kernel of btx_contract_stempool.h or nothing
+  StemPoolPlan spp;
+  const bool want_pool = ep && ep->pool;
+  if (want_pool) {
+    Plan sp;
+    if (ep->pool != 1 || !stem || ep->residual || (noise && (noise->sign_in || noise->sign_out)) ||
+        (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_SWAP_SIGNS)) || make_plan(g, prec, flags, DBM, &sp) ||
+        !make_stem_pool_plan(g, act_dtype, prec, sp, &spp))
+      return BTX_E_UNSUPPORTED;
+    pl.nwg = spp.nwg;
   }
   // patch variant: stride-1 2-D convolutions keep the halo'd input patch of the tile in LDS (BTX_NO_PATCH=1 disables)
   static const bool no_patch = tune_env("BTX_NO_PATCH") != nullptr;
@@ -903,7 +965,12 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.wt_delta_off = (uint32_t)wt_one;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (stem) {
+  if (want_pool) {
+    p.pt_R = spp.TB; p.pt_rtiles = spp.bands; p.pt_Rp = spp.Rp; p.pt_astage = spp.astage; p.st_sbytes = spp.sbytes;
+    p.pt_lds = spp.lds; p.pt_PP = spp.patch_bytes; p.sp_Hq = spp.Hq; p.sp_Wq = spp.Wq;
+    p.fd_rtiles = make_fastdiv((uint32_t)spp.bands);
+    rc = launch_stem_pool_bf16(kind, p, pl.nwg, st);
+  } else if (stem) {
     p.pt_R = stp.R; p.pt_Rp = stp.Rp; p.pt_rtiles = stp.rtiles; p.pt_nw = stp.nw; p.pt_astage = stp.astage;
     p.st_sbytes = stp.sbytes; p.pt_lds = stp.lds; p.pt_PP = stp.patch_bytes;
     p.fd_rtiles = make_fastdiv((uint32_t)stp.rtiles);

@@ -130,6 +130,7 @@ struct ContractParams {
   int pt_kg;      // tap-unrolled kernel: K-groups per workgroup (1 | 2)
   int pt_lds_g;   //                      LDS bytes of one K-group
   int pt_taps;    // 10*KH + KW when the tap-unrolled kernel (btx_contract_taps.h) takes the launch, else 0
+  int sp_Hq, sp_Wq;  // stem + max-pool variant (btx_contract_stempool.h): pooled extent
   int st_sbytes;  // stem variant: bytes of the s_in word array in LDS  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off
   uint32_t wt_bytes, wt_delta_off;
@@ -748,6 +749,7 @@ int launch_contract_dma_bf16(int kind, const ContractParams& p, int nwg, hipStre
 int launch_contract_patch_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_stem_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_stem_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_stem_pool_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
 struct PresampleBatch;
 int launch_presample_batch_f32(const PresampleBatch& b, hipStream_t st);
 int launch_presample_batch_bf16(const PresampleBatch& b, hipStream_t st);

@@ -382,12 +382,12 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     }
     if (cbi < ncb) block(std::integral_constant<int, 0>{}, cbi, true);
     if (KG == 2 && kg == 0) asm volatile("s_barrier" ::: "memory");
-    };  // kloop
-    if (mi1_dead) kloop(std::integral_constant<int, 1>{});
-    else kloop(std::integral_constant<int, 2>{});
 #ifdef BTX_PT_TRACE
     tr_s[0] = tr_ab; tr_s[1] = tr_lg; tr_s[2] = tr_bc; tr_s[3] = tr_cd;
 #endif
+    };  // kloop
+    if (mi1_dead) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 2>{});
   }
 #ifdef BTX_PT_TRACE
   tr_t2 = (uint32_t)__builtin_amdgcn_s_memtime();

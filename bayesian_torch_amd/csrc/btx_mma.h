@@ -42,7 +42,8 @@ __device__ __forceinline__ void load_delta(DeltaFrag& d, const unsigned char* ws
 // prefetch of the next stage): LDS returns in order, so delta fragments queued behind a prefetch would make the delta
 // MFMAs wait for data they do not need.
 // MIA = the wave's 32-pixel tiles that hold real pixels (<= MI): the tiles behind them are tile padding and are skipped.
-template <int PREC, int KIND, int MI = 2, int MIA = MI>
+// ZERO (bf16): first stage of a tile — the accumulators start from the MFMA's inline zero operand instead of 128 v_mov.
+template <int PREC, int KIND, int MI = 2, int MIA = MI, bool ZERO = false>
 __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& dfrag, f32x16 (&accm)[MI][2],
                                           f32x16 (&accd)[MI][2], int l31, int h) {
     const u32x4 (&wd)[NG / 2][2] = dfrag.w;
@@ -57,7 +58,11 @@ __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& df
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(f.wm[kk][ni]), "v"(f.a[kk][mi])); accm[mi][ni][0] += 1.f; }
-            else accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            else if constexpr (ZERO) {
+              const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, f.wm[kk][ni]), __builtin_bit_cast(bf16x8, f.a[kk][mi]), kk == 0 ? zc : accm[mi][ni], 0, 0, 0);
+            } else accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                 __builtin_bit_cast(bf16x8, f.wm[kk][ni]), __builtin_bit_cast(bf16x8, f.a[kk][mi]), accm[mi][ni], 0, 0, 0);
           }
       } else {
@@ -88,7 +93,11 @@ __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& df
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
               if constexpr (BTX_PT_ABL & 1) { asm volatile("" ::"v"(wd[kk][ni]), "v"(f.a[kk][mi])); accd[mi][ni][0] += 1.f; }
-              else accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              else if constexpr (ZERO) {
+                const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, wd[kk][ni]), __builtin_bit_cast(bf16x8, f.a[kk][mi]), kk == 0 ? zc : accd[mi][ni], 0, 0, 0);
+              } else accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                   __builtin_bit_cast(bf16x8, wd[kk][ni]), __builtin_bit_cast(bf16x8, f.a[kk][mi]), accd[mi][ni], 0, 0, 0);
             }
         } else {

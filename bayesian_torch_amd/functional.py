@@ -299,6 +299,11 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
             _GEOM_CACHE.clear()
         cached = _GEOM_CACHE[gkey] = (g, L.btx_contract_workspace_bytes(ctypes.byref(g), kind, act, prec_c, flags), op)
     g, need = cached[0], cached[1]
+    if epilogue is not None and epilogue.get("pool"):  # BtxEpilogue.pool: `out` is the max-pooled tensor
+        hq, wq = ctypes.c_int32(0), ctypes.c_int32(0)
+        if not L.btx_contract_pool_shape(ctypes.byref(g), act, prec_c, flags, ctypes.byref(hq), ctypes.byref(wq)):
+            raise _lib.BtxError("the fused stem max-pool is not available for this geometry (contract_pool_ok)")
+        out_sp = (1, hq.value, wq.value)
     out = _alloc_out(op, nb, out_sp, out_dtype or x.dtype, x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     ws = _workspace(x.device, need, stream) if need else None
@@ -351,6 +356,7 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
             keep.append(rp)
             ep.residual = rp.data_ptr()
         ep.relu = 1 if epilogue.get("relu") else 0
+        ep.pool = 1 if epilogue.get("pool") else 0
     rc = L.btx_contract_fwd_ex(kind, ctypes.byref(g), xp.data_ptr(), mu_p.data_ptr(), rho_p.data_ptr(),
                                mu_b.data_ptr() if mu_b is not None else None,
                                rho_b.data_ptr() if rho_b is not None else None,
@@ -497,6 +503,23 @@ def rowfuse_plan(op, x_shape):
     Hp = H + 2 * ph
     fop = OpDesc(2, cp, op.out_channels, (kh, kwp), (sh, sw), 0, 1, 1)
     return dict(op=fop, Hp=Hp, Wp=Wp, ph=ph, pw=pw, Ho=Ho, Wo=Wo, kw=kw, kwp=kwp, cp=cp, cin=op.in_channels)
+
+
+def contract_pool_ok(op, nb, spatial, act_dtype, prec, extra_flags=0):
+    """True when btx_contract_fwd_ex takes BtxEpilogue.pool = 1 (the ResNet stem's MaxPool2d(3, 2, 1) folded into the
+    store of the row-fused stem contraction) for this geometry."""
+    L = _lib.lib()
+    g = _lib.Geom()
+    g.NB, (g.D, g.H, g.W), g.C, g.N = nb, spatial, op.in_channels, op.out_channels
+    g.KD, g.KH, g.KW = op.kernel
+    g.sd, g.sh, g.sw = op.stride
+    g.pd, g.ph, g.pw = op.padding
+    g.dd, g.dh, g.dw = op.dilation
+    g.od, g.oh, g.ow = op.output_padding
+    g.groups = op.groups
+    act = _lib.ACT_BF16 if act_dtype == torch.bfloat16 else _lib.ACT_F32
+    prec_c = _lib.PREC_BF16 if prec == "bf16" else _lib.PREC_F32
+    return bool(L.btx_contract_pool_shape(ctypes.byref(g), act, prec_c, extra_flags, None, None))
 
 
 def rowfuse_input(x, plan, out_dtype=None):

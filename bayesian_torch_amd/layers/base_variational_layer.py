@@ -307,7 +307,11 @@ class _VariationalNd(BaseVariationalLayer_):
             out = BF.contract_hip(kind, xin, mu_f, rho_f, mb, rb, plan["op"], _rng.seed(), sample_idx,
                                   self._btx_layer_id, prec=prec, extra_flags=_lib.FLAG_ROWFUSE, out_dtype=x.dtype,
                                   epilogue=epilogue, sampled_w=pre, sample_dev=getattr(self, "_btx_sample_dev", None))
+            if epilogue is not None and epilogue.get("pool"):
+                return out  # pooled inside the launch (pool_fusable() vouched for the geometry)
             return out[:, :, :plan["Ho"], :plan["Wo"]]
+        if epilogue is not None and epilogue.get("pool"):
+            raise _lib.BtxError("the fused max-pool needs the row-fused stem path (pool_fusable)")
         if self._btx_cpad is not None and noise is None:  # explicit noise (parity mode) stays unpadded -> gather kernel
             extra = self._btx_cpad - op.in_channels
             x = BF.pad_channels(x, op, extra)
@@ -323,12 +327,28 @@ class _VariationalNd(BaseVariationalLayer_):
                                sample_dev=getattr(self, "_btx_sample_dev", None),
                                extra_flags=_lib.FLAG_GATHER if gather else 0)
 
-    def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False):
+    def pool_fusable(self, x):
+        """True when forward_fused(..., pool=True) can fold nn.MaxPool2d(3, 2, 1) into this layer's launch: a row-fused
+        bf16 stem on the GPU whose padded geometry has exactly the layer's output extent (btx_contract_pool_shape)."""
+        if not self._use_hip(x) or x.dtype != torch.bfloat16 or (self.precision or BF.get_precision()) != "bf16":
+            return False
+        plan = self._rowfuse_plan(x)
+        if plan is None:
+            return False
+        fo = plan["op"].out_spatial((1, plan["Hp"], plan["Wp"]))
+        if (fo[1], fo[2]) != (plan["Ho"], plan["Wo"]):
+            return False
+        return BF.contract_pool_ok(plan["op"], x.shape[0], (1, plan["Hp"], plan["Wp"]), torch.bfloat16, "bf16",
+                                   _lib.FLAG_ROWFUSE)
+
+    def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False, pool=False):
         """`relu?(forward(x) * scale[c] + shift[c] (+ residual))` with the affine / residual / ReLU
         folded into the store of the HIP contraction (eval-mode BatchNorm folds into scale/shift).  Returns `out` only.
         CPU tensors / autograd evaluate the same expression with ATen ops."""
         if self._use_hip(x):
-            return self._forward_hip(x, epilogue=dict(scale=scale, shift=shift, residual=residual, relu=relu))
+            return self._forward_hip(x, epilogue=dict(scale=scale, shift=shift, residual=residual, relu=relu, pool=pool))
+        if pool:
+            raise _lib.BtxError("forward_fused(pool=True) is a GPU path (pool_fusable)")
         out = self._forward_aten(x, False)
         shape = (1, -1) + (1,) * self._op.nd if self._op.nd else (1, -1)
         if scale is not None:

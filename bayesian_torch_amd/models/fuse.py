@@ -6,6 +6,7 @@ The module tree is untouched (state_dict keys of the fused and the unfused model
 way) and the folded (scale, shift) follow the BatchNorm tensors.  Only for inference (`model.eval()`); the unfused model
 is the parity reference (tests/test_gpu_model.py).
 """
+import os
 import types
 
 import torch
@@ -44,9 +45,9 @@ class _Folded:
             self._ss, self._key = fold_bn(bn), key
         return self._ss
 
-    def __call__(self, x, residual=None, relu=False):
+    def __call__(self, x, residual=None, relu=False, pool=False):
         scale, shift = self._scale_shift()
-        return self.conv.forward_fused(x, scale, shift, residual, relu)
+        return self.conv.forward_fused(x, scale, shift, residual, relu, pool=pool)
 
 
 def _downsample(self, x):
@@ -99,8 +100,27 @@ def fuse_resnet(model):
                 return BF.maxpool2d_hip(y, mp.kernel_size, mp.stride, mp.padding)
             return mp(y)
 
+        def stem_pool_fusable(self, x):
+            """conv1 -> bn1 -> relu -> MaxPool2d(3, 2, 1) in ONE launch (btx_contract_stempool.h): the 112x112 conv
+            output never reaches HBM.  Decided per input shape; everything else pools with its own kernel."""
+            mp = self.maxpool
+            if os.environ.get("BTX_NO_STEM_POOL"):  # A/B measurements
+                return False
+            if not (isinstance(mp, nn.MaxPool2d) and mp.kernel_size in (3, (3, 3)) and mp.stride in (2, (2, 2))
+                    and mp.padding in (1, (1, 1)) and mp.dilation in (1, (1, 1)) and not mp.ceil_mode
+                    and not mp.return_indices and not torch.is_grad_enabled()):
+                return False
+            cache = self.__dict__.setdefault("_stem_pool_ok", {})
+            key = (tuple(x.shape), x.dtype, x.device)
+            if key not in cache:
+                cache[key] = bool(self.conv1.pool_fusable(x))
+            return cache[key]
+
         def fwd(self, x):
-            x = pool(self.maxpool, self._stem(x, None, True))
+            if stem_pool_fusable(self, x):
+                x = self._stem(x, None, True, pool=True)
+            else:
+                x = pool(self.maxpool, self._stem(x, None, True))
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
             ap = self.avgpool
             # the reference's nn.AvgPool2d(7, stride=1) on a 7x7 map (resnet_large.py:125) and torchvision's

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BTX_ABI_VERSION 3
+#define BTX_ABI_VERSION 4
 
 /* argument-error codes (negative) */
 #define BTX_E_NULL        (-1)   /* required pointer is NULL */
@@ -181,13 +181,20 @@ int btx_contract_fwd(int kind, const BtxGeom* g,
 /* §8(f)-3, the step either side of the path: eval-mode BatchNorm (+ residual add, + ReLU) folded into the store of the
  * contraction (reference models/deterministic/resnet_large.py:49-60: out = relu(bn(conv(x)) [+ identity])).
  *   y = conv_out * scale[n] + shift[n]  (+ residual[same index as out])  ;  y = max(y, 0) if relu
- * scale/shift: f32 [N] (NULL => 1 / 0); residual: same layout and dtype as `out` (NULL => none). */
+ * scale/shift: f32 [N] (NULL => 1 / 0); residual: same layout and dtype as `out` (NULL => none).
+ * pool = 1: the ResNet stem's nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (resnet_large.py:118,145) is applied to y
+ * inside the same launch and `out` is the POOLED tensor [NB][Hq][Wq][N] (btx_contract_pool_shape); the conv output never
+ * reaches HBM.  Row-fused bf16 stems only (BTX_FLAG_ROWFUSE, generated noise, no residual): everything else returns
+ * BTX_E_UNSUPPORTED and the caller pools with btx_maxpool2d_cl.  Values are bit-identical to the two-launch chain. */
 typedef struct BtxEpilogue {
   const float* scale;
   const float* shift;
   const void*  residual;
   int32_t      relu;
+  int32_t      pool;
 } BtxEpilogue;
+/* 1 (and the pooled extent) when btx_contract_fwd_ex would take epilogue.pool = 1 for this geometry, else 0 */
+int btx_contract_pool_shape(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, int32_t* Hq, int32_t* Wq);
 int btx_contract_fwd_ex(int kind, const BtxGeom* g,
                         const void* x, const float* mu_w, const float* rho_w,
                         const float* mu_b, const float* rho_b,

@@ -28,7 +28,7 @@ def test_abi_version_and_argument_errors_without_gpu():
     """pure host-side calls: version, strerror, shape arithmetic, argument validation (no kernel is launched)"""
     from bayesian_torch_amd import _lib
     L = _lib.lib()
-    assert L.btx_abi_version() == 3
+    assert L.btx_abi_version() == 4
     assert b"NULL" in L.btx_strerror(-1)
     g = _lib.Geom()
     g.NB, g.D, g.H, g.W, g.C, g.N = 64, 1, 56, 56, 64, 128

@@ -156,6 +156,67 @@ def test_fused_epilogue_matches_unfused_layer(prec, act, tol):
         assert (got >= 0).all()
 
 
+@pytest.mark.parametrize("family", ["Flipout", "Reparameterization"])
+def test_stem_with_fused_maxpool_is_bit_identical_to_the_two_launch_chain(family):
+    """BtxEpilogue.pool (btx_contract_stempool.h): conv1 -> bn1 -> relu -> MaxPool2d(3, 2, 1) in one launch == the stem
+    launch followed by torch's max-pool, bit for bit, for the same MC sample; even / odd extents, band edges, bias and no
+    bias, with and without ReLU / affine."""
+    import torch.nn.functional as F
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    cls = getattr(L, "Conv2d" + family)
+    cases = [((2, 3, 224, 224), True, True, False), ((5, 3, 64, 64), True, True, True), ((3, 3, 70, 62), True, False, True),
+             ((1, 3, 97, 130), False, True, False), ((9, 3, 32, 48), True, True, False), ((2, 3, 37, 33), False, False, True)]
+    for xs, relu, affine, bias in cases:
+        torch.manual_seed(11)
+        layer = cls(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=bias).to(dev)
+        layer.precision = "bf16"
+        x = torch.randn(*xs, device=dev).to(torch.bfloat16)
+        scale = (torch.rand(64, device=dev) + 0.5).contiguous() if affine else None
+        shift = torch.randn(64, device=dev).contiguous() if affine else None
+        with torch.no_grad():
+            assert layer.pool_fusable(x), xs
+            layer._btx_sample = 5
+            conv = layer.forward_fused(x, scale, shift, None, relu)
+            ref = F.max_pool2d(conv.float(), 3, 2, 1)
+            layer._btx_sample = 5
+            got = layer.forward_fused(x, scale, shift, None, relu, pool=True)
+        assert got.shape == ref.shape, (xs, got.shape, ref.shape)
+        assert got.dtype == torch.bfloat16
+        assert torch.equal(got.float(), ref), (family, xs, float((got.float() - ref).abs().max()))
+    # f32 activations keep the two-launch chain
+    lf = cls(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False).to(dev)
+    assert not lf.pool_fusable(torch.randn(2, 3, 64, 64, device=dev))
+
+
+def test_fused_resnet18_bf16_takes_the_one_launch_stem_and_matches_the_pool_kernel():
+    """fuse_resnet(): bf16 inputs route conv1/bn1/relu/maxpool through the one-launch stem; logits equal those of the
+    same fused model with the stem pool forced onto its own kernel (bit-identical stem -> identical logits)"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.resnet import resnet18
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    dev = _dev()
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(PRIOR, type="Flipout"))
+    m = m.to(dev).eval()
+    bt.set_precision("bf16")
+    try:
+        fuse_resnet(m)
+        x = torch.randn(4, 3, 224, 224, device=dev).to(torch.bfloat16)
+        with torch.no_grad():
+            bt.set_sample_index(m, 3, presample=True)
+            a = m(x)
+            assert m.__dict__["_stem_pool_ok"] and all(m.__dict__["_stem_pool_ok"].values())
+            for k in m.__dict__["_stem_pool_ok"]:
+                m.__dict__["_stem_pool_ok"][k] = False
+            bt.set_sample_index(m, 3, presample=True)
+            b = m(x)
+        assert torch.equal(a, b)
+    finally:
+        bt.set_precision("f32")
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 4e-3)])
 def test_avgpool_global_cl_matches_torch(dtype, tol):
     from bayesian_torch_amd import functional as BF
