@@ -709,9 +709,9 @@ static bool make_stem_plan(const BtxGeom* g, int act_dtype, int prec, const Plan
 }
 
 // Plan of the stem + max-pool variant (btx_contract_stempool.h): 8-wave workgroups, one per CU, each walking a band of
-// `TB` four-row tiles of one image with all weight tiles resident in LDS.  bf16 only; the pool is 3x3 / stride 2 / pad 1.
+// `PB` pooled rows of one image with all weight tiles resident in LDS.  bf16 only; the pool is 3x3 / stride 2 / pad 1.
 struct StemPoolPlan {
-  int TB, bands, Rp, astage, sbytes, lds, patch_bytes, nwg, Hq, Wq;
+  int PB, bands, Rp, astage, sbytes, lds, patch_bytes, nwg, Hq, Wq;
 };
 static bool make_stem_pool_plan(const BtxGeom* g, int act_dtype, int prec, const Plan& pl, StemPoolPlan* sp) {
   if (prec != BTX_PREC_BF16 || act_dtype != BTX_ACT_BF16) return false;
@@ -722,25 +722,23 @@ static bool make_stem_pool_plan(const BtxGeom* g, int act_dtype, int prec, const
   if (nstages < 1 || nstages > 7) return false;
   if (2 * pl.Wo > 256 || pl.Ho < 1) return false;
   const int Hq = (pl.Ho - 1) / 2 + 1, Wq = (pl.Wo - 1) / 2 + 1;
-  if (2 * Wq * 4 > 512) return false;
   const long long rowB = (long long)g->W * g->C * 2;
-  const long long Rp = 3LL * g->sh + g->KH;
+  const long long Rp = (long long)g->sh + g->KH;  // input rows of a half tile (two conv rows)
   const long long pb = Rp * rowB;
-  const long long astage = (pb + 8191) / 8192 * 8192;
+  const long long astage = (pb + 1023) / 1024 * 1024;
   const long long sbytes = ((pb / 2 + 31) / 32 + 3) * 4;
-  const long long sb16 = (sbytes + 15) / 16 * 16;
+  const long long sb16 = (sbytes + 63) / 64 * 64;  // keeps the store-side rows 64-byte aligned (chunk swizzle in address bits)
   const long long lds = (long long)nstages * 8192 + 2 * astage + 2 * sb16 + 6LL * pl.Wo * 64 + 1024;
   if (lds > 163840) return false;
-  // bands: about one workgroup per CU, at least two tiles per band (every band pays one closing one-row tile)
+  // bands: about one workgroup per CU (every band pays two phases of fill / drain and a closing one-row half tile)
   const long long units = (long long)g->NB * pl.ntiles;
-  long long TB = ((long long)Hq * units) / 512;
-  const int tb_max = (Hq + 1) / 2;
-  if (TB < 2) TB = 2;
-  if (TB > tb_max) TB = tb_max;
-  const int bands = (Hq + 2 * (int)TB - 1) / (2 * (int)TB);
+  long long PB = ((long long)Hq * units) / 256;
+  if (PB < 4) PB = 4;
+  if (PB > Hq) PB = Hq;
+  const int bands = (Hq + (int)PB - 1) / (int)PB;
   const long long nwg = units * bands;
   if (nwg > 0x7fffffffLL) return false;
-  sp->TB = (int)TB; sp->bands = bands; sp->Rp = (int)Rp; sp->astage = (int)astage; sp->sbytes = (int)sb16;
+  sp->PB = (int)PB; sp->bands = bands; sp->Rp = (int)Rp; sp->astage = (int)astage; sp->sbytes = (int)sb16;
   sp->lds = (int)lds; sp->patch_bytes = (int)pb; sp->nwg = (int)nwg; sp->Hq = Hq; sp->Wq = Wq;
   return true;
 }
@@ -966,7 +964,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   }
   hipStream_t st = (hipStream_t)stream;
   if (want_pool) {
-    p.pt_R = spp.TB; p.pt_rtiles = spp.bands; p.pt_Rp = spp.Rp; p.pt_astage = spp.astage; p.st_sbytes = spp.sbytes;
+    p.pt_R = spp.PB; p.pt_rtiles = spp.bands; p.pt_Rp = spp.Rp; p.pt_astage = spp.astage; p.st_sbytes = spp.sbytes;
     p.pt_lds = spp.lds; p.pt_PP = spp.patch_bytes; p.sp_Hq = spp.Hq; p.sp_Wq = spp.Wq;
     p.fd_rtiles = make_fastdiv((uint32_t)spp.bands);
     rc = launch_stem_pool_bf16(kind, p, pl.nwg, st);
