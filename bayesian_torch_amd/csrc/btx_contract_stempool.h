@@ -11,15 +11,20 @@
 //   * the two groups of four waves alternate roles.  In phase f one group multiplies half tile f (its K loop) while
 //     the other runs the store side of half tile f-1 from its accumulator registers — per SIMD one wave feeds the matrix
 //     pipe while the other does the VALU / LDS work of the epilogue, and the next phase they swap.  (A first version
-//     that had all eight waves multiply, then all eight store, spent 30 % of its time in the K loops: 105 us.)  A phase
-//     is four steps with a workgroup barrier after each: K role: a quarter of the stages per step; store role: stage
-//     channels 0-31 | pool them | stage channels 32-63 | pool them;
+//     that had all eight waves multiply, then all eight store, spent 30 % of its time in the K loops: 105 us per launch.)
+//     A phase is three steps with a workgroup barrier after each;
+//   * Flipout: x * s_in of the half tile is written ONCE per input element into a second copy of the patch (step 1 of
+//     the K role) and the K loop runs as two passes — mean pass: raw patch x mu tiles, delta pass: signed copy x delta
+//     tiles — instead of masking every activation fragment (each input element sits in ~12 fragments of a 7x7 / stride-2
+//     stem; the second version was bound by the VALU port: ~100 VALU per stage and wave for 16 MFMAs);
+//     K role: sign copy + mean pass | delta stages 0-3 | delta stages 4-6; store role: stage channels 0-31 | stage
+//     channels 32-63 | pool all 64 and prepare the next carry row;
 //   * the input rows of half tile f+1 are fetched (one contiguous byte range, LDS-DMA) by the K group and their s_in
 //     words hashed by the store group during phase f;
 //   * the epilogue (bias, Flipout combine, BN affine, bf16 rounding — the same arithmetic, in the same order, as
-//     btx_epilogue.h) writes the half tile's conv rows r0, r1 into LDS, 32 channels at a time (XOR-swizzled 16-byte
-//     chunks); pooled row P0+u-1 = max3x3 over (carry, r0) of half tile u, carry = max(r0, r1) of half tile u-1, one LDS
-//     row per channel half (c0 = 2*P0 - 1 is the band's first conv row, r0 = c0 + 2u).  A band of PB pooled rows needs
+//     btx_epilogue.h) writes the half tile's conv rows r0, r1 into LDS (128 bytes per pixel, XOR-swizzled 16-byte
+//     chunks); pooled row P0+u-1 = max3x3 over (carry, r0) of half tile u, carry = max(r0, r1) of half tile u-1 in a
+//     third LDS row (c0 = 2*P0 - 1 is the band's first conv row, r0 = c0 + 2u).  A band of PB pooled rows needs
 //     2*PB + 1 conv rows: PB half tiles and a closing one-row half tile.  ReLU is applied after the max (both are
 //     monotonic, bf16 rounding too): the pool then compares the bf16 bit patterns as signed 16-bit integers — equal to
 //     the float order whenever the maximum is non-negative, and a negative maximum becomes 0 either way.  Values are
@@ -37,7 +42,7 @@
 namespace btx {
 
 constexpr int SP_HROWS = 2;  // conv rows per half tile
-constexpr int SP_LROWS = 6;  // LDS rows of the store side: r0, r1 and, per channel half, the carry rows of even / odd half tiles
+constexpr int SP_LROWS = 3;  // LDS rows (64 channels each) of the store side: r0, r1 and the carry row
 constexpr int SP_MAXST = 7;  // K-stages whose weight tiles stay resident
 
 typedef __attribute__((ext_vector_type(8))) short i16x8;
@@ -59,16 +64,40 @@ __device__ __forceinline__ u32x4 sp_max8(const u32x4 a, const u32x4 b) {
   }
 }
 
+// fragments of one K-stage of one pass: activations a[kk][mi] and weights w[kk][ni]
+struct SpFrag {
+  u32x4 a[NG / 2][2], w[NG / 2][2];
+};
+template <int MIA, bool ZERO>
+__device__ __forceinline__ void sp_mma(const SpFrag& f, f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int kk = 0; kk < NG / 2; ++kk)
+#pragma unroll
+    for (int mi = 0; mi < MIA; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if constexpr (ZERO) {
+          const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.w[kk][ni]),
+                                                               __builtin_bit_cast(bf16x8, f.a[kk][mi]),
+                                                               kk == 0 ? zc : acc[mi][ni], 0, 0, 0);
+        } else {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.w[kk][ni]),
+                                                               __builtin_bit_cast(bf16x8, f.a[kk][mi]), acc[mi][ni], 0, 0, 0);
+        }
+      }
+}
+
 // ContractParams fields used: pt_R (pooled rows per band), pt_rtiles (bands per image), pt_PP (patch bytes), pt_astage
-// (patch slot bytes, 1-KiB multiple), st_sbytes (bytes of one sign-word slot), sp_Hq / sp_Wq (pooled extent).  Geometry
-// as for contract_stem_kernel (BTX_FLAG_ROWFUSE).
+// (patch slot bytes, 1-KiB multiple), st_sbytes (bytes of one sign-word slot, 128-byte multiple), sp_Hq / sp_Wq (pooled
+// extent).  Geometry as for contract_stem_kernel (BTX_FLAG_ROWFUSE).
 template <int KIND>
 __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams p) {
   constexpr int G = 8, BK = NG * G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef BTX_PT_TRACE
   const uint32_t tr_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
-  uint32_t tr_pro = 0, tr_k = 0, tr_st = 0, tr_pool = 0, tr_bar = 0, tr_x = 0;
+  uint32_t tr_pro = 0, tr_k = 0, tr_st = 0, tr_pool = 0, tr_bar = 0, tr_x = 0, tr_bld = 0;
 #define SP_T(var) { __builtin_amdgcn_sched_barrier(0); const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); var += n_ - tr_x; tr_x = n_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define SP_T(var)
@@ -103,10 +132,10 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
   const int RowE = p.W * p.C;    // elements per input row
   const int nstages = p.K / BK;  // K = KH * Cg, Cg % BK == 0
   const int spr = p.Cg / BK;     // stages per kernel row
-  const int cs = (nstages + 3) >> 2;  // stages per step of a phase
-  const int W_OFF = 0, A_OFF = nstages * DW_STAGE, S_OFF = A_OFF + 2 * p.pt_astage, R_OFF = S_OFF + 2 * p.st_sbytes;
-  const int row_b = Wo * 64;     // bytes of one LDS row of the store side: 32 channels of Wo pixels
-  const int C_OFF = R_OFF + SP_HROWS * row_b;  // carry rows [channel half][half-tile parity]: written by half tile u, read by u+1
+  const int W_OFF = 0, A_OFF = nstages * DW_STAGE, X_OFF = A_OFF + 2 * p.pt_astage;  // weights | raw patches | signed patch
+  const int S_OFF = X_OFF + (KIND == 1 ? p.pt_astage : 0), R_OFF = S_OFF + 2 * p.st_sbytes;
+  const int row_b = Wo * 128;    // bytes of one LDS row of the store side: 64 channels of Wo pixels
+  const int C_OFF = R_OFF + SP_HROWS * row_b;  // carry row: max(r0, r1) of the previous half tile
   float* const ba_lds = (float*)(smem + R_OFF + SP_LROWS * row_b);
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -151,6 +180,29 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
         *(uint32_t*)(ss + w * 4) = btx_sign_word((uint32_t)(word0 + w), rl.kin_a, rl.kin_b);
     }
   };
+  // ---- x * s_in of half tile u, once per element: every 16-byte granule of the patch (8 elements, inside one 32-sign
+  //      word: rows are whole granules) gets its signs.  The delta pass of the K loop then reads this copy as it is — the
+  //      per-fragment masks of the other kernels would be applied ~12 times per input element here (7x7 windows, stride 2).
+  auto build_signed = [&](int u) __attribute__((always_inline)) {
+    if constexpr (KIND == 1) {
+      const int base_e = tile_base_e(u);
+      const int word0 = base_e >> 5;
+      const unsigned char* raw = smem + A_OFF + (u & 1) * p.pt_astage;
+      const unsigned char* ss = smem + S_OFF + (u & 1) * p.st_sbytes;
+      unsigned char* dst = smem + X_OFF;
+      const int nchunks = p.pt_PP >> 4;
+      for (int i = gtid; i < nchunks; i += 256) {
+        u32x4 v = *(const u32x4*)(raw + i * 16);
+        const int e = base_e + 8 * i;
+        const uint32_t w = *(const uint32_t*)(ss + ((e >> 5) - word0) * 4);
+        // element pair j of the word (elements 2j, 2j+1) has its signs at bits 15-j and 31-j: dword d of granule c is pair 4c+d
+        const uint32_t ws = w << (((uint32_t)e >> 3 & 3u) * 4u);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] ^= (ws << d) & 0x80008000u;
+        *(u32x4*)(dst + i * 16) = v;
+      }
+    }
+  };
   issue_patch(0, wave, 8);
   write_signs(0, tid, 512);
   {
@@ -158,13 +210,14 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     const bool has_aff = (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
     ep_fill_constants<KIND>(p, rl, ba_lds, tid, ntile, 0, has_bias, has_aff);
   }
-  const bool has_ba = (p.mu_b != nullptr) || (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
+  const bool has_bias = p.mu_b != nullptr;
+  const bool has_aff = (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
   const bool relu = p.ep_relu != 0;
 
   // ---- MFMA role: the wave owns pixels [64*w4, +64) of its group's half tile (2 conv rows, flattened (row, col))
-  int eo[2];      // element offset of the pixel's window inside the patch
+  int eo[2];      // byte offset of the pixel's window inside the patch
   int st_off[2];  // byte offset of the pixel's 8-byte piece (lane half h) in the store-side rows, chunk swizzle in bits
-                  // 4-5 (the address of chunk q is st_off ^ (q << 4)); -1: the pixel does not exist
+                  // 4-6 (the address of chunk c is st_off ^ (c << 4)); -1: the pixel does not exist
   uint32_t st_orow[2];  // s_out index of the pixel's first channel in half tile 0
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
@@ -173,82 +226,64 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     const int plc = ok ? pl : 0;
     const int r = plc >= Wo ? 1 : 0;
     const int col = plc - r * Wo;
-    eo[mi] = r * p.sh * RowE + col * p.sw * p.C;
-    st_off[mi] = ok ? R_OFF + r * row_b + col * 64 + (((col >> 2) & 3) << 4) + h * 8 : -1;
+    eo[mi] = (r * p.sh * RowE + col * p.sw * p.C) * 2;
+    st_off[mi] = ok ? R_OFF + r * row_b + col * 128 + (((col >> 1) & 7) << 4) + h * 8 : -1;
     st_orow[mi] = (uint32_t)(((img * Ho + c0 + r) * Wo + col) * p.N + ntile * BN);
   }
-  // ---- pool role: thread (of the group) = (pooled column gtid>>2, 8-channel chunk gtid&3 of the 32-channel half)
-  bool pool_thread = gtid < Wq * 4;
-  int pool_coff[3];  // byte offset of the chunk in a store-side row for conv columns 2pc-1, 2pc, 2pc+1 (-1: none)
+  // ---- pool role: thread (of the group) handles pooled pixels (gtid + 256 j) >> 3, j = 0, 1, 8-channel chunk gtid & 7;
+  //      byte offsets of that chunk in a store-side row for conv columns 2pc-1, 2pc, 2pc+1 (-1: none)
+  int pool_coff[2][3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int col = 2 * (gtid >> 2) - 1 + k;
-    pool_coff[k] = (pool_thread && col >= 0 && col < Wo) ? col * 64 + (((gtid & 3) ^ ((col >> 2) & 3)) * 16) : -1;
-  }
-  // carry role: the thread owns chunk gtid&3 of columns gtid>>2 and (gtid>>2) + 64 of the carry rows (-1: none)
-  int carry_off[2];
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = (gtid >> 2) + 64 * j;
-    carry_off[j] = col < Wo ? col * 64 + (((gtid & 3) ^ ((col >> 2) & 3)) * 16) : -1;
+    for (int k = 0; k < 3; ++k) {
+      const int pc = (gtid + 256 * j) >> 3, col = 2 * pc - 1 + k;
+      pool_coff[j][k] = (pc < Wq && col >= 0 && col < Wo) ? col * 128 + (((gtid & 7) ^ ((col >> 1) & 7)) << 4) : -1;
+    }
+  // carry role: the thread owns chunk gtid & 7 of columns (gtid + 256 j) >> 3, j = 0..3 (-1: none)
+  int carry_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = (gtid + 256 * j) >> 3;
+    carry_off[j] = col < Wo ? col * 128 + (((gtid & 7) ^ ((col >> 1) & 7)) << 4) : -1;
   }
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       p.out, 0, (uint32_t)((size_t)p.NB * Hq * Wq * p.N * 2), 0x00020000);
 
   f32x16 accm[2][2], accd[2][2];
 
-  // fragments of stage (kh, j) of half tile u: element offset st_e = kh*RowE + j*BK inside the lane's window
-  auto load_frag = [&](StageFrag& f, int u, int st_e, int s, int base_e, auto mia_tag) __attribute__((always_inline)) {
+  // =================== K role ===================================================================================
+  // One pass over the K-stages of half tile u: activations from `abase` (the raw patch: mean pass; the signed copy: delta
+  // pass), weights from the resident tiles at +woff (0: mu, 4096: delta).  A workgroup barrier is passed before stages
+  // bs0 and bs1 (if inside the pass); returns how many.
+  auto run_pass = [&](const unsigned char* abase, int woff, f32x16 (&acc)[2][2], int bs0, int bs1, auto mia_tag)
+                      __attribute__((always_inline)) {
     constexpr int MIA = decltype(mia_tag)::value;
-    const unsigned char* as = smem + A_OFF + (u & 1) * p.pt_astage + st_e * 2;
-    const unsigned char* ss = smem + S_OFF + (u & 1) * p.st_sbytes;
-    const unsigned char* ws = smem + W_OFF + s * DW_STAGE;
-#pragma unroll
-    for (int kk = 0; kk < NG / 2; ++kk) {
-      const int row = 2 * kk + h;
-#pragma unroll
-      for (int mi = 0; mi < MIA; ++mi) f.a[kk][mi] = *(const u32x4*)(as + eo[mi] * 2 + row * 16);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) f.wm[kk][ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
-    }
-    if constexpr (KIND == 1) {
-      const int word0 = base_e >> 5;
-#pragma unroll
-      for (int mi = 0; mi < MIA; ++mi) {
-        // the stage's 32 signs start at element e0: composed from the two hashed words they straddle (btx_contract_stem.h)
-        const int e0 = base_e + eo[mi] + st_e;
-        const int wi = (e0 >> 5) - word0;
-        const uint32_t w = *(const uint32_t*)(ss + wi * 4);
-        const uint32_t w1 = *(const uint32_t*)(ss + wi * 4 + 4);
-        const uint32_t k = ((uint32_t)e0 & 31u) >> 1;
-        const uint32_t lo = ((w & 0xffffu) << 16) | (w1 & 0xffffu);
-        const uint32_t hi = (w & 0xffff0000u) | (w1 >> 16);
-        f.sw[mi] = ((lo << k) >> 16) | ((hi << k) & 0xffff0000u);
-      }
-    }
-  };
-
-  // =================== K role: the stages of one half tile, a workgroup barrier after each of the phase's first three
-  // steps (the store group runs its four steps beside it) =========================================================
-  auto run_k = [&](int u, auto mia_tag) __attribute__((always_inline)) {
-    constexpr int MIA = decltype(mia_tag)::value;
-    const int base_e = tile_base_e(u);
-    int l_j = 0, l_rowE = 0, l_e = 0;  // stage being loaded: element offset of (kernel row, stage within the row)
+    int l_j = 0, l_row = 0, l_b = 0;  // stage being loaded: byte offset of (kernel row, stage within the row)
     auto advance_load = [&]() __attribute__((always_inline)) {
-      l_e += BK;
-      if (++l_j == spr) { l_j = 0; l_rowE += RowE; l_e = l_rowE; }
+      l_b += BK * 2;
+      if (++l_j == spr) { l_j = 0; l_row += RowE * 2; l_b = l_row; }
     };
-    StageFrag fa, fb;
-    load_frag(fa, u, 0, 0, base_e, mia_tag);
-    advance_load();
-    int nb = 0, nextb = cs;
-    auto iter = [&](int s, StageFrag& cur, StageFrag& nxt, auto zero_tag) __attribute__((always_inline)) {
-      constexpr bool ZERO = decltype(zero_tag)::value;
-      if (s == nextb && nb < 3) { SP_BARRIER(); ++nb; nextb += cs; }
-      DeltaFrag dfrag;
-      load_delta<KIND>(dfrag, smem + W_OFF + s * DW_STAGE, l31, h);
-      if (s + 1 < nstages) { load_frag(nxt, u, l_e, s + 1, base_e, mia_tag); advance_load(); }
-      stage_mma<1, KIND, 2, MIA, ZERO>(cur, dfrag, accm, accd, l31, h);
+    auto load = [&](SpFrag& f, int s) __attribute__((always_inline)) {
+      const unsigned char* as = abase + l_b;
+      const unsigned char* ws = smem + W_OFF + s * DW_STAGE + woff;
+#pragma unroll
+      for (int kk = 0; kk < NG / 2; ++kk) {
+        const int row = 2 * kk + h;
+#pragma unroll
+        for (int mi = 0; mi < MIA; ++mi) f.a[kk][mi] = *(const u32x4*)(as + eo[mi] + row * 16);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) f.w[kk][ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
+      }
+      advance_load();
+    };
+    int nb = 0;
+    SpFrag fa, fb;
+    load(fa, 0);
+    auto iter = [&](int s, SpFrag& cur, SpFrag& nxt, auto zero_tag) __attribute__((always_inline)) {
+      if (s == bs0 || s == bs1) { SP_BARRIER(); ++nb; }
+      if (s + 1 < nstages) load(nxt, s + 1);
+      sp_mma<MIA, decltype(zero_tag)::value>(cur, acc);
     };
     iter(0, fa, fb, std::true_type{});
     int s = 1;
@@ -257,15 +292,29 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       iter(s + 1, fa, fb, std::false_type{});
     }
     if (s < nstages) iter(s, fb, fa, std::false_type{});
-    for (; nb < 3; ++nb) SP_BARRIER();
+    return nb;
+  };
+  // the K role of one phase: three workgroup barriers (the store group runs its three steps beside it)
+  auto run_k = [&](int u, auto mia_tag) __attribute__((always_inline)) {
+    const unsigned char* raw = smem + A_OFF + (u & 1) * p.pt_astage;
+    int nb;
+    if constexpr (KIND == 1) {
+      run_pass(raw, 0, accm, -1, -1, mia_tag);
+      SP_BARRIER();  // the signed copy is complete (build_signed ran before this pass)
+      nb = 1 + run_pass(smem + X_OFF, 4096, accd, (nstages + 1) >> 1, -1, mia_tag);
+    } else {
+      const int t3 = (nstages + 2) / 3;
+      nb = run_pass(raw, 0, accm, t3, 2 * t3, mia_tag);
+    }
+    for (; nb < 2; ++nb) SP_BARRIER();
   };
 
   // =================== store role ================================================================================
   // fragments -> LDS rows r0 / r1, channel half NI (btx_epilogue.h stage 1 + the bf16 rounding of its stage 2; the ReLU
   // follows the pool)
-  auto stage_half = [&](int u, int mia, auto ni_tag, auto ba_tag) __attribute__((always_inline)) {
+  auto stage_half = [&](int u, int mia, auto ni_tag, auto bias_tag, auto aff_tag) __attribute__((always_inline)) {
     constexpr int ni = decltype(ni_tag)::value;
-    constexpr bool BA = decltype(ba_tag)::value;
+    constexpr bool BIAS = decltype(bias_tag)::value, AFF = decltype(aff_tag)::value;
     uint32_t wsh[2] = {0u, 0u};
     if constexpr (KIND == 1) {
 #pragma unroll
@@ -281,9 +330,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     for (int q = 0; q < 4; ++q) {
       const int cl = ni * 32 + 8 * q + 4 * h;
       f32x4 bm, bd, sc, sh;
-      if constexpr (BA) {
+      if constexpr (BIAS) {
         bm = *(const f32x4*)(ba_lds + cl);
         bd = *(const f32x4*)(ba_lds + BN + cl);
+      }
+      if constexpr (AFF) {
         sc = *(const f32x4*)(ba_lds + 2 * BN + cl);
         sh = *(const f32x4*)(ba_lds + 3 * BN + cl);
       }
@@ -293,60 +344,75 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           float val = accm[mi][ni][4 * q + rr];
-          if constexpr (BA) val += bm[rr];
+          if constexpr (BIAS) val += bm[rr];
           if constexpr (KIND == 1) {
             float dl = accd[mi][ni][4 * q + rr];
-            if constexpr (BA) dl += bd[rr];
+            if constexpr (BIAS) dl += bd[rr];
             // element e = 8q + 4h + rr of the word sits at bit ((e&1) ? 31 : 15) - (e>>1); wsh is pre-shifted by 2h
             const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1));
             val += u2f(f2u(dl) ^ ((wsh[mi] << sft) & 0x80000000u));
           }
-          if constexpr (BA) val = __builtin_fmaf(val, sc[rr], sh[rr]);
+          if constexpr (AFF) val = __builtin_fmaf(val, sc[rr], sh[rr]);
           v[rr] = val;
         }
         if (wr[mi])
-          *(u32x2*)(smem + (st_off[mi] ^ (q << 4))) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+          *(u32x2*)(smem + (st_off[mi] ^ ((ni * 4 + q) << 4))) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
       }
     }
   };
-  // LDS rows (+ the carry row of the previous half tile) -> pooled row P0+u-1, channel half ni; writes the carry row of
-  // this half tile, max(r0, r1), for the next one (the other parity's row: nobody reads it during this phase)
-  auto pool_half = [&](int u, int ni, auto relu_tag) __attribute__((always_inline)) {
+  auto stage_dispatch = [&](int u, int mia, auto ni_tag) __attribute__((always_inline)) {
+    using T = std::true_type;
+    using F = std::false_type;
+    if (has_bias) stage_half(u, mia, ni_tag, T{}, T{});  // (a bias without an affine: scale 1, shift 0 from the constants)
+    else if (has_aff) stage_half(u, mia, ni_tag, F{}, T{});
+    else stage_half(u, mia, ni_tag, F{}, F{});
+  };
+  // LDS rows (+ the carry row of the previous half tile) -> pooled row P0+u-1; returns this thread's pieces of the next
+  // carry row, max(r0, r1) (written behind the phase's last barrier, write_carry)
+  auto pool_all = [&](int u, u32x4 (&cnew)[4], auto relu_tag) __attribute__((always_inline)) {
     constexpr bool RL = decltype(relu_tag)::value;
     const uint32_t ninf = RL ? 0x80008000u : 0xff80ff80u;  // below everything: most negative int16 pair | -inf pair
     const int prow = P0 + u - 1;
     const int cr0 = c0 + SP_HROWS * u;
     const bool r0_ok = cr0 >= 0 && cr0 < Ho, r1_ok = (cr0 + 1) < Ho && u + 1 < NH;  // the closing half tile has no r1
-    const bool ok = pool_thread && u >= 1 && prow < Hq;
+    const bool row_ok = u >= 1 && prow < Hq;
     const unsigned char* rows = smem + R_OFF;
-    const unsigned char* carry = smem + C_OFF + (2 * ni + ((u + 1) & 1)) * row_b;  // written by half tile u-1
-    u32x4 m = {ninf, ninf, ninf, ninf};
-    if (ok) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        if (pool_coff[k] >= 0) {
-          m = sp_max8<RL>(m, *(const u32x4*)(carry + pool_coff[k]));  // rows that do not exist were folded in as `ninf`
-          if (r0_ok) m = sp_max8<RL>(m, *(const u32x4*)(rows + pool_coff[k]));
-        }
-      }
-      if constexpr (RL) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        m = sp_max8<true>(m, z);
-      }
-    }
-    const uint32_t off = ok ? (uint32_t)((((img * Hq + prow) * Wq + (gtid >> 2)) * p.N + ntile * BN + ni * 32 + (gtid & 3) * 8) * 2)
-                            : DMA_OOB;
-    __builtin_amdgcn_raw_buffer_store_b128(m, out_rsrc, off, 0, 0);
-    unsigned char* cdst = smem + C_OFF + (2 * ni + (u & 1)) * row_b;
+    const unsigned char* carry = smem + C_OFF;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      const bool ok = row_ok && pool_coff[j][1] >= 0;
+      u32x4 m = {ninf, ninf, ninf, ninf};
+      if (ok) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (pool_coff[j][k] >= 0) {
+            m = sp_max8<RL>(m, *(const u32x4*)(carry + pool_coff[j][k]));  // rows that do not exist were folded in as `ninf`
+            if (r0_ok) m = sp_max8<RL>(m, *(const u32x4*)(rows + pool_coff[j][k]));
+          }
+        }
+        if constexpr (RL) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          m = sp_max8<true>(m, z);
+        }
+      }
+      const int pc = (gtid + 256 * j) >> 3;
+      const uint32_t off = ok ? (uint32_t)((((img * Hq + prow) * Wq + pc) * p.N + ntile * BN + (gtid & 7) * 8) * 2) : DMA_OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(m, out_rsrc, off, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32x4 c = {ninf, ninf, ninf, ninf};
       if (carry_off[j] >= 0) {
-        u32x4 c = {ninf, ninf, ninf, ninf};
         if (r0_ok) c = sp_max8<RL>(c, *(const u32x4*)(rows + carry_off[j]));
         if (r1_ok) c = sp_max8<RL>(c, *(const u32x4*)(rows + row_b + carry_off[j]));
-        *(u32x4*)(cdst + carry_off[j]) = c;
       }
+      cnew[j] = c;
     }
+  };
+  auto write_carry = [&](const u32x4 (&cnew)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (carry_off[j] >= 0) *(u32x4*)(smem + C_OFF + carry_off[j]) = cnew[j];
   };
   // Every path through the K role redefines ALL accumulators (those a wave does not compute are cleared): were some left
   // as they are, their previous values would be live through the K loops on every path and spill (116 VGPRs).
@@ -368,6 +434,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
   };
 
   // =================== the band ==================================================================================
+  u32x4 cnew[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  bool carry_pending = false;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights, first patch, constants
   SP_BARRIER();
 #ifdef BTX_PT_TRACE
@@ -378,23 +446,29 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
   using F = std::false_type;
   for (int ph = 0; ph <= NH; ++ph) {
     // keep everything derived from the per-lane indices inside the phase: hoisted out of this loop, the address vectors of
-    // both roles (~100 VGPRs) stay live across the K loops and the accumulators spill
+    // both roles stay live across the K loops and the accumulators spill
     asm volatile("" : "+v"(lane), "+v"(l31), "+v"(h), "+v"(gtid), "+v"(eo[0]), "+v"(eo[1]), "+v"(st_off[0]), "+v"(st_off[1]));
-    asm volatile("" : "+v"(st_orow[0]), "+v"(st_orow[1]), "+v"(pool_coff[0]), "+v"(pool_coff[1]), "+v"(pool_coff[2]),
-                      "+v"(carry_off[0]), "+v"(carry_off[1]));
+    asm volatile("" : "+v"(st_orow[0]), "+v"(st_orow[1]), "+v"(carry_off[0]), "+v"(carry_off[1]), "+v"(carry_off[2]),
+                      "+v"(carry_off[3]));
+    asm volatile("" : "+v"(pool_coff[0][0]), "+v"(pool_coff[0][1]), "+v"(pool_coff[0][2]), "+v"(pool_coff[1][0]),
+                      "+v"(pool_coff[1][1]), "+v"(pool_coff[1][2]));
     if (grp == (ph & 1)) {
-      // ---------------- K role: half tile ph
+      // ---------------- K role: half tile ph.  First the carry row this group produced as last phase's store group:
+      // every read of the old one ended before the barrier that closed that phase, the next read is two barriers away.
+      if (carry_pending) { write_carry(cnew); carry_pending = false; }
       if (ph < NH) {
         if (ph + 1 < NH) issue_patch(ph + 1, w4, 4);
+        build_signed(ph);
+        SP_T(tr_bld)
         const int mia = mia_of(ph);
         if (mia == 2) run_k(ph, std::integral_constant<int, 2>{});
         else if (mia == 1) { clear_acc(1); run_k(ph, std::integral_constant<int, 1>{}); }
-        else { clear_acc(0); SP_BARRIER(); SP_BARRIER(); SP_BARRIER(); }
+        else { clear_acc(0); SP_BARRIER(); SP_BARRIER(); }
         SP_T(tr_k)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next patch: issued a whole K loop ago
       } else {
         clear_acc(0);
-        SP_BARRIER(); SP_BARRIER(); SP_BARRIER();
+        SP_BARRIER(); SP_BARRIER();
       }
     } else {
       // ---------------- store role: half tile ph-1 (this group's accumulators of the previous phase)
@@ -402,24 +476,19 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       if (ph + 1 < NH) write_signs(ph + 1, gtid, 256);
       if (u >= 0) {
         const int mia = mia_of(u);
-        if (has_ba) stage_half(u, mia, std::integral_constant<int, 0>{}, T{});
-        else stage_half(u, mia, std::integral_constant<int, 0>{}, F{});
+        stage_dispatch(u, mia, std::integral_constant<int, 0>{});
         SP_T(tr_st)
         SP_BARRIER();
         SP_T(tr_bar)
-        if (relu) pool_half(u, 0, T{}); else pool_half(u, 0, F{});
-        SP_T(tr_pool)
-        SP_BARRIER();
-        SP_T(tr_bar)
-        if (has_ba) stage_half(u, mia, std::integral_constant<int, 1>{}, T{});
-        else stage_half(u, mia, std::integral_constant<int, 1>{}, F{});
+        stage_dispatch(u, mia, std::integral_constant<int, 1>{});
         SP_T(tr_st)
         SP_BARRIER();
         SP_T(tr_bar)
-        if (relu) pool_half(u, 1, T{}); else pool_half(u, 1, F{});
+        if (relu) pool_all(u, cnew, T{}); else pool_all(u, cnew, F{});
+        carry_pending = true;
         SP_T(tr_pool)
       } else {
-        SP_BARRIER(); SP_BARRIER(); SP_BARRIER();
+        SP_BARRIER(); SP_BARRIER();
       }
     }
     SP_BARRIER();
@@ -431,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     const uint32_t tr_t3 = (uint32_t)__builtin_amdgcn_s_memtime();
     if (lane == 0) {
       uint32_t* tr = (uint32_t*)p.trace + (size_t)(blockIdx.x * 8 + wave) * 8;
-      tr[0] = tr_pro; tr[1] = 0; tr[2] = tr_k; tr[3] = tr_st; tr[4] = tr_pool; tr[5] = tr_t3 - tr_t0; tr[6] = tr_bar;
+      tr[0] = tr_pro; tr[1] = tr_bld; tr[2] = tr_k; tr[3] = tr_st; tr[4] = tr_pool; tr[5] = tr_t3 - tr_t0; tr[6] = tr_bar;
       tr[7] = tr_t0;
     }
   }

@@ -22,7 +22,7 @@ with torch.no_grad():
 t = buf.cpu().numpy().view(np.uint32).reshape(-1, 8)
 t = t[t[:, 5] != 0]
 print(fam, "waves traced:", len(t))
-names = ["prologue", "prefetch+zero", "K loops", "staging", "pool", "total", "barrier waits"]
+names = ["prologue", "sign copy", "K loops", "staging", "pool", "total", "barrier waits"]
 for i, n in enumerate(names):
     c = t[:, i].astype(np.float64)
     print("  %-14s mean %9.0f  min %9.0f  max %9.0f" % (n, c.mean(), c.min(), c.max()))
