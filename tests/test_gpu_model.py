@@ -465,7 +465,8 @@ def test_graphed_mc_replays_equal_eager_samples():
                 bt.set_sample_index(m, s_)
                 mc.accumulate(eager3, m(x), 0.5)
         assert torch.allclose(got3, eager3, rtol=1e-6, atol=1e-6)  # same per-sample values, summed in a different order
-        assert torch.allclose(got3, eager, rtol=0, atol=2e-2)      # the two plans differ by bf16 rounding only
+        # the two plans (K-groups / split-K vs plain blocks) sum in a different order: bf16 rounding of the activations only
+        assert float((got3 - eager).norm() / eager.norm()) < 2e-2
         for mod in m.modules():
             if hasattr(mod, "_btx_layer_id"):
                 mod._btx_sample_dev = g.sample_dev
