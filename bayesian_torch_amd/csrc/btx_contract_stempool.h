@@ -12,7 +12,9 @@
 //     the other runs the store side of half tile f-1 from its accumulator registers — per SIMD one wave feeds the matrix
 //     pipe while the other does the VALU / LDS work of the epilogue, and the next phase they swap.  (A first version
 //     that had all eight waves multiply, then all eight store, spent 30 % of its time in the K loops: 105 us per launch.)
-//     A phase is three steps with a workgroup barrier after each;
+//     A phase is three steps with a workgroup barrier after each.  (Measured alternative, git history: barriers among the
+//     four waves of a group through LDS arrival counters and a single s_barrier per phase, 99 instead of 103 us per stem
+//     call — dropped: spin-waits give up the forward-progress guarantee of s_barrier for 4 %.)
 //   * Flipout: x * s_in of the half tile is written ONCE per input element into a second copy of the patch (step 1 of
 //     the K role) and the K loop runs as two passes — mean pass: raw patch x mu tiles, delta pass: signed copy x delta
 //     tiles — instead of masking every activation fragment (each input element sits in ~12 fragments of a 7x7 / stride-2
@@ -42,7 +44,7 @@
 namespace btx {
 
 constexpr int SP_HROWS = 2;  // conv rows per half tile
-constexpr int SP_LROWS = 3;  // LDS rows (64 channels each) of the store side: r0, r1 and the carry row, rotating (see pool_all)
+constexpr int SP_LROWS = 3;  // LDS rows (64 channels each) of the store side: r0, r1 and the carry row
 constexpr int SP_MAXST = 7;  // K-stages whose weight tiles stay resident
 
 typedef __attribute__((ext_vector_type(8))) short i16x8;
@@ -86,22 +88,6 @@ __device__ __forceinline__ void sp_mma(const SpFrag& f, f32x16 (&acc)[2][2]) {
                                                                __builtin_bit_cast(bf16x8, f.a[kk][mi]), acc[mi][ni], 0, 0, 0);
         }
       }
-}
-
-// Barrier among the four waves of ONE group (s_barrier only knows the whole workgroup, and the two groups of a phase
-// should not wait for each other's intermediate steps): an arrival counter in LDS.  `target` counts this group's use.
-// (inline asm: the compiler would put s_waitcnt vmcnt(0) in front of an LDS atomic — the LDS-DMA of the next patch and the
-// pooled stores are in flight here and have nothing to do with it)
-__device__ __forceinline__ void sp_group_barrier(uint32_t cnt_lds, uint32_t& target, int lane) {
-  target += 4u;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are done
-  if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_lds), "v"(1u) : "memory");
-  uint32_t v;
-  for (;;) {
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_lds) : "memory");
-    if ((int)(v - target) >= 0) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
 }
 
 // ContractParams fields used: pt_R (pooled rows per band), pt_rtiles (bands per image), pt_PP (patch bytes), pt_astage
@@ -151,12 +137,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
   const int W_OFF = 0, A_OFF = nstages * DW_STAGE, X_OFF = A_OFF + 2 * p.pt_astage;  // weights | raw patches | signed patch
   const int S_OFF = X_OFF + (KIND == 1 ? p.pt_astage : 0), R_OFF = S_OFF + 2 * p.st_sbytes;
   const int row_b = Wo * 128;    // bytes of one LDS row of the store side: 64 channels of Wo pixels
+  const int C_OFF = R_OFF + SP_HROWS * row_b;  // carry row: max(r0, r1) of the previous half tile
   float* const ba_lds = (float*)(smem + R_OFF + SP_LROWS * row_b);
-  const int D_OFF = R_OFF + SP_LROWS * row_b + 4 * BN * 4 + 128;  // 1 KiB dump area (128-byte aligned: the chunk xor stays inside) for the stores of pixels that do not exist
-  // arrival counter of this group (sp_group_barrier), as an LDS byte address
-  const uint32_t gcnt = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem) +
-                        (uint32_t)(R_OFF + SP_LROWS * row_b + 4 * BN * 4 + 4 * grp);
-  uint32_t gtarget = 0;
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.wt_bytes, 0x00020000);
@@ -211,34 +193,20 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       const unsigned char* ss = smem + S_OFF + (u & 1) * p.st_sbytes;
       unsigned char* dst = smem + X_OFF;
       const int nchunks = p.pt_PP >> 4;
-      for (int i0 = gtid; i0 < nchunks; i0 += 2048) {  // eight granules per round: all loads first, then the masks
-        u32x4 v[8];
-        uint32_t w[8];
+      for (int i = gtid; i < nchunks; i += 256) {
+        u32x4 v = *(const u32x4*)(raw + i * 16);
+        const int e = base_e + 8 * i;
+        const uint32_t w = *(const uint32_t*)(ss + ((e >> 5) - word0) * 4);
+        // element pair j of the word (elements 2j, 2j+1) has its signs at bits 15-j and 31-j: dword d of granule c is pair 4c+d
+        const uint32_t ws = w << (((uint32_t)e >> 3 & 3u) * 4u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = i0 + 256 * j;
-          if (i < nchunks) {
-            v[j] = *(const u32x4*)(raw + i * 16);
-            w[j] = *(const uint32_t*)(ss + (((base_e + 8 * i) >> 5) - word0) * 4);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int i = i0 + 256 * j;
-          if (i < nchunks) {
-            // element pair j of the word (elements 2j, 2j+1) has its signs at bits 15-j and 31-j: dword d of granule c is pair 4c+d
-            const uint32_t ws = w[j] << ((((uint32_t)(base_e + 8 * i) >> 3) & 3u) * 4u);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) v[j][d] ^= (ws << d) & 0x80008000u;
-            *(u32x4*)(dst + i * 16) = v[j];
-          }
-        }
+        for (int d = 0; d < 4; ++d) v[d] ^= (ws << d) & 0x80008000u;
+        *(u32x4*)(dst + i * 16) = v;
       }
     }
   };
   issue_patch(0, wave, 8);
   write_signs(0, tid, 512);
-  if (tid < 2) ((uint32_t*)(ba_lds + 4 * BN))[tid] = 0u;
   {
     const bool has_bias = p.mu_b != nullptr;
     const bool has_aff = (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
@@ -250,8 +218,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
 
   // ---- MFMA role: the wave owns pixels [64*w4, +64) of its group's half tile (2 conv rows, flattened (row, col))
   int eo[2];      // byte offset of the pixel's window inside the patch
-  int st_off[2];  // byte offset of the pixel's 8-byte piece (lane half h) inside its store-side row, chunk swizzle in
-                  // bits 4-6 (the address of chunk c is st_off ^ (c << 4)), bit 0: the pixel is in r1; -1: no such pixel
+  int st_off[2];  // byte offset of the pixel's 8-byte piece (lane half h) in the store-side rows, chunk swizzle in bits
+                  // 4-6 (the address of chunk c is st_off ^ (c << 4)); -1: the pixel does not exist
   uint32_t st_orow[2];  // s_out index of the pixel's first channel in half tile 0
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
@@ -261,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     const int r = plc >= Wo ? 1 : 0;
     const int col = plc - r * Wo;
     eo[mi] = (r * p.sh * RowE + col * p.sw * p.C) * 2;
-    st_off[mi] = ok ? (col * 128 + (((col >> 1) & 7) << 4) + h * 8) | r : -1;
+    st_off[mi] = ok ? R_OFF + r * row_b + col * 128 + (((col >> 1) & 7) << 4) + h * 8 : -1;
     st_orow[mi] = (uint32_t)(((img * Ho + c0 + r) * Wo + col) * p.N + ntile * BN);
   }
   // ---- pool role: thread (of the group) handles pooled pixels (gtid + 256 j) >> 3, j = 0, 1, 8-channel chunk gtid & 7;
@@ -288,8 +256,10 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
 
   // =================== K role ===================================================================================
   // One pass over the K-stages of half tile u: activations from `abase` (the raw patch: mean pass; the signed copy: delta
-  // pass), weights from the resident tiles at +woff (0: mu, 4096: delta).
-  auto run_pass = [&](const unsigned char* abase, int woff, f32x16 (&acc)[2][2], auto mia_tag) __attribute__((always_inline)) {
+  // pass), weights from the resident tiles at +woff (0: mu, 4096: delta).  A workgroup barrier is passed before stages
+  // bs0 and bs1 (if inside the pass); returns how many.
+  auto run_pass = [&](const unsigned char* abase, int woff, f32x16 (&acc)[2][2], int bs0, int bs1, auto mia_tag)
+                      __attribute__((always_inline)) {
     constexpr int MIA = decltype(mia_tag)::value;
     int l_j = 0, l_row = 0, l_b = 0;  // stage being loaded: byte offset of (kernel row, stage within the row)
     auto advance_load = [&]() __attribute__((always_inline)) {
@@ -309,9 +279,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       }
       advance_load();
     };
+    int nb = 0;
     SpFrag fa, fb;
     load(fa, 0);
     auto iter = [&](int s, SpFrag& cur, SpFrag& nxt, auto zero_tag) __attribute__((always_inline)) {
+      if (s == bs0 || s == bs1) { SP_BARRIER(); ++nb; }
       if (s + 1 < nstages) load(nxt, s + 1);
       sp_mma<MIA, decltype(zero_tag)::value>(cur, acc);
     };
@@ -322,12 +294,27 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       iter(s + 1, fa, fb, std::false_type{});
     }
     if (s < nstages) iter(s, fb, fa, std::false_type{});
+    return nb;
+  };
+  // the K role of one phase: three workgroup barriers (the store group runs its three steps beside it)
+  auto run_k = [&](int u, auto mia_tag) __attribute__((always_inline)) {
+    const unsigned char* raw = smem + A_OFF + (u & 1) * p.pt_astage;
+    int nb;
+    if constexpr (KIND == 1) {
+      run_pass(raw, 0, accm, -1, -1, mia_tag);
+      SP_BARRIER();  // the signed copy is complete (build_signed ran before this pass)
+      nb = 1 + run_pass(smem + X_OFF, 4096, accd, (nstages + 1) >> 1, -1, mia_tag);
+    } else {
+      const int t3 = (nstages + 2) / 3;
+      nb = run_pass(raw, 0, accm, t3, 2 * t3, mia_tag);
+    }
+    for (; nb < 2; ++nb) SP_BARRIER();
   };
 
   // =================== store role ================================================================================
   // fragments -> LDS rows r0 / r1, channel half NI (btx_epilogue.h stage 1 + the bf16 rounding of its stage 2; the ReLU
   // follows the pool)
-  auto stage_half = [&](int u, int rb0, int rb1, int mia, auto ni_tag, auto bias_tag, auto aff_tag) __attribute__((always_inline)) {
+  auto stage_half = [&](int u, int mia, auto ni_tag, auto bias_tag, auto aff_tag) __attribute__((always_inline)) {
     constexpr int ni = decltype(ni_tag)::value;
     constexpr bool BIAS = decltype(bias_tag)::value, AFF = decltype(aff_tag)::value;
     uint32_t wsh[2] = {0u, 0u};
@@ -338,118 +325,96 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
         wsh[mi] = btx_sign_word((orow + 32u * ni) >> 5, rl.kout_a, rl.kout_b) << (2 * h);
       }
     }
-    int dst[2];  // the half tile's rows: r0 in LDS row u % 3, r1 in row (u + 1) % 3; pixels that do not exist: a dump area
+    bool wr[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-      dst[mi] = st_off[mi] >= 0 ? R_OFF + ((st_off[mi] & 1) ? rb1 : rb0) + (st_off[mi] & ~1) : D_OFF + lane * 8;
-    // the per-channel constants of the half: every LDS read up front (one latency, not one per channel group)
-    f32x4 bm[4], bd[4], sc[4], sh[4];
+    for (int mi = 0; mi < 2; ++mi) wr[mi] = mi < mia && st_off[mi] >= 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int cl = ni * 32 + 8 * q + 4 * h;
+      f32x4 bm, bd, sc, sh;
       if constexpr (BIAS) {
-        bm[q] = *(const f32x4*)(ba_lds + cl);
-        bd[q] = *(const f32x4*)(ba_lds + BN + cl);
+        bm = *(const f32x4*)(ba_lds + cl);
+        bd = *(const f32x4*)(ba_lds + BN + cl);
       }
       if constexpr (AFF) {
-        sc[q] = *(const f32x4*)(ba_lds + 2 * BN + cl);
-        sh[q] = *(const f32x4*)(ba_lds + 3 * BN + cl);
+        sc = *(const f32x4*)(ba_lds + 2 * BN + cl);
+        sh = *(const f32x4*)(ba_lds + 3 * BN + cl);
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      if (mi < mia) {  // wave-uniform
+      for (int mi = 0; mi < 2; ++mi) {
+        f32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            float val = accm[mi][ni][4 * q + rr];
-            if constexpr (BIAS) val += bm[q][rr];
-            if constexpr (KIND == 1) {
-              float dl = accd[mi][ni][4 * q + rr];
-              if constexpr (BIAS) dl += bd[q][rr];
-              // element e = 8q + 4h + rr of the word sits at bit ((e&1) ? 31 : 15) - (e>>1); wsh is pre-shifted by 2h
-              const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1));
-              val += u2f(f2u(dl) ^ ((wsh[mi] << sft) & 0x80000000u));
-            }
-            if constexpr (AFF) val = __builtin_fmaf(val, sc[q][rr], sh[q][rr]);
-            v[rr] = val;
+        for (int rr = 0; rr < 4; ++rr) {
+          float val = accm[mi][ni][4 * q + rr];
+          if constexpr (BIAS) val += bm[rr];
+          if constexpr (KIND == 1) {
+            float dl = accd[mi][ni][4 * q + rr];
+            if constexpr (BIAS) dl += bd[rr];
+            // element e = 8q + 4h + rr of the word sits at bit ((e&1) ? 31 : 15) - (e>>1); wsh is pre-shifted by 2h
+            const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1));
+            val += u2f(f2u(dl) ^ ((wsh[mi] << sft) & 0x80000000u));
           }
-          *(u32x2*)(smem + (dst[mi] ^ ((ni * 4 + q) << 4))) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+          if constexpr (AFF) val = __builtin_fmaf(val, sc[rr], sh[rr]);
+          v[rr] = val;
         }
+        if (wr[mi])
+          *(u32x2*)(smem + (st_off[mi] ^ ((ni * 4 + q) << 4))) = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
       }
     }
   };
-  auto stage_dispatch = [&](int u, int rb0, int rb1, int mia, auto ni_tag) __attribute__((always_inline)) {
+  auto stage_dispatch = [&](int u, int mia, auto ni_tag) __attribute__((always_inline)) {
     using T = std::true_type;
     using F = std::false_type;
-    if (has_bias) stage_half(u, rb0, rb1, mia, ni_tag, T{}, T{});  // (a bias without an affine: scale 1, shift 0 from the constants)
-    else if (has_aff) stage_half(u, rb0, rb1, mia, ni_tag, F{}, T{});
-    else stage_half(u, rb0, rb1, mia, ni_tag, F{}, F{});
+    if (has_bias) stage_half(u, mia, ni_tag, T{}, T{});  // (a bias without an affine: scale 1, shift 0 from the constants)
+    else if (has_aff) stage_half(u, mia, ni_tag, F{}, T{});
+    else stage_half(u, mia, ni_tag, F{}, F{});
   };
-  // LDS rows r0 (+ the carry row of the previous half tile) -> pooled row P0+u-1, and the next carry row max(r0, r1).  The
-  // three LDS rows rotate: half tile u stages r0 into row u % 3 and r1 into (u + 1) % 3 and finds the carry of u-1 in
-  // (u + 2) % 3; once the group has read everything (group barrier) the new carry replaces r0 — row u % 3 is the carry
-  // the next half tile expects, and its own rows (u + 1) % 3, (u + 2) % 3 hold nothing anybody still needs.
-  auto pool_all = [&](int u, int rb0, int rb1, int rbc, auto relu_tag) __attribute__((always_inline)) {
+  // LDS rows (+ the carry row of the previous half tile) -> pooled row P0+u-1; returns this thread's pieces of the next
+  // carry row, max(r0, r1) (written behind the phase's last barrier, write_carry)
+  auto pool_all = [&](int u, u32x4 (&cnew)[4], auto relu_tag) __attribute__((always_inline)) {
     constexpr bool RL = decltype(relu_tag)::value;
     const uint32_t ninf = RL ? 0x80008000u : 0xff80ff80u;  // below everything: most negative int16 pair | -inf pair
     const int prow = P0 + u - 1;
     const int cr0 = c0 + SP_HROWS * u;
     const bool r0_ok = cr0 >= 0 && cr0 < Ho, r1_ok = (cr0 + 1) < Ho && u + 1 < NH;  // the closing half tile has no r1
     const bool row_ok = u >= 1 && prow < Hq;
-    unsigned char* r0 = smem + R_OFF + rb0;
-    const unsigned char* r1 = smem + R_OFF + rb1;
-    const unsigned char* carry = smem + R_OFF + rbc;
-    // every LDS read first (offsets of columns / pixels that do not exist read chunk 0 of the row: harmless, unused)
-    u32x4 vc[2][3], v0[2][3], w0[4], w1[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int o = pool_coff[j][k] >= 0 ? pool_coff[j][k] : 0;
-        vc[j][k] = *(const u32x4*)(carry + o);
-        v0[j][k] = *(const u32x4*)(r0 + o);
-      }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int o = carry_off[j] >= 0 ? carry_off[j] : 0;
-      w0[j] = *(const u32x4*)(r0 + o);
-      w1[j] = *(const u32x4*)(r1 + o);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const u32x4 nv = {ninf, ninf, ninf, ninf};
+    const unsigned char* rows = smem + R_OFF;
+    const unsigned char* carry = smem + C_OFF;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool ok = row_ok && pool_coff[j][1] >= 0;
-      u32x4 m = nv;
+      u32x4 m = {ninf, ninf, ninf, ninf};
+      if (ok) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const bool ck = pool_coff[j][k] >= 0;
-        m = sp_max8<RL>(m, ck ? vc[j][k] : nv);  // rows that do not exist were folded into the carry as `ninf`
-        m = sp_max8<RL>(m, (ck && r0_ok) ? v0[j][k] : nv);
-      }
-      if constexpr (RL) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        m = sp_max8<true>(m, z);
+        for (int k = 0; k < 3; ++k) {
+          if (pool_coff[j][k] >= 0) {
+            m = sp_max8<RL>(m, *(const u32x4*)(carry + pool_coff[j][k]));  // rows that do not exist were folded in as `ninf`
+            if (r0_ok) m = sp_max8<RL>(m, *(const u32x4*)(rows + pool_coff[j][k]));
+          }
+        }
+        if constexpr (RL) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          m = sp_max8<true>(m, z);
+        }
       }
       const int pc = (gtid + 256 * j) >> 3;
       const uint32_t off = ok ? (uint32_t)((((img * Hq + prow) * Wq + pc) * p.N + ntile * BN + (gtid & 7) * 8) * 2) : DMA_OOB;
       __builtin_amdgcn_raw_buffer_store_b128(m, out_rsrc, off, 0, 0);
     }
-    u32x4 cnew[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      u32x4 c = r0_ok ? w0[j] : nv;
-      c = sp_max8<RL>(c, r1_ok ? w1[j] : nv);
+      u32x4 c = {ninf, ninf, ninf, ninf};
+      if (carry_off[j] >= 0) {
+        if (r0_ok) c = sp_max8<RL>(c, *(const u32x4*)(rows + carry_off[j]));
+        if (r1_ok) c = sp_max8<RL>(c, *(const u32x4*)(rows + row_b + carry_off[j]));
+      }
       cnew[j] = c;
     }
-    sp_group_barrier(gcnt, gtarget, lane);
+  };
+  auto write_carry = [&](const u32x4 (&cnew)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (carry_off[j] >= 0) *(u32x4*)(r0 + carry_off[j]) = cnew[j];
+      if (carry_off[j] >= 0) *(u32x4*)(smem + C_OFF + carry_off[j]) = cnew[j];
   };
   // Every path through the K role redefines ALL accumulators (those a wave does not compute are cleared): were some left
   // as they are, their previous values would be live through the K loops on every path and spill (116 VGPRs).
@@ -471,7 +436,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
   };
 
   // =================== the band ==================================================================================
-  int um3 = 2;  // (ph - 1) % 3, the LDS row of r0 of the half tile the store group handles (starts at -1 = 2 mod 3)
+  u32x4 cnew[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  bool carry_pending = false;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights, first patch, constants
   SP_BARRIER();
 #ifdef BTX_PT_TRACE
@@ -489,27 +455,22 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     asm volatile("" : "+v"(pool_coff[0][0]), "+v"(pool_coff[0][1]), "+v"(pool_coff[0][2]), "+v"(pool_coff[1][0]),
                       "+v"(pool_coff[1][1]), "+v"(pool_coff[1][2]));
     if (grp == (ph & 1)) {
-      // ---------------- K role: half tile ph
+      // ---------------- K role: half tile ph.  First the carry row this group produced as last phase's store group:
+      // every read of the old one ended before the barrier that closed that phase, the next read is two barriers away.
+      if (carry_pending) { write_carry(cnew); carry_pending = false; }
       if (ph < NH) {
         if (ph + 1 < NH) issue_patch(ph + 1, w4, 4);
         build_signed(ph);
         SP_T(tr_bld)
-        const unsigned char* raw = smem + A_OFF + (ph & 1) * p.pt_astage;
         const int mia = mia_of(ph);
-        // mean pass (raw patch), then — once the whole group has finished the signed copy — the delta pass
-        if (mia == 2) run_pass(raw, 0, accm, std::integral_constant<int, 2>{});
-        else if (mia == 1) { clear_acc(1); run_pass(raw, 0, accm, std::integral_constant<int, 1>{}); }
-        else clear_acc(0);
-        if constexpr (KIND == 1) {
-          sp_group_barrier(gcnt, gtarget, lane);
-          SP_T(tr_bar)
-          if (mia == 2) run_pass(smem + X_OFF, 4096, accd, std::integral_constant<int, 2>{});
-          else if (mia == 1) run_pass(smem + X_OFF, 4096, accd, std::integral_constant<int, 1>{});
-        }
+        if (mia == 2) run_k(ph, std::integral_constant<int, 2>{});
+        else if (mia == 1) { clear_acc(1); run_k(ph, std::integral_constant<int, 1>{}); }
+        else { clear_acc(0); SP_BARRIER(); SP_BARRIER(); }
         SP_T(tr_k)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next patch: issued a whole K loop ago
       } else {
         clear_acc(0);
+        SP_BARRIER(); SP_BARRIER();
       }
     } else {
       // ---------------- store role: half tile ph-1 (this group's accumulators of the previous phase)
@@ -517,18 +478,22 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       if (ph + 1 < NH) write_signs(ph + 1, gtid, 256);
       if (u >= 0) {
         const int mia = mia_of(u);
-        const int rb0 = um3 * row_b, rb1 = (um3 == 2 ? 0 : um3 + 1) * row_b, rbc = (um3 == 0 ? 2 : um3 - 1) * row_b;
-        stage_dispatch(u, rb0, rb1, mia, std::integral_constant<int, 0>{});
-        stage_dispatch(u, rb0, rb1, mia, std::integral_constant<int, 1>{});
+        stage_dispatch(u, mia, std::integral_constant<int, 0>{});
         SP_T(tr_st)
-        sp_group_barrier(gcnt, gtarget, lane);
+        SP_BARRIER();
         SP_T(tr_bar)
-        if (relu) pool_all(u, rb0, rb1, rbc, T{}); else pool_all(u, rb0, rb1, rbc, F{});
+        stage_dispatch(u, mia, std::integral_constant<int, 1>{});
+        SP_T(tr_st)
+        SP_BARRIER();
+        SP_T(tr_bar)
+        if (relu) pool_all(u, cnew, T{}); else pool_all(u, cnew, F{});
+        carry_pending = true;
         SP_T(tr_pool)
+      } else {
+        SP_BARRIER(); SP_BARRIER();
       }
     }
     SP_BARRIER();
-    um3 = (um3 == 2) ? 0 : um3 + 1;
     SP_T(tr_bar)
   }
 #ifdef BTX_PT_TRACE
