@@ -669,6 +669,56 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   return true;
 }
 
+// Tile plan of the stride-2 form of the tap-unrolled kernel (btx_contract_taps2.h): 3x3 / stride 2 / pad 1, one phase
+// plane of (R+1) x (Wo+1) pixels per image of the tile in each of three LDS slots.
+static bool make_patch2_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, Plan* pl, PatchPlan* pt) {
+  if (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_ROWFUSE)) return false;
+  if (tune_env("BTX_NO_TAPS2")) return false;  // A/B: the per-tap LDS-DMA kernel instead
+  if (make_plan(g, prec, flags, DBM, pl)) return false;
+  if (!dma_shape_ok(g, act_dtype, prec, *pl)) return false;
+  if (g->D != 1 || g->KD != 1 || pl->Do != 1) return false;
+  if (g->KH != 3 || g->KW != 3 || g->sh != 2 || g->sw != 2 || g->ph != 1 || g->pw != 1 || g->dh != 1 || g->dw != 1) return false;
+  BtxGeom gp = *g;  // the plane of a tile is the halo'd patch of a 2x2 stride-1 window: R+1 rows, Wo+1 columns
+  gp.KH = 2; gp.KW = 2;
+  if (!patch_tile(&gp, *pl, 256, 272, pt)) return false;
+  pt->nw = 4; pt->mi = 2;
+  const int pieces = (pt->PP + 15) / 16;
+  pt->NI = (pieces + 3) / 4;
+  if (pt->NI > 5) return false;
+  pt->astage = pieces * 1024;
+  int lds = 3 * pt->astage + 3 * (pt->astage / 16) + 3 * 8192 + 1024;
+  const int ep = 4 * PT_EP_WAVE + 1024;
+  if (lds < ep) lds = ep;
+  if (lds > 81920) return false;
+  pt->lds = lds;
+  pt->lds_g = (lds + 15) & ~15;
+  const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
+  const int ncb = pl->Cg / bk;
+  pl->mtiles = ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
+  const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
+  pt->taps = 332;
+  pt->kg = 1;
+  int ks = 1;
+  {
+    const long long slots = slots4();
+    long long best = -1;
+    for (int c = 1; c <= ncb && c <= 32; ++c) {
+      const int per = (ncb + c - 1) / c;
+      const long long rounds = (base * c + slots - 1) / slots;
+      const long long cost = rounds * (per * 9 + 4) + (c > 1 ? 1 : 0);
+      if (best < 0 || cost < best) { best = cost; ks = c; }
+      if ((flags & BTX_FLAG_CONCURRENT) && base * c >= 64) { ks = c; break; }  // see make_plan
+    }
+  }
+  const int per = (ncb + ks - 1) / ks;
+  pl->kper = per * bk;
+  pl->ksplits = (ncb + per - 1) / per;
+  const long long nwg = base * pl->ksplits;
+  if (nwg > 0x7fffffffLL) return false;
+  pl->nwg = (int)nwg;
+  return true;
+}
+
 // Tile plan of the stem variant (btx_contract_stem.h): row-fused small-C 2-D convolutions; R output rows x full width
 // per workgroup, the input rows they need resident in LDS.
 struct StemPlan {
@@ -784,7 +834,7 @@ size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, i
   }
   Plan c;
   PatchPlan pt;
-  if (make_patch_plan(g, act_dtype, prec, flags, &c, &pt)) {
+  if (make_patch_plan(g, act_dtype, prec, flags, &c, &pt) || make_patch2_plan(g, act_dtype, prec, flags, &c, &pt)) {
     const size_t wc = pad256(plan_ws(c, g)) + patch_wt_bytes(c, g, BTX_KIND_FLIPOUT, prec, nullptr);
     if (wc > wa) wa = wc;
   }
@@ -871,6 +921,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   if (dma && !rowfuse && !no_patch) {
     Plan pp;
     if (make_patch_plan(g, act_dtype, prec, flags, &pp, &pt)) { pl = pp; patch = true; }
+    else if (make_patch2_plan(g, act_dtype, prec, flags, &pp, &pt)) { pl = pp; patch = true; }
   }
   int out_bf16 = (act_dtype == BTX_ACT_BF16) ? 1 : 0;
   if (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_OUT_BF16)) {

@@ -27,6 +27,7 @@
 #include "btx_presample.h"
 #include "btx_mma.h"
 #include "btx_contract_taps.h"
+#include "btx_contract_taps2.h"
 
 namespace btx {
 
@@ -366,6 +367,22 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
   } while (0)
   int rc = launch_presample_impl<PREC>(kind, p, st);
   if (rc) return rc;
+  if (p.pt_taps == 332) {  // 3x3 / stride 2 / pad 1: the phase-plane form of the tap-unrolled kernel (btx_contract_taps2.h)
+#define BTX_LAUNCH_T2(KIND)                                                                                       \
+  do {                                                                                                            \
+    auto kfn = contract_taps2_kernel<PREC, KIND>;                                                                 \
+    static bool attr_done = false;                                                                                \
+    if (!attr_done) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);   \
+      if (e != hipSuccess) return (int)e;                                                                         \
+      attr_done = true;                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), p.pt_lds, st, p);                                               \
+  } while (0)
+    if (kind == 0) BTX_LAUNCH_T2(0); else BTX_LAUNCH_T2(1);
+#undef BTX_LAUNCH_T2
+    return (int)hipGetLastError();
+  }
   if (p.pt_taps == 33) {  // 3x3, 4-wave K-groups: the tap-unrolled kernel (btx_contract_taps.h)
 #define BTX_LAUNCH_TP(KIND, KG)                                                                                    \
   do {                                                                                                            \

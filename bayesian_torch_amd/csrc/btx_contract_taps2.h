@@ -15,7 +15,8 @@
 // Three patch slots ((R+1) x (Wo+1) pixels each, <= 17 KiB) rotate: the plane after next is fetched while a plane
 // multiplies (stages 0-1 fetch (1,0), stage 4 fetches (0,1), stages 5-6 the next block's (1,1), stages 7-8 its (0,0)) — every
 // piece is issued at least two stages before its first use.  Everything else is the stride-1 kernel: static DMA schedule
-// and s_waitcnt immediates, weight tiles by scalar-offset DMA (ring of three here, two stages ahead: the LDS budget),
+// and s_waitcnt immediates, weight tiles by scalar-offset DMA (ring of three here, two stages ahead: the LDS budget — which
+// is also why a stage reads its own fragments instead of prefetching the next stage's),
 // one hashed s_in word per patch pixel per plane, staged epilogue.  K order (channel block, plane, tap) — the noise indices
 // k = tap*Cg + c are those of every other variant.
 #pragma once
@@ -250,22 +251,20 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
     issue_plane(0, MAXNI, 0, 0, cb0, sl1 * a_stage);
     write_signs(1, 1, cb0, sl0 * s_stage);
     write_signs(0, 0, cb0, sl1 * s_stage);
-    // W(0), plane (1,1), W(1) landed (iteration 0 prefetches the fragments of stage 1); plane (0,0) may be in flight
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(MAXNI) : "memory");
-    Frag fa, fb;
+    // W(0) and plane (1,1) landed; W(1) and plane (0,0) may be in flight
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(MAXNI + WOPS) : "memory");
+    Frag fa;
     const int nvalid_px = min(p.pt_G, p.NB - img0) * min(p.pt_R, p.Ho - row0) * p.Wo;
     const bool mi1_dead = wave * 64 + 32 >= nvalid_px;
     auto kloop = [&](auto mia_tag) __attribute__((always_inline)) {
-      load_frag(fa, sl0 * a_stage, sl0 * s_stage, 0, 0, mia_tag);
       constexpr int MIA = decltype(mia_tag)::value;
-      auto block = [&](auto par_tag, int cbi, bool last) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_tag)::value;  // parity of the block: T is odd, the fragment sets alternate per stage
+      auto block = [&](int cbi, bool last) __attribute__((always_inline)) {
         static_for<0, T>([&](auto t_tag) __attribute__((always_inline)) {
           constexpr int s = decltype(t_tag)::value;
-          constexpr int sp = (PAR * T + s) & 1;
-          Frag& cur = sp ? fb : fa;
-          Frag& nxt = sp ? fa : fb;
-          asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));  // keep per-tap addresses out of long-lived registers (btx_contract_taps.h)
+          // keep per-tap addresses out of long-lived registers (btx_contract_taps.h) — and the validity bits: hoisted, every
+          // (piece, plane) test becomes a wave mask held in an SGPR pair across the loop (28 of them)
+          asm volatile("" : "+v"(q0[0]), "+v"(q0[1]), "+v"(pvalid), "+v"(sg_v), "+v"(sg_base[0]), "+v"(sg_base[1]));
+          asm volatile("" : "+v"(pp_base[0]), "+v"(pp_base[1]), "+v"(pp_base[2]), "+v"(pp_base[3]), "+v"(pp_base[4]));
           auto slot_of = [&](int k) __attribute__((always_inline)) { return (k % 3) == 0 ? sl0 : ((k % 3) == 1 ? sl1 : sl2); };
           // 1. W(s+2)
           constexpr int s2 = (s + 2) % T, c2 = (s + 2) / T;
@@ -281,17 +280,17 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
               if constexpr (t2_p0(s) == 0) write_signs(t2_a(FK), t2_b(FK), cb0 + cbi + FC, so * s_stage);
             }
           }
-          // 3. delta weights of this stage, then the fragments of the next one
+          // 3. this stage's fragments (no prefetch across the stage boundary: the weight ring is three deep — W(s+1) is only
+          //    guaranteed at the end of this stage — and the other block of the CU covers the LDS latency)
           DeltaFrag df;
           load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
-          constexpr int s1 = (s + 1) % T, c1 = (s + 1) / T;
           {
-            constexpr int K1 = t2_seq(s1) + 4 * c1, TP1 = t2_tap(s1);
-            const int so = slot_of(K1);
-            load_frag(nxt, so * a_stage, so * s_stage, ((TP1 / 3) == 2 ? Wp : 0) + ((TP1 % 3) == 2 ? 1 : 0), (wslot + 1) % WD, mia_tag);
+            constexpr int TP = t2_tap(s);
+            const int so = slot_of(t2_seq(s));
+            load_frag(fa, so * a_stage, so * s_stage, ((TP / 3) == 2 ? Wp : 0) + ((TP % 3) == 2 ? 1 : 0), wslot, mia_tag);
           }
           // 4. multiply
-          stage_mma<PREC, KIND, MI, MIA>(cur, df, accm, accd, l31, h);
+          stage_mma<PREC, KIND, MI, MIA>(fa, df, accm, accd, l31, h);
           // 5. everything issued before this stage has landed (W(s+1), and any plane that starts at s+1); meet the others
           if (!last) end_stage<WOPS + NP>();
           else end_stage<((s + 2 < T) ? WOPS : 0) + ((t2_fseq(s) < 4) ? NP : 0)>();
@@ -300,12 +299,8 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
         // the next block's planes: sequence 4 -> slot of (k % 3 == 1), i.e. rotate by one
         const int t0 = sl0; sl0 = sl1; sl1 = sl2; sl2 = t0;
       };
-      int cbi = 0;
-      for (; cbi + 2 <= ncb; cbi += 2) {
-        block(std::integral_constant<int, 0>{}, cbi, false);
-        block(std::integral_constant<int, 1>{}, cbi + 1, cbi + 2 == ncb);
-      }
-      if (cbi < ncb) block(std::integral_constant<int, 0>{}, cbi, true);
+      for (int cbi = 0; cbi + 1 < ncb; ++cbi) block(cbi, false);
+      block(ncb - 1, true);
     };
     if (mi1_dead) kloop(std::integral_constant<int, 1>{});
     else kloop(std::integral_constant<int, 2>{});

@@ -99,6 +99,14 @@ FUSED_CASES = [
     ("Conv2dFlipout", dict(in_channels=32, out_channels=64, kernel_size=3, padding=0, dilation=(2, 3)), (2, 32, 25, 31)),
     ("Conv2dReparameterization", dict(in_channels=64, out_channels=64, kernel_size=5, padding=2, groups=2), (2, 64, 30, 30)),
     ("Conv2dFlipout", dict(in_channels=32, out_channels=16, kernel_size=3, padding=1), (1, 32, 3, 200)),
+    # phase-plane kernel (3x3 / stride 2 / pad 1): row tiles with a ragged last tile, whole images, several images per tile
+    # with a ragged last group, odd extents, groups, several channel blocks, split-K
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=3, stride=2, padding=1, bias=False), (3, 64, 56, 56)),
+    ("Conv2dFlipout", dict(in_channels=128, out_channels=64, kernel_size=3, stride=2, padding=1), (2, 128, 28, 28)),
+    ("Conv2dFlipout", dict(in_channels=256, out_channels=64, kernel_size=3, stride=2, padding=1, bias=False), (9, 256, 14, 14)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=64, kernel_size=3, stride=2, padding=1), (2, 32, 51, 37)),
+    ("Conv2dReparameterization", dict(in_channels=64, out_channels=64, kernel_size=3, stride=2, padding=1, groups=2), (5, 64, 13, 18)),
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=32, kernel_size=3, stride=2, padding=1), (1, 32, 2, 2)),
     # element-wise (GEN) kernels with in-kernel noise: odd channel counts
     ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 32, 32)),
     ("LinearFlipout", dict(in_features=50, out_features=10), (7, 50)),
