@@ -211,6 +211,10 @@ def time_launches(recs, prec, reps=10, algo_k=None):
             torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / (2 * reps) * 1e3
         m_rows = y.numel() // op.out_channels
+        if (k.get("epilogue") or {}).get("pool"):  # the stem's max-pool is folded into the launch: y is the pooled tensor,
+            sp = (1,) * (3 - op.nd) + tuple(xin.shape[2:])  # the contraction still produces every conv pixel
+            osp = op.out_spatial(sp)
+            m_rows = xin.shape[0] * osp[0] * osp[1] * osp[2]
         k_red = op.kernel[0] * op.kernel[1] * op.kernel[2] * (op.in_channels // op.groups)
         k_red = (algo_k or {}).get(id(op), k_red)
         nmm = 2 if kind == _lib.KIND_FLIPOUT else 1
