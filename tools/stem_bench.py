@@ -1,7 +1,8 @@
 """GPU time of the ResNet stem chain (conv1 7x7/2 + bn + relu + maxpool 3/2/1), bs 64 bf16: one-launch (BtxEpilogue.pool)
 vs stem launch + pool kernel.  20 calls per hipGraph."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bayesian_torch_amd as bt
 from bayesian_torch_amd import layers as L, functional as BF
 

@@ -1,5 +1,6 @@
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch.nn.functional as F
 from bayesian_torch_amd import layers as L
 dev = torch.device("cuda:0")

@@ -2,7 +2,8 @@
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesian_torch_amd import layers as L
 
 dev = torch.device("cuda:0")
