@@ -6,11 +6,13 @@ The module tree is untouched (state_dict keys of the fused and the unfused model
 way) and the folded (scale, shift) follow the BatchNorm tensors.  Only for inference (`model.eval()`); the unfused model
 is the parity reference (tests/test_gpu_model.py).
 """
-import os
 import types
 
 import torch
 import torch.nn as nn
+
+
+STEM_POOL_FUSION = True  # conv1 -> bn1 -> relu -> maxpool as one launch when the geometry allows (btx_contract_pool_shape)
 
 
 def fold_bn(bn):
@@ -104,7 +106,7 @@ def fuse_resnet(model):
             """conv1 -> bn1 -> relu -> MaxPool2d(3, 2, 1) in ONE launch (btx_contract_stempool.h): the 112x112 conv
             output never reaches HBM.  Decided per input shape; everything else pools with its own kernel."""
             mp = self.maxpool
-            if os.environ.get("BTX_NO_STEM_POOL"):  # A/B measurements
+            if not STEM_POOL_FUSION:  # A/B measurements (bench.py --no-stem-pool)
                 return False
             if not (isinstance(mp, nn.MaxPool2d) and mp.kernel_size in (3, (3, 3)) and mp.stride in (2, (2, 2))
                     and mp.padding in (1, (1, 1)) and mp.dilation in (1, (1, 1)) and not mp.ceil_mode

@@ -601,12 +601,17 @@ def main():
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg2/cfg3/cfg5/f32 sub-results")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC traffic measurement")
+    ap.add_argument("--no-stem-pool", action="store_true", help="A/B: the stem's max-pool as its own kernel instead of folded "
+                    "into the stem launch (BtxEpilogue.pool)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank protocol (no GPU)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:], args.dry_run))
 
+    if args.no_stem_pool:
+        from bayesian_torch_amd.models import fuse as _fuse
+        _fuse.STEM_POOL_FUSION = False
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -6,5 +6,5 @@ timeout 600 python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "stem or fu
 B="python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extras --no-traffic --no-launch-timing"
 for i in 1; do
 timeout 300 $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('fused-pool', d['value'], d['ms_per_step'])"
-BTX_NO_STEM_POOL=1 timeout 300 $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('two-launch', d['value'], d['ms_per_step'])"
+timeout 300 $B --no-stem-pool 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('two-launch', d['value'], d['ms_per_step'])"
 done
