@@ -110,7 +110,12 @@ class ContractFn(torch.autograd.Function):
             want_b = rho_b is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6])
             if want_w or want_b:
                 signs = (nz["sign_in"], nz["sign_out"]) if (flip and padded) else None
-                if not op.transposed:
+                if plan is not None and not op.transposed:
+                    # row-fused stem: the gradient on the geometry the forward ran on (7 kernel rows x 32 elements instead of
+                    # 49 taps x 3 channels of a 64-wide tile; the forward's hashed signs instead of sign tensors)
+                    dW, dWd, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
+                                                    bias=want_b, rowfuse=plan)
+                elif not op.transposed:
                     dW, dWd, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
                                                     signs=signs, bias=want_b)
                 else:

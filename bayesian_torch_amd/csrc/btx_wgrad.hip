@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int kw = tap % p.KW, kh = (tap / p.KW) % p.KH, kd = tap / (p.KW * p.KH);
   const int m_begin = chunk * p.chunk_px, m_end = min(p.M, m_begin + p.chunk_px);
   const bool do_bias = (tap == 0) && (ct == 0) && (p.dbm != nullptr);
+  const int ni_live = (p.Ng - nt * 64 > 32) ? 2 : 1, nj_live = (p.Cg - ct * 64 > 32) ? 2 : 1;
 
   // staging role: thread t loads 16 consecutive channels of pixel (t >> 2) of each tile: quarter q = t & 3
   const int s_px = tid >> 2, s_q = tid & 3;
@@ -83,7 +84,92 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       for (int r = 0; r < 16; ++r) { acc_m[a][b][r] = 0.f; acc_d[a][b][r] = 0.f; }
   float bsum_m = 0.f, bsum_d = 0.f;  // threads 0..63: column n = tid of the dy tile
 
+  // bf16 fast path of the staging (the shapes of a ResNet body): whole 16-channel runs, 32-byte aligned, hashed signs — two
+  // 16-byte loads per operand, the Flipout signs as XOR masks on the packed pairs (one hashed word covers the run), and the
+  // loads of step m0 + 64 are requested before the MFMAs of step m0 so that their latency runs beside the matrix pipe.
+  constexpr bool IS_BF16 = sizeof(ACT) == 2;
+  // (x runs of a row-fused stem start at multiples of C = 4 elements: 8-byte loads, signs out of two hashed words)
+  const bool fast = IS_BF16 && (p.C % 4 == 0) && (p.Cg % 16 == 0) && (p.N % 16 == 0) && (p.Ng % 16 == 0) &&
+                    !p.sign_in && !p.sign_out && ((((uintptr_t)p.x) | ((uintptr_t)p.dy)) % 16 == 0);
+  const bool x_al16 = (p.C % 16) == 0;
+  struct Raw {
+    u32x4 x[2], y[2];
+    uint32_t xi, yi;  // element offsets of the runs (sign words)
+  };
+  auto fetch = [&](int m0, Raw& r) __attribute__((always_inline)) {
+    const int m = m0 + s_px;
+    const bool pix_ok = m < m_end;
+    uint32_t t1, uow, uoh, uod, unb;
+    fdivmod((uint32_t)(pix_ok ? m : 0), p.fd_Wo, (uint32_t)p.Wo, t1, uow);
+    fdivmod(t1, p.fd_Ho, (uint32_t)p.Ho, t1, uoh);
+    fdivmod(t1, p.fd_Do, (uint32_t)p.Do, unb, uod);
+    const int id = (int)uod * p.sd - p.pd + kd * p.dd, ih = (int)uoh * p.sh - p.ph + kh * p.dh,
+              iw = (int)uow * p.sw - p.pw + kw * p.dw;
+    const bool in_ok = pix_ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W &&
+                       (ct * 64 + 16 * s_q < p.Cg);
+    const bool out_ok = pix_ok && (nt * 64 + 16 * s_q < p.Ng);
+    const long long xo = ((((long long)unb * p.D + id) * p.H + ih) * p.W + iw) * p.C + grp * p.Cg + ct * 64 + 16 * s_q;
+    const long long yo = (long long)m * p.N + grp * p.Ng + nt * 64 + 16 * s_q;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const u32x4* yp = (const u32x4*)((const uint16_t*)p.dy + (out_ok ? yo : 0));
+    const u32x4 y0 = yp[0], y1 = yp[1];
+    u32x4 x0, x1;
+    if (x_al16) {
+      const u32x4* xp = (const u32x4*)((const uint16_t*)p.x + (in_ok ? xo : 0));
+      x0 = xp[0]; x1 = xp[1];
+    } else {
+      const u32x2* xp = (const u32x2*)((const uint16_t*)p.x + (in_ok ? xo : 0));
+      const u32x2 a0 = xp[0], a1 = xp[1], a2 = xp[2], a3 = xp[3];
+      x0 = (u32x4){a0[0], a0[1], a1[0], a1[1]}; x1 = (u32x4){a2[0], a2[1], a3[0], a3[1]};
+    }
+    r.x[0] = in_ok ? x0 : z; r.x[1] = in_ok ? x1 : z;
+    r.y[0] = out_ok ? y0 : z; r.y[1] = out_ok ? y1 : z;
+    r.xi = (uint32_t)xo; r.yi = (uint32_t)yo;
+  };
+  // packed bf16 pairs -> f32 rows in LDS (+ the sign-flipped copies): dword d of half hf holds elements 8 hf + 2d, + 1
+  auto stash = [&](const Raw& r) __attribute__((always_inline)) {
+    unsigned char* rx = t_x + s_px * WG_ROW + s_q * 64;
+    unsigned char* ry = t_dy + s_px * WG_ROW + s_q * 64;
+    uint32_t wx = 0, wy = 0;
+    if constexpr (KIND == 1) {
+      // one hashed word covers the 16-element run; pair j of the word has its signs at bits 15 - j and 31 - j
+      if (x_al16) {
+        wx = btx_sign_word(r.xi >> 5, p.kin_a, p.kin_b) << ((r.xi & 31u) >> 1);
+      } else {  // the run may straddle two words: the 32 signs starting at element xi (btx_contract_stem.h)
+        const uint32_t w = btx_sign_word(r.xi >> 5, p.kin_a, p.kin_b), w1 = btx_sign_word((r.xi >> 5) + 1u, p.kin_a, p.kin_b);
+        const uint32_t k = (r.xi & 31u) >> 1;
+        const uint32_t lo = ((w & 0xffffu) << 16) | (w1 & 0xffffu), hi = (w & 0xffff0000u) | (w1 >> 16);
+        wx = ((lo << k) >> 16) | ((hi << k) & 0xffff0000u);
+      }
+      wy = btx_sign_word(r.yi >> 5, p.kout_a, p.kout_b) << ((r.yi & 31u) >> 1);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int d2 = 0; d2 < 2; ++d2) {  // two dwords = four elements = one 16-byte LDS write
+        const int d = 2 * d2;
+        const uint32_t xa = r.x[hf][d], xb = r.x[hf][d + 1], ya = r.y[hf][d], yb = r.y[hf][d + 1];
+        const int v = 2 * hf + d2;
+        *(f32x4*)(rx + 16 * v) = (f32x4){u2f(xa << 16), u2f(xa & 0xffff0000u), u2f(xb << 16), u2f(xb & 0xffff0000u)};
+        *(f32x4*)(ry + 16 * v) = (f32x4){u2f(ya << 16), u2f(ya & 0xffff0000u), u2f(yb << 16), u2f(yb & 0xffff0000u)};
+        if constexpr (KIND == 1) {
+          const int j = 4 * hf + d;  // pair index of dword d inside the run
+          const uint32_t xas = xa ^ ((wx << j) & 0x80008000u), xbs = xb ^ ((wx << (j + 1)) & 0x80008000u);
+          const uint32_t yas = ya ^ ((wy << j) & 0x80008000u), ybs = yb ^ ((wy << (j + 1)) & 0x80008000u);
+          *(f32x4*)(t_xs + s_px * WG_ROW + s_q * 64 + 16 * v) =
+              (f32x4){u2f(xas << 16), u2f(xas & 0xffff0000u), u2f(xbs << 16), u2f(xbs & 0xffff0000u)};
+          *(f32x4*)(t_dys + s_px * WG_ROW + s_q * 64 + 16 * v) =
+              (f32x4){u2f(yas << 16), u2f(yas & 0xffff0000u), u2f(ybs << 16), u2f(ybs & 0xffff0000u)};
+        }
+      }
+  };
+  Raw raw;
+  if (fast && m_begin < m_end) fetch(m_begin, raw);
+
   for (int m0 = m_begin; m0 < m_end; m0 += WG_PX) {
+    if (fast) {
+      stash(raw);
+    } else {
     // ---- stage: dy[m0 + s_px][nt*64 + 16 s_q ..] and x[(m0 + s_px) @ tap][ct*64 + 16 s_q ..]
     {
       const int m = m0 + s_px;
@@ -154,7 +240,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         }
       }
     }
+    }
     __syncthreads();
+    if (fast && m0 + WG_PX < m_end) fetch(m0 + WG_PX, raw);  // in flight during the MFMAs below
     // ---- multiply: wave w takes pixels 16w..16w+15 of the step, two per MFMA
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -173,8 +261,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc_m[i][j], 0, 0, 0);
-          if constexpr (KIND == 1) acc_d[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as_[i], bs_[j], acc_d[i][j], 0, 0, 0);
+          if (i < ni_live && j < nj_live) {  // uniform: halves of the tile beyond Ng / Cg (row-fused stems: 32 of 64 columns)
+            acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc_m[i][j], 0, 0, 0);
+            if constexpr (KIND == 1) acc_d[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as_[i], bs_[j], acc_d[i][j], 0, 0, 0);
+          }
         }
     }
     if (do_bias && tid < 64) {
@@ -234,7 +324,12 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
   if (kind == BTX_KIND_FLIPOUT && !dw_delta) return BTX_E_NULL;
   if ((db_mu != nullptr) && kind == BTX_KIND_FLIPOUT && !db_delta) return BTX_E_NULL;
   if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
-  if (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_ROWFUSE)) return BTX_E_UNSUPPORTED;  // transposed layers: swap x and dy (host)
+  if (flags & BTX_FLAG_TRANSPOSED) return BTX_E_UNSUPPORTED;  // transposed layers: swap x and dy (host)
+  // BTX_FLAG_ROWFUSE (small-C stems on the row-fused geometry of the forward, include/btx.h): a kernel row = KW*C contiguous
+  // elements of x plays the part of the channel axis — KH "taps" of KW*C "channels" instead of KH*KW taps of C channels (a
+  // 7x7x3 stem: 7 x 32 of a 64-wide tile instead of 49 x 3 of 64) — and the signs are the forward's hashed ones
+  const bool rowfuse = (flags & BTX_FLAG_ROWFUSE) != 0;
+  if (rowfuse && (g->groups != 1 || g->D != 1 || g->KD != 1 || g->pw != 0 || g->dw != 1)) return BTX_E_UNSUPPORTED;
   if (rng->sample_idx_dev) return BTX_E_UNSUPPORTED;
   int32_t Do, Ho, Wo;
   int rc = btx_out_shape(g, 0, &Do, &Ho, &Wo);
@@ -251,6 +346,7 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
   const long long M = (long long)g->NB * Do * Ho * Wo;
   if (M > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
   p.M = (int)M; p.T = g->KD * g->KH * g->KW; p.K = p.T * p.Cg; p.groups = g->groups;
+  if (rowfuse) { p.Cg = g->KW * g->C; p.KW = 1; p.T = g->KD * g->KH; }  // K = T * Cg unchanged; the pixel stride p.C stays C
   p.ntiles = (p.Ng + 63) / 64; p.ctiles = (p.Cg + 63) / 64;
   const long long base = (long long)p.groups * p.ntiles * p.ctiles * p.T;
   long long chunks = (2048 + base - 1) / base;  // ~2048 workgroups in flight

@@ -379,13 +379,27 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     return res.contiguous() if (_OUT_LAYOUT == "contiguous" and op.nd > 0) else res
 
 
-def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, swap=False, bias=False):
+def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, swap=False, bias=False, rowfuse=None,
+              _flags=0):
     """btx_contract_wgrad: (dW_mu, dW_delta | None, db_mu | None, db_delta | None) in the layer's LOGICAL weight layout
     (f32).  `op` is a plain (non-transposed) contraction; `signs` = (sign_in, sign_out) logical +/-1 tensors for layers
-    whose forward ran on padded layouts, else the forward's hashed signs are regenerated."""
+    whose forward ran on padded layouts, else the forward's hashed signs are regenerated.  `rowfuse` = the layer's
+    rowfuse_plan(): the gradient is taken on the row-fused geometry the forward ran on (hashed signs, a kernel row as the
+    channel axis) and un-padded here."""
     L = _lib.lib()
     if op.transposed:
         raise _lib.BtxError("wgrad_hip wants the plain-convolution geometry (exchange x and dy for transposed layers)")
+    if rowfuse is not None:
+        plan, fop = rowfuse, rowfuse["op"]
+        xin = rowfuse_input(x, plan, dy.dtype)
+        fo = fop.out_spatial((1, plan["Hp"], plan["Wp"]))
+        if (fo[1], fo[2]) != tuple(dy.shape[2:]):  # the forward computed (and dropped) extra rows / columns: their dy is 0
+            dy = F.pad(dy, (0, fo[2] - dy.shape[3], 0, fo[1] - dy.shape[2]))
+        kh, kwp, cp, kw, cin = fop.kernel[1], plan["kwp"], plan["cp"], plan["kw"], plan["cin"]
+        dwm, dwd, dbm, dbd = wgrad_hip(kind, xin, dy, fop, seed, sample_idx, layer_id, (fop.out_channels, cp, kh, kwp),
+                                       bias=bias, _flags=_lib.FLAG_ROWFUSE)
+        un = lambda t: t[:, :cin, :, :kw].contiguous() if t is not None else None  # noqa: E731
+        return un(dwm), un(dwd), dbm, dbd
     xp, nb, spatial, _ = _to_channels_last(x, op)
     yop = OpDesc(op.nd, op.out_channels, op.out_channels)
     dy2 = dy.reshape(-1, op.out_channels) if op.nd == 0 else dy
@@ -420,7 +434,7 @@ def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, 
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     _lib.check(L.btx_contract_wgrad(kind, ctypes.byref(g), xp.data_ptr(), dyp.data_ptr(), dwm.data_ptr(), ptr(dwd), ptr(dbm),
                                     ptr(dbd), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None, act,
-                                    _lib.FLAG_SWAP_SIGNS if swap else 0, torch.cuda.current_stream(dev).cuda_stream))
+                                    (_lib.FLAG_SWAP_SIGNS if swap else 0) | _flags, torch.cuda.current_stream(dev).cuda_stream))
     un = lambda t: unpack_gemm_major(t, w_shape, op) if t is not None else None  # noqa: E731
     return un(dwm), un(dwd), dbm, dbd
 

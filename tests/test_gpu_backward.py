@@ -23,6 +23,10 @@ CASES = [
     ("Conv3dReparameterization", dict(in_channels=8, out_channels=8, kernel_size=3, prior_mean=0, prior_variance=1,
                                       posterior_mu_init=0, posterior_rho_init=-3.0, padding=1), (1, 8, 5, 6, 7)),
     ("ConvTranspose2dFlipout", dict(in_channels=16, out_channels=16, kernel_size=4, stride=2, padding=1), (2, 16, 6, 7)),
+    # small-C stems: forward and weight gradient on the row-fused geometry
+    ("Conv2dFlipout", dict(in_channels=3, out_channels=32, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 30, 26)),
+    ("Conv2dReparameterization", dict(in_channels=3, out_channels=16, kernel_size=3, stride=1, padding=1), (2, 3, 11, 9)),
+    ("Conv2dFlipout", dict(in_channels=1, out_channels=80, kernel_size=5, stride=1, padding=2), (3, 1, 12, 12)),
 ]
 
 
@@ -160,9 +164,16 @@ def test_readme_training_snippet_runs_on_the_hip_backend():
         assert not torch.equal(p.detach(), before[n]), n
 
 
-def test_bf16_activations_train_with_f32_weight_gradients():
-    """throughput mode: bf16 activations + bf16 MFMA forward / data gradient, exact-f32 weight gradient — against the f32
-    reference chain on the same bf16-valued tensors (bound 1e-2: 8-bit mantissas in the forward / dx operands)"""
+@pytest.mark.parametrize("kw,xshape", [
+    (dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=False), (4, 64, 14, 14)),
+    (dict(in_channels=32, out_channels=48, kernel_size=3, stride=2, padding=1), (3, 32, 15, 13)),      # bias sums, ragged tiles
+    (dict(in_channels=64, out_channels=96, kernel_size=3, padding=1, groups=2, bias=False), (2, 64, 9, 9)),
+    (dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 32, 32)),  # row-fused stem
+])
+def test_bf16_activations_train_with_f32_weight_gradients(kw, xshape):
+    """throughput mode: bf16 activations + bf16 MFMA forward / data gradient, exact-f32 weight gradient (vectorised staging
+    path of btx_wgrad.hip) — against the f32 reference chain on the same bf16-valued tensors (bound 1e-2: 8-bit mantissas
+    in the forward / dx operands)"""
     import bayesian_torch_amd as bt
     from bayesian_torch_amd import layers as L
     from bayesian_torch_amd import functional as BF
@@ -172,8 +183,8 @@ def test_bf16_activations_train_with_f32_weight_gradients():
     bt.set_precision("bf16")
     try:
         torch.manual_seed(0)
-        layer = L.Conv2dFlipout(64, 64, 3, padding=1, bias=False).to(dev)
-        x = torch.randn(4, 64, 14, 14, device=dev).to(torch.bfloat16).requires_grad_(True)
+        layer = L.Conv2dFlipout(**kw).to(dev)
+        x = torch.randn(*xshape, device=dev).to(torch.bfloat16).requires_grad_(True)
         bt.set_sample_index(layer, 2)
         out = layer(x, return_kl=False)
         gy = torch.randn_like(out)
@@ -183,11 +194,18 @@ def test_bf16_activations_train_with_f32_weight_gradients():
             nz = layer.materialize_noise(2, tuple(x.shape), tuple(out.shape), x.dtype)
         xr = x.detach().float().requires_grad_(True)
         mur, rhor = BF.plain_layout(mu.detach()).requires_grad_(True), BF.plain_layout(rho.detach()).requires_grad_(True)
-        ref = bt_ref.flipout_forward(xr, mur, rhor, None, None, nz["eps_w"], None, nz["sign_in"].float(), nz["sign_out"].float(),
-                                     dict(kind="conv", nd=2, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1))
+        mbr = layer.mu_bias.detach().clone().requires_grad_(True) if layer.mu_bias is not None else None
+        rbr = layer.rho_bias.detach().clone().requires_grad_(True) if layer.mu_bias is not None else None
+        op = layer._op
+        ref = bt_ref.flipout_forward(xr, mur, rhor, mbr, rbr, nz["eps_w"], nz.get("eps_b"), nz["sign_in"].float().reshape(x.shape),
+                                     nz["sign_out"].float().reshape(out.shape),
+                                     dict(kind="conv", nd=2, stride=op.stride[1:], padding=op.padding[1:], dilation=op.dilation[1:],
+                                          groups=op.groups))
         (ref * gy.float()).sum().backward()
         assert _rel(out.float(), ref) < 1e-2
         assert _rel(x.grad.float(), xr.grad) < 1e-2
         assert _rel(mu.grad, mur.grad) < 1e-4 and _rel(rho.grad, rhor.grad) < 1e-4   # f32 MFMA on identical bf16-valued inputs
+        if mbr is not None:
+            assert _rel(layer.mu_bias.grad, mbr.grad) < 1e-4 and _rel(layer.rho_bias.grad, rbr.grad) < 1e-4
     finally:
         bt.set_precision("f32")
