@@ -8,10 +8,13 @@
 // dmu = dW_mu, drho = dW_delta * eps * sigmoid(rho) follow elementwise on the host side.)
 //
 // A GEMM whose reduction axis is the PIXEL axis: both operands are stored channels-last, i.e. with the reduction index
-// slowest.  The exact-f32 MFMA v_mfma_f32_32x32x2_f32 takes ONE element per lane per operand (A[i = lane&31][k = lane>>5],
-// B[k][j]), so its fragments are plain 4-byte LDS reads of a pixel-major tile and no transpose is needed; gradients
-// accumulate in f32 whatever the activation dtype.  (157 TFLOP/s peak, 1/16 of the bf16 rate: a bf16 form needs
-// ds_read_b64_tr_b16 fragment loads — next.)
+// slowest.  Two forms of the product:
+//   * general (f32 activations, odd channel counts, sign tensors): the exact-f32 MFMA v_mfma_f32_32x32x2_f32 takes ONE
+//     element per lane per operand, so its fragments are plain 4-byte LDS reads of a pixel-major f32 tile;
+//   * FAST (bf16 activations in whole 16-channel runs, hashed signs — a ResNet body and its row-fused stem): 16-byte
+//     loads, the next step's loads in flight during the MFMAs, tiles written to LDS transposed and still bf16 so that a
+//     fragment (8 consecutive pixels of a channel) is one 16-byte read for v_mfma_f32_32x32x16_bf16.  bf16 x bf16 products
+//     are exact in f32 and the accumulation is f32 in both forms: the same gradient.
 //
 // Workgroup = 4 waves <-> (64 output channels, 64 input channels of ONE tap, a chunk of output pixels).  Per 64-pixel
 // step the tile dy[64 px][64 n] and the tap-shifted tile x[64 px][64 c] (zeros outside the input) are staged as f32,
@@ -52,7 +55,8 @@ constexpr int WG_TILE = WG_PX * WG_ROW;
 
 __device__ __forceinline__ float sgn_flip(float v, bool neg) { return neg ? -v : v; }
 
-template <typename ACT, int KIND>
+// FAST: the bf16 staging / bf16-MFMA path below (chosen by the host: wgrad_fast_ok); otherwise exact-f32 MFMA on f32 tiles
+template <typename ACT, int KIND, bool FAST>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // tiles: dy, x (+ signed copies for Flipout)
@@ -87,10 +91,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   // bf16 fast path of the staging (the shapes of a ResNet body): whole 16-channel runs, 32-byte aligned, hashed signs — two
   // 16-byte loads per operand, the Flipout signs as XOR masks on the packed pairs (one hashed word covers the run), and the
   // loads of step m0 + 64 are requested before the MFMAs of step m0 so that their latency runs beside the matrix pipe.
-  constexpr bool IS_BF16 = sizeof(ACT) == 2;
-  // (x runs of a row-fused stem start at multiples of C = 4 elements: 8-byte loads, signs out of two hashed words)
-  const bool fast = IS_BF16 && (p.C % 4 == 0) && (p.Cg % 16 == 0) && (p.N % 16 == 0) && (p.Ng % 16 == 0) &&
-                    !p.sign_in && !p.sign_out && ((((uintptr_t)p.x) | ((uintptr_t)p.dy)) % 16 == 0);
+  constexpr bool fast = FAST;
+  static_assert(!FAST || sizeof(ACT) == 2, "the fast path stages bf16");
   const bool x_al16 = (p.C % 16) == 0;
   struct Raw {
     u32x4 x[2], y[2];
@@ -126,13 +128,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     r.y[0] = out_ok ? y0 : z; r.y[1] = out_ok ? y1 : z;
     r.xi = (uint32_t)xo; r.yi = (uint32_t)yo;
   };
-  // packed bf16 pairs -> f32 rows in LDS (+ the sign-flipped copies): dword d of half hf holds elements 8 hf + 2d, + 1
+  // Fast path: the tiles go to LDS TRANSPOSED and stay bf16 — T[channel][pixel], 144-byte rows — so that an MFMA fragment
+  // (8 consecutive pixels of one channel) is one 16-byte read and the product runs on v_mfma_f32_32x32x16_bf16 (bf16 x bf16
+  // products are exact in f32, the accumulation stays f32: the same gradient as the f32 MFMA, 16x the matrix rate).
+  // dword d of half hf of a run holds elements 8 hf + 2d (low half) and + 1 (high half).
+  constexpr int TR_ROW = 64 * 2 + 16;
   auto stash = [&](const Raw& r) __attribute__((always_inline)) {
-    unsigned char* rx = t_x + s_px * WG_ROW + s_q * 64;
-    unsigned char* ry = t_dy + s_px * WG_ROW + s_q * 64;
     uint32_t wx = 0, wy = 0;
     if constexpr (KIND == 1) {
-      // one hashed word covers the 16-element run; pair j of the word has its signs at bits 15 - j and 31 - j
+      // one hashed word covers an aligned 16-element run; pair j of the word has its signs at bits 15 - j and 31 - j
+      wy = btx_sign_word(r.yi >> 5, p.kout_a, p.kout_b) << ((r.yi & 31u) >> 1);
       if (x_al16) {
         wx = btx_sign_word(r.xi >> 5, p.kin_a, p.kin_b) << ((r.xi & 31u) >> 1);
       } else {  // the run may straddle two words: the 32 signs starting at element xi (btx_contract_stem.h)
@@ -141,33 +146,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         const uint32_t lo = ((w & 0xffffu) << 16) | (w1 & 0xffffu), hi = (w & 0xffff0000u) | (w1 >> 16);
         wx = ((lo << k) >> 16) | ((hi << k) & 0xffff0000u);
       }
-      wy = btx_sign_word(r.yi >> 5, p.kout_a, p.kout_b) << ((r.yi & 31u) >> 1);
     }
+    const int col = s_px * 2;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int d2 = 0; d2 < 2; ++d2) {  // two dwords = four elements = one 16-byte LDS write
-        const int d = 2 * d2;
-        const uint32_t xa = r.x[hf][d], xb = r.x[hf][d + 1], ya = r.y[hf][d], yb = r.y[hf][d + 1];
-        const int v = 2 * hf + d2;
-        *(f32x4*)(rx + 16 * v) = (f32x4){u2f(xa << 16), u2f(xa & 0xffff0000u), u2f(xb << 16), u2f(xb & 0xffff0000u)};
-        *(f32x4*)(ry + 16 * v) = (f32x4){u2f(ya << 16), u2f(ya & 0xffff0000u), u2f(yb << 16), u2f(yb & 0xffff0000u)};
+      for (int d = 0; d < 4; ++d) {
+        const int row = (16 * s_q + 8 * hf + 2 * d) * TR_ROW + col;  // channel of the dword's low half; the high half: next row
+        const uint32_t xv_ = r.x[hf][d], yv_ = r.y[hf][d];
+        *(uint16_t*)(t_x + row) = (uint16_t)xv_;
+        *(uint16_t*)(t_x + row + TR_ROW) = (uint16_t)(xv_ >> 16);
+        *(uint16_t*)(t_dy + row) = (uint16_t)yv_;
+        *(uint16_t*)(t_dy + row + TR_ROW) = (uint16_t)(yv_ >> 16);
         if constexpr (KIND == 1) {
-          const int j = 4 * hf + d;  // pair index of dword d inside the run
-          const uint32_t xas = xa ^ ((wx << j) & 0x80008000u), xbs = xb ^ ((wx << (j + 1)) & 0x80008000u);
-          const uint32_t yas = ya ^ ((wy << j) & 0x80008000u), ybs = yb ^ ((wy << (j + 1)) & 0x80008000u);
-          *(f32x4*)(t_xs + s_px * WG_ROW + s_q * 64 + 16 * v) =
-              (f32x4){u2f(xas << 16), u2f(xas & 0xffff0000u), u2f(xbs << 16), u2f(xbs & 0xffff0000u)};
-          *(f32x4*)(t_dys + s_px * WG_ROW + s_q * 64 + 16 * v) =
-              (f32x4){u2f(yas << 16), u2f(yas & 0xffff0000u), u2f(ybs << 16), u2f(ybs & 0xffff0000u)};
+          const int j = 4 * hf + d;  // pair index of the dword inside the run
+          const uint32_t xs_ = xv_ ^ ((wx << j) & 0x80008000u), ys_ = yv_ ^ ((wy << j) & 0x80008000u);
+          *(uint16_t*)(t_xs + row) = (uint16_t)xs_;
+          *(uint16_t*)(t_xs + row + TR_ROW) = (uint16_t)(xs_ >> 16);
+          *(uint16_t*)(t_dys + row) = (uint16_t)ys_;
+          *(uint16_t*)(t_dys + row + TR_ROW) = (uint16_t)(ys_ >> 16);
         }
       }
   };
   Raw raw;
-  if (fast && m_begin < m_end) fetch(m_begin, raw);
+  if constexpr (fast) { if (m_begin < m_end) fetch(m_begin, raw); }
 
   for (int m0 = m_begin; m0 < m_end; m0 += WG_PX) {
-    if (fast) {
+    if constexpr (fast) {
       stash(raw);
     } else {
     // ---- stage: dy[m0 + s_px][nt*64 + 16 s_q ..] and x[(m0 + s_px) @ tap][ct*64 + 16 s_q ..]
@@ -242,7 +247,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
     }
     __syncthreads();
-    if (fast && m0 + WG_PX < m_end) fetch(m0 + WG_PX, raw);  // in flight during the MFMAs below
+    if constexpr (fast) { if (m0 + WG_PX < m_end) fetch(m0 + WG_PX, raw); }  // in flight during the MFMAs below
+    if constexpr (fast) {
+      // ---- multiply (bf16 MFMA): wave w takes pixels 16w..16w+15 of the step = one k-step of 16
+      const int ko = (16 * wave + 8 * hk) * 2;
+      bf16x8 a[2], b[2], as_[2], bs_[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *(const bf16x8*)(t_dy + (32 * i + l31) * TR_ROW + ko);
+        b[i] = *(const bf16x8*)(t_x + (32 * i + l31) * TR_ROW + ko);
+        if constexpr (KIND == 1) {
+          as_[i] = *(const bf16x8*)(t_dys + (32 * i + l31) * TR_ROW + ko);
+          bs_[i] = *(const bf16x8*)(t_xs + (32 * i + l31) * TR_ROW + ko);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (i < ni_live && j < nj_live) {
+            acc_m[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc_m[i][j], 0, 0, 0);
+            if constexpr (KIND == 1) acc_d[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_[i], bs_[j], acc_d[i][j], 0, 0, 0);
+          }
+        }
+      if (do_bias && tid < 64) {  // column n = tid of dy: its 64 pixels are one row of the transposed tile
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+          const u32x4 v = *(const u32x4*)(t_dy + tid * TR_ROW + q8 * 16);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) bsum_m += u2f(v[d] << 16) + u2f(v[d] & 0xffff0000u);
+          if constexpr (KIND == 1) {
+            const u32x4 vs = *(const u32x4*)(t_dys + tid * TR_ROW + q8 * 16);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) bsum_d += u2f(vs[d] << 16) + u2f(vs[d] & 0xffff0000u);
+          }
+        }
+      }
+    } else {
     // ---- multiply: wave w takes pixels 16w..16w+15 of the step, two per MFMA
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -272,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         bsum_m += *(const float*)(t_dy + q * WG_ROW + tid * 4);
         if constexpr (KIND == 1) bsum_d += *(const float*)(t_dys + q * WG_ROW + tid * 4);
       }
+    }
     }
     __syncthreads();
   }
@@ -376,9 +418,13 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
   const int nwg = (int)(base * chunks);
   const int lds = (kind == BTX_KIND_FLIPOUT ? 4 : 2) * WG_TILE;
   const int lds_need = lds > 65536 ? lds : 65536;  // the cross-wave reduction uses 64 KiB
-#define BTX_LAUNCH_WG(ACT, KIND)                                                                                    \
+  // bf16 fast path (the shapes of a ResNet body and its row-fused stem): whole 16-channel runs, x runs at multiples of 4
+  // elements (8-byte loads) or 16 (16-byte loads), hashed signs, 16-byte aligned tensors
+  const bool fast_ok = act_dtype == BTX_ACT_BF16 && (p.C % 4 == 0) && (p.Cg % 16 == 0) && (p.N % 16 == 0) && (p.Ng % 16 == 0) &&
+                       !p.sign_in && !p.sign_out && ((((uintptr_t)x) | ((uintptr_t)dy)) % 16 == 0);
+#define BTX_LAUNCH_WG(ACT, KIND, FAST)                                                                              \
   do {                                                                                                            \
-    auto kfn = wgrad_kernel<ACT, KIND>;                                                                            \
+    auto kfn = wgrad_kernel<ACT, KIND, FAST>;                                                                      \
     static bool attr_done = false;                                                                                \
     if (!attr_done) {                                                                                             \
       hipError_t e2 = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);  \
@@ -387,8 +433,9 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
     }                                                                                                             \
     hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), lds_need, st, p);                                               \
   } while (0)
-  if (act_dtype == BTX_ACT_F32) { if (kind == 0) BTX_LAUNCH_WG(float, 0); else BTX_LAUNCH_WG(float, 1); }
-  else { if (kind == 0) BTX_LAUNCH_WG(__bf16, 0); else BTX_LAUNCH_WG(__bf16, 1); }
+  if (act_dtype == BTX_ACT_F32) { if (kind == 0) BTX_LAUNCH_WG(float, 0, false); else BTX_LAUNCH_WG(float, 1, false); }
+  else if (fast_ok) { if (kind == 0) BTX_LAUNCH_WG(__bf16, 0, true); else BTX_LAUNCH_WG(__bf16, 1, true); }
+  else { if (kind == 0) BTX_LAUNCH_WG(__bf16, 0, false); else BTX_LAUNCH_WG(__bf16, 1, false); }
 #undef BTX_LAUNCH_WG
   return (int)hipGetLastError();
 }
