@@ -98,18 +98,23 @@ class ContractFn(torch.autograd.Function):
         flip = layer._family == "flipout"
         dy = dy.contiguous() if op.nd == 0 else dy
         with torch.no_grad():
-            nz = layer.materialize_noise(s, tuple(x.shape), tuple(dy.shape), x.dtype)
+            plan = layer._rowfuse_plan(x) if op.nd == 2 else None
+            padded = layer._btx_cpad is not None or plan is not None   # forward noise indices run over padded layouts
+            # sign TENSORS are only needed where the kernels cannot regenerate the hashed signs: channel-padded layouts, and
+            # the data gradient / transposed weight gradient of a row-fused stem
+            stem_wgrad = plan is not None and not op.transposed
+            need_signs = flip and ((padded and (ctx.needs_input_grad[2] or not stem_wgrad)) or
+                                   (op.transposed and rho_b is not None))  # transposed layers: db_delta by torch
+            nz = layer.materialize_noise(s, tuple(x.shape), tuple(dy.shape), x.dtype, signs=need_signs)
             eps = nz["eps_w"]
             dsig = torch.sigmoid(rho.detach())
             w_shape = tuple(rho.shape)
             dx = dmu = drho = dmu_b = drho_b = None
-            plan = layer._rowfuse_plan(x) if op.nd == 2 else None
-            padded = layer._btx_cpad is not None or plan is not None   # forward noise indices run over padded layouts
             kind = _lib.KIND_FLIPOUT if flip else _lib.KIND_REPARAM
             want_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
             want_b = rho_b is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6])
             if want_w or want_b:
-                signs = (nz["sign_in"], nz["sign_out"]) if (flip and padded) else None
+                signs = (nz["sign_in"], nz["sign_out"]) if (flip and padded and "sign_in" in nz) else None
                 if plan is not None and not op.transposed:
                     # row-fused stem: the gradient on the geometry the forward ran on (7 kernel rows x 32 elements instead of
                     # 49 taps x 3 channels of a 64-wide tile; the forward's hashed signs instead of sign tensors)

@@ -370,10 +370,11 @@ class _VariationalNd(BaseVariationalLayer_):
             cache[key] = BF.rowfuse_plan(self._op, key)
         return cache[key]
 
-    def materialize_noise(self, sample_idx, x_shape=None, out_shape=None, x_dtype=None):
+    def materialize_noise(self, sample_idx, x_shape=None, out_shape=None, x_dtype=None, signs=True):
         """The noise BTX-RNG v1 defines for MC sample `sample_idx` of this layer, in the reference's logical
         layouts: dict(eps_w, eps_b[, sign_in, sign_out]).  Also refreshes the eps_* buffers (the reference's
-        observable side effect, conv_variational.py:362)."""
+        observable side effect, conv_variational.py:362).  signs=False: skip the Flipout sign tensors (the backward
+        regenerates the hashed signs inside its kernels and only needs eps)."""
         mu, _ = self._w()
         op, seed, lid = self._op, _rng.seed(), self._btx_layer_id
         cin, cpad = op.in_channels, self._btx_cpad
@@ -389,7 +390,7 @@ class _VariationalNd(BaseVariationalLayer_):
             if self.mu_bias is not None:
                 d["eps_b"] = BF.fill_eps_hip(self.mu_bias.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_B)
                 self.eps_bias.copy_(d["eps_b"])
-            if self._family == "flipout":
+            if self._family == "flipout" and signs:
                 n, _, h, w = x_shape
                 sp = BF.fill_sign_hip(n * plan["Hp"] * plan["Wp"] * cp, mu.device, seed, sample_idx, lid,
                                       _lib.STREAM_SIGN_IN).reshape(n, plan["Hp"], plan["Wp"], cp)
@@ -410,7 +411,7 @@ class _VariationalNd(BaseVariationalLayer_):
         if self.mu_bias is not None:
             d["eps_b"] = BF.fill_eps_hip(self.mu_bias.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_B)
             self.eps_bias.copy_(d["eps_b"])
-        if self._family == "flipout" and x_shape is not None:
+        if self._family == "flipout" and x_shape is not None and signs:
             def cl_to_logical(flat8, shape):
                 if op.nd == 0:
                     return flat8.reshape(shape)
