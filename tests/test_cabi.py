@@ -95,3 +95,27 @@ def test_argument_errors_of_the_sampling_and_format_entry_points():
     assert L.btx_maxpool2d_cl(ctypes.c_void_p(8), one, 1, 1, 8, 8, 16, 3, 2, 1, None) == -6  # alignment
     assert L.btx_avgpool_global_cl(one, one, 1, 1, 49, 12, None) == -3
     assert L.btx_avgpool_global_cl(None, one, 1, 1, 49, 16, None) == -1
+
+
+def test_pool_shape_query_without_gpu():
+    """btx_contract_pool_shape (host-side plan only): the ResNet stem on its row-fused geometry takes BtxEpilogue.pool,
+    f32 activations / non-row-fused / oversized geometries do not"""
+    from bayesian_torch_amd import _lib
+    L = _lib.lib()
+    g = _lib.Geom()
+    g.NB, g.D, g.H, g.W, g.C, g.N = 64, 1, 230, 230, 4, 64          # 224^2 + 2*3 padding, 3 -> 4 channels
+    g.KD, g.KH, g.KW = 1, 7, 8                                        # 7 -> 8 taps per kernel row
+    g.sd, g.sh, g.sw = 1, 2, 2
+    g.pd = g.ph = g.pw = 0
+    g.dd = g.dh = g.dw = 1
+    g.groups = 1
+    hq, wq = ctypes.c_int32(), ctypes.c_int32()
+    q = lambda act, prec, flags: L.btx_contract_pool_shape(ctypes.byref(g), act, prec, flags, ctypes.byref(hq), ctypes.byref(wq))  # noqa: E731
+    assert q(_lib.ACT_BF16, _lib.PREC_BF16, _lib.FLAG_ROWFUSE) == 1 and (hq.value, wq.value) == (56, 56)
+    assert q(_lib.ACT_F32, _lib.PREC_F32, _lib.FLAG_ROWFUSE) == 0      # bf16 only
+    assert q(_lib.ACT_BF16, _lib.PREC_BF16, 0) == 0                    # the row-fused stem path only
+    g.H = g.W = 518                                                   # 256 output columns: two conv rows exceed a half tile
+    assert q(_lib.ACT_BF16, _lib.PREC_BF16, _lib.FLAG_ROWFUSE) == 0
+    g.H = g.W = 230
+    g.N = 96                                                          # whole 64-channel tiles only
+    assert q(_lib.ACT_BF16, _lib.PREC_BF16, _lib.FLAG_ROWFUSE) == 0
