@@ -15,7 +15,7 @@ from . import layers, models, utils  # noqa: F401
 from .functional import set_precision, get_precision, set_output_layout  # noqa: F401
 from .layers.base_variational_layer import set_backend  # noqa: F401
 from .models.dnn_to_bnn import dnn_to_bnn, get_kl_loss  # noqa: F401
-from .rng import manual_seed, set_sample_index, assign_layer_ids, presample  # noqa: F401
+from .rng import manual_seed, set_sample_index, set_sample_lanes, assign_layer_ids, presample  # noqa: F401
 
 __version__ = "0.1.0"
 

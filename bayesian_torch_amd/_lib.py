@@ -12,7 +12,9 @@ PREC_F32, PREC_BF16 = 0, 1
 FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER, FLAG_SWAP_SIGNS, FLAG_CONCURRENT = 1, 2, 4, 8, 16, 32, 64, 128
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
+FLAG_LANES_SHIFT = 16
+SAMPLE_SKIP_MU = 1
 
 
 class BtxError(RuntimeError):
@@ -35,6 +37,11 @@ class Epilogue(ctypes.Structure):
                 ("relu", ctypes.c_int32), ("pool", ctypes.c_int32)]
 
 
+class Lanes(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("x_stride", ctypes.c_int64), ("out_stride", ctypes.c_int64),
+                ("res_stride", ctypes.c_int64)]
+
+
 class Noise(ctypes.Structure):
     _fields_ = [("eps_w", ctypes.c_void_p), ("eps_b", ctypes.c_void_p),
                 ("sign_in", ctypes.c_void_p), ("sign_out", ctypes.c_void_p), ("sampled_w", ctypes.c_void_p)]
@@ -54,8 +61,8 @@ class KlItem(ctypes.Structure):
 
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss", "btx_kl_model_workspace_bytes",
            "btx_kl_gauss_model", "btx_kl_gauss_model_bwd", "btx_contract_wgrad",
-           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
-           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
+           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_fwd_lanes", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
+           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
 
 
 def lib_path():
@@ -98,6 +105,8 @@ def lib():
                                    ctypes.POINTER(Noise), i32, i32, u32, vp, sz, vp]
     L.btx_contract_fwd_ex.restype = i32
     L.btx_contract_fwd_ex.argtypes = L.btx_contract_fwd.argtypes + [ctypes.POINTER(Epilogue)]
+    L.btx_contract_fwd_lanes.restype = i32
+    L.btx_contract_fwd_lanes.argtypes = L.btx_contract_fwd_ex.argtypes + [ctypes.POINTER(Lanes)]
     L.btx_contract_pool_shape.restype = i32
     L.btx_contract_pool_shape.argtypes = [ctypes.POINTER(Geom), i32, i32, u32] + [ctypes.POINTER(ctypes.c_int32)] * 2
     L.btx_out_shape.restype = i32
@@ -112,6 +121,10 @@ def lib():
     L.btx_sampled_w_bytes.argtypes = [ctypes.POINTER(Geom), i32, i32]
     L.btx_sample_weights.restype = i32
     L.btx_sample_weights.argtypes = [ctypes.POINTER(SampleItem), i32, ctypes.POINTER(Rng), i32, vp]
+    L.btx_sampled_w_bytes_lanes.restype = sz
+    L.btx_sampled_w_bytes_lanes.argtypes = [ctypes.POINTER(Geom), i32, i32, i32]
+    L.btx_sample_weights_lanes.restype = i32
+    L.btx_sample_weights_lanes.argtypes = [ctypes.POINTER(SampleItem), i32, ctypes.POINTER(Rng), i32, vp, i32, u32]
     L.btx_rowfuse_pack.restype = i32
     L.btx_rowfuse_pack.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int64), i32, i32, i32, i32, vp, i32, i32, i32, i32, i32,
                                    i32, vp]

@@ -513,6 +513,15 @@ struct Plan {
   int Do, Ho, Wo, Cg, Ng, M, K, mtiles, ntiles, ksplits, kper, nwg;
 };
 
+// MC sample lanes of the launch being planned (BTX_FLAG_LANES(n) in the flags): the grid is `lanes` copies of the
+// single-sample grid, so that many times more workgroups fill the workgroup slots before K has to be split
+static inline long long plan_lanes(uint32_t flags) {
+  const long long n = (flags >> BTX_FLAG_LANES_SHIFT) & 0xffu;
+  return n > 1 ? n : 1;
+}
+
+static inline bool throughput_plan(uint32_t flags) { return (flags & BTX_FLAG_CONCURRENT) || plan_lanes(flags) > 1; }
+
 static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* pl) {
   int rc = btx_out_shape(g, flags, &pl->Do, &pl->Ho, &pl->Wo);
   if (rc) return rc;
@@ -527,7 +536,8 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* p
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   pl->mtiles = (pl->M + bm - 1) / bm;
   pl->ntiles = (pl->Ng + BN - 1) / BN;
-  const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
+  const long long base1 = (long long)pl->mtiles * pl->ntiles * g->groups;
+  const long long base = base1 * plan_lanes(flags);  // workgroups of all lanes
   const int stages = (pl->K + bk - 1) / bk;
   // split-K: pick the split that minimises (grid rounds on 256 CUs) x (stages per block + fixed per-block cost);
   // each split keeps >= 4 stages so the DMA ring fills.
@@ -537,19 +547,21 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* p
     long long best = -1;
     const int max_ks = stages / 4 > 1 ? (stages / 4 < 32 ? stages / 4 : 32) : 1;
     for (int c = 1; c <= max_ks; ++c) {
-      const long long rounds = (base * c + ncu - 1) / ncu;
+      const long long rounds = (base1 * c + ncu - 1) / ncu;  // of ONE lane: the split must not depend on the lane count
       const long long cost = rounds * ((stages + c - 1) / c + 4) + (c > 1 ? 1 : 0);  // +1: the reduce pass
       if (best < 0 || cost < best) { best = cost; ks = c; }
       // BTX_FLAG_CONCURRENT: other launches fill the CUs this one leaves idle, so what counts is its CU-time, and that
       // only grows with the split (fixed per-block cost, partial sums through HBM, the reduce launch): split just far
-      // enough that the launch is not a long thin tail of its own stream
-      if ((flags & BTX_FLAG_CONCURRENT) && base * c >= 64) { ks = c; break; }
+      // enough that the launch is not a long thin tail of its own stream.  Launches with MC sample lanes take the same
+      // plan, decided by the grid of ONE lane: the K split — the f32 summation order — of a sample then does not depend
+      // on how many samples share its launch, nor on how the samples were grouped over launches and ranks.
+      if (throughput_plan(flags) && base1 * c >= 64) { ks = c; break; }
     }
   }
   int per_stages = (stages + ks - 1) / ks;
   pl->kper = per_stages * bk;
   pl->ksplits = (pl->K + pl->kper - 1) / pl->kper;
-  const long long nwg = base * pl->ksplits;
+  const long long nwg = base1 * pl->ksplits;  // per lane
   if (nwg > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
   pl->nwg = (int)nwg;
   return 0;
@@ -573,7 +585,38 @@ static bool dma_shape_ok(const BtxGeom* g, int act_dtype, int prec, const Plan& 
 struct PatchPlan {
   int G, R, Rp, Wp, PP, NI, rtiles, nw, mi, astage, lds;
   int taps, kg, lds_g;  // tap-unrolled kernel (btx_contract_taps.h): 10*KH+KW or 0; K-groups per workgroup; LDS per group
+  int tall, P, Wt, ncs;  // tall-strip tiles (ContractParams.pt_tall): virtual rows per image, strip width, strips per row tile
 };
+// Tall-strip tile of the tap-unrolled kernel: the batch as ONE tall image with P = max(H + ph, Ho) virtual rows per image
+// (P - H zero rows between consecutive images: bottom padding of one, top padding of the next; output rows >= Ho of a
+// period are dummies), cut into tiles of R virtual rows x Wt columns.  R and Wt need not divide Ho / Wo, so the tile
+// can fill the 256 pixel slots of a workgroup whatever the map size (7 | 14 | 28 | 56: 252 pixels) where whole-row /
+// whole-image tiles leave an eighth to a quarter of the MFMA tiles empty.  Returns the fraction of pixel slots that hold
+// real output pixels (0: no tall tile fits).
+static double tall_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, PatchPlan* pt) {
+  const int halo_r = (g->KH - 1) * g->dh, halo_c = (g->KW - 1) * g->dw;
+  if (g->ph > halo_r) return 0.0;
+  const int P = (g->H + g->ph > pl.Ho) ? g->H + g->ph : pl.Ho;
+  const long long rows_total = (long long)(g->NB - 1) * P + pl.Ho;
+  double best = 0.0;
+  for (int ncs = 1; ncs <= 8; ++ncs) {
+    const int Wt = (pl.Wo + ncs - 1) / ncs;
+    if (Wt > tp || Wt < 4 || (ncs > 1 && Wt < 8)) continue;  // Wt >= 4: PixTall::Walk steps 8 pixels with two row wraps
+    int R = tp / Wt;
+    if (R > rows_total) R = (int)rows_total;
+    while (R >= 1 && (R + halo_r) * (Wt + halo_c) > ppcap) --R;
+    if (R < 1) continue;
+    const long long rtiles = (rows_total + R - 1) / R;
+    const double eff = (double)pl.M / ((double)rtiles * ncs * tp);
+    if (eff > best * 1.01) {
+      best = eff;
+      pt->tall = 1; pt->P = P; pt->Wt = Wt; pt->ncs = ncs;
+      pt->G = 1; pt->R = R; pt->Rp = R + halo_r; pt->Wp = Wt + halo_c; pt->PP = pt->Rp * pt->Wp;
+      pt->rtiles = (int)rtiles;
+    }
+  }
+  return best;
+}
 // tile of `tp` output pixels whose patch holds at most `ppcap` pixels
 static bool patch_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, PatchPlan* pt) {
   const int Ho = pl.Ho, Wo = pl.Wo;
@@ -616,10 +659,22 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   static const char* mi_env = tune_env("BTX_PATCH_MI");
   const bool want_mi4 = mi_env && atoi(mi_env) == 4;
   pt->mi = 2;
+  pt->tall = 0; pt->P = 1; pt->Wt = 1; pt->ncs = 1;
   if (want_mi4 && patch_tile(g, *pl, 512, 960, pt)) { pt->nw = 4; pt->mi = 4; }
   else if (!force8 && patch_tile(g, *pl, 256, 352, pt)) pt->nw = 4;
   else if (patch_tile(g, *pl, 512, 960, pt)) pt->nw = 8;
   else return false;
+  // 3x3 on 4-wave blocks (the tap-unrolled kernel): tall-strip tiles when they fill the pixel slots better
+  if (pt->nw == 4 && pt->mi == 2 && g->KH == 3 && g->KW == 3 && !tune_env("BTX_NO_TALL") && !tune_env("BTX_NO_TAPS")) {
+    const long long mt_old = (long long)((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
+    const double eff_old = (double)pl->M / ((double)mt_old * 256.0);
+    PatchPlan tp = *pt;
+    const double eff_tall = tall_tile(g, *pl, 256, 352, &tp);
+    // measured (tools/kbench.py --throughput-plan, batch 256 / 512): the heavier tile (4 full waves, a store side 50 %
+    // longer) pays off only where it removes >= ~15 % of the workgroups (28x28: 19 %, 14x14: 16 %; 56x56: 9 % and 7x7:
+    // 6 % lose)
+    if (eff_tall > eff_old * 1.12) *pt = tp;
+  }
   const int pieces = (pt->PP + 15) / 16;
   pt->NI = (pieces + pt->nw - 1) / pt->nw;
   if (pt->NI > (pt->mi == 4 ? 16 : PT_MAXNI)) return false;
@@ -633,8 +688,9 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   // grid: m-tiles are (image group, row tile); split-K over the channel blocks
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   const int ncb = pl->Cg / bk;
-  pl->mtiles = ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
-  const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
+  pl->mtiles = pt->tall ? pt->rtiles * pt->ncs : ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
+  const long long base1 = (long long)pl->mtiles * pl->ntiles * g->groups;
+  const long long base = base1 * plan_lanes(flags);
   const bool no_taps = tune_env("BTX_NO_TAPS") != nullptr;  // A/B: the run-time-tap patch kernel instead (read per call)
   pt->taps = (!no_taps && pt->nw == 4 && pt->mi == 2 && pt->NI <= 6 && g->KH == 3 && g->KW == 3) ? 33 : 0;
   // Few pixel tiles (at most one 4-wave block per CU): 8-wave blocks of two K-groups — split-K inside the workgroup
@@ -642,7 +698,7 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   // BTX_FLAG_CONCURRENT: plain 4-wave blocks — an 8-wave block takes the whole LDS of its CU, so two such launches of
   // different MC samples cannot share a CU; 4-wave blocks of two launches pair up and free-run against each other
   // (measured, ResNet18 bs 64, 3 / 4 / 6 samples in flight: 1340 / 1369 / 1346 -> 1382 / 1402 / 1378 MC-samples/s).
-  const bool no_kg = tune_env("BTX_NO_KG") != nullptr || (flags & BTX_FLAG_CONCURRENT);
+  const bool no_kg = tune_env("BTX_NO_KG") != nullptr || throughput_plan(flags);
   pt->kg = (pt->taps && !no_kg && base <= 256 && ncb >= 2 && (ncb % 2) == 0 && 2 * pt->lds_g <= 163840) ? 2 : 1;
   const int units = ncb / pt->kg;  // channel blocks per K-group over the whole K
   int ks = 1;
@@ -653,16 +709,16 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
       const int per = (units + c - 1) / c;
       if (c > 1 && per * T < 4) break;
       if (pt->kg == 2 && units % c) continue;  // the 8-wave kernel wants every split full
-      const long long rounds = (base * c + slots - 1) / slots;
+      const long long rounds = (base1 * c + slots - 1) / slots;
       const long long cost = rounds * (per * T + 4) + (c > 1 ? 1 : 0);
       if (best < 0 || cost < best) { best = cost; ks = c; }
-      if ((flags & BTX_FLAG_CONCURRENT) && base * c * pt->kg >= 64) { ks = c; break; }  // see make_plan
+      if (throughput_plan(flags) && base1 * c * pt->kg >= 64) { ks = c; break; }  // see make_plan
     }
   }
   const int per = (units + ks - 1) / ks;
   pl->kper = per * pt->kg * bk;
   pl->ksplits = (units + per - 1) / per;
-  const long long nwg = base * pl->ksplits;
+  const long long nwg = base1 * pl->ksplits;
   if (nwg > 0x7fffffffLL) return false;
   pl->nwg = (int)nwg;
   if (pt->kg == 2) pt->lds = 2 * pt->lds_g;
@@ -682,6 +738,7 @@ static bool make_patch2_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t
   gp.KH = 2; gp.KW = 2;
   if (!patch_tile(&gp, *pl, 256, 272, pt)) return false;
   pt->nw = 4; pt->mi = 2;
+  pt->tall = 0; pt->P = 1; pt->Wt = 1; pt->ncs = 1;
   const int pieces = (pt->PP + 15) / 16;
   pt->NI = (pieces + 3) / 4;
   if (pt->NI > 5) return false;
@@ -695,7 +752,8 @@ static bool make_patch2_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   const int ncb = pl->Cg / bk;
   pl->mtiles = ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
-  const long long base = (long long)pl->mtiles * pl->ntiles * g->groups;
+  const long long base1 = (long long)pl->mtiles * pl->ntiles * g->groups;
+  const long long base = base1 * plan_lanes(flags);
   pt->taps = 332;
   pt->kg = 1;
   int ks = 1;
@@ -704,16 +762,16 @@ static bool make_patch2_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t
     long long best = -1;
     for (int c = 1; c <= ncb && c <= 32; ++c) {
       const int per = (ncb + c - 1) / c;
-      const long long rounds = (base * c + slots - 1) / slots;
+      const long long rounds = (base1 * c + slots - 1) / slots;
       const long long cost = rounds * (per * 9 + 4) + (c > 1 ? 1 : 0);
       if (best < 0 || cost < best) { best = cost; ks = c; }
-      if ((flags & BTX_FLAG_CONCURRENT) && base * c >= 64) { ks = c; break; }  // see make_plan
+      if (throughput_plan(flags) && base1 * c >= 64) { ks = c; break; }  // see make_plan
     }
   }
   const int per = (ncb + ks - 1) / ks;
   pl->kper = per * bk;
   pl->ksplits = (ncb + per - 1) / per;
-  const long long nwg = base * pl->ksplits;
+  const long long nwg = base1 * pl->ksplits;
   if (nwg > 0x7fffffffLL) return false;
   pl->nwg = (int)nwg;
   return true;
@@ -795,15 +853,17 @@ static bool make_stem_pool_plan(const BtxGeom* g, int act_dtype, int prec, const
 }
 
 // workspace of the patch variant: split-K partials (256-byte padded), then the pre-sampled weight tiles
-static size_t patch_wt_bytes(const Plan& pl, const BtxGeom* g, int kind, int prec, size_t* one) {
+// Flipout: [mu tiles | delta tiles of lane 0 | lane 1 | ...] — the mu tiles do not depend on the MC sample, one set serves
+// every lane; Reparameterization: [W tiles of lane 0 | lane 1 | ...]
+static size_t patch_wt_bytes(const Plan& pl, const BtxGeom* g, int kind, int prec, size_t* one, int lanes = 1) {
   const size_t arr = (size_t)g->groups * pl.ntiles * 64 * (size_t)pl.K * (prec == BTX_PREC_BF16 ? 2 : 4);
   if (one) *one = arr;
-  return arr * (kind == BTX_KIND_FLIPOUT ? 2 : 1);
+  return arr * (size_t)(kind == BTX_KIND_FLIPOUT ? 1 + lanes : lanes);
 }
 static size_t pad256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static size_t plan_ws(const Plan& pl, const BtxGeom* g) {
-  return pl.ksplits > 1 ? (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
+static size_t plan_ws(const Plan& pl, const BtxGeom* g, int lanes = 1) {  // split-K partials [lane][split][M][N]
+  return pl.ksplits > 1 ? (size_t)lanes * (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
 }
 
 int btx_contract_pool_shape(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, int32_t* Hq, int32_t* Wq) {
@@ -824,18 +884,19 @@ size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, i
   Plan a, b;
   if (!g || make_plan(g, prec, flags, BM, &a) || make_plan(g, prec, flags, DBM, &b)) return 0;
   (void)kind;
-  size_t wa = plan_ws(a, g);  // which kernel runs also depends on pointer alignment
-  const size_t wb = pad256(plan_ws(b, g)) + patch_wt_bytes(b, g, BTX_KIND_FLIPOUT, prec, nullptr);
+  const int lanes = (int)plan_lanes(flags);
+  size_t wa = plan_ws(a, g, lanes);  // which kernel runs also depends on pointer alignment
+  const size_t wb = pad256(plan_ws(b, g, lanes)) + patch_wt_bytes(b, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
   if (wb > wa) wa = wb;
   Plan b4;
   if (!make_plan(g, prec, flags, 256, &b4)) {
-    const size_t w4 = pad256(plan_ws(b4, g)) + patch_wt_bytes(b4, g, BTX_KIND_FLIPOUT, prec, nullptr);
+    const size_t w4 = pad256(plan_ws(b4, g, lanes)) + patch_wt_bytes(b4, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
     if (w4 > wa) wa = w4;
   }
   Plan c;
   PatchPlan pt;
   if (make_patch_plan(g, act_dtype, prec, flags, &c, &pt) || make_patch2_plan(g, act_dtype, prec, flags, &c, &pt)) {
-    const size_t wc = pad256(plan_ws(c, g)) + patch_wt_bytes(c, g, BTX_KIND_FLIPOUT, prec, nullptr);
+    const size_t wc = pad256(plan_ws(c, g, lanes)) + patch_wt_bytes(c, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
     if (wc > wa) wa = wc;
   }
   return wa;
@@ -848,11 +909,37 @@ int btx_contract_fwd(int kind, const BtxGeom* g, const void* x, const float* mu_
                              ws_bytes, stream, nullptr);
 }
 
+static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
+                             const float* mu_b, const float* rho_b, void* out, const BtxRng* rng, const BtxNoise* noise,
+                             int act_dtype, int prec, uint32_t flags, void* ws, size_t ws_bytes, void* stream,
+                             const BtxEpilogue* ep, const BtxLanes* ln);
+
 int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
                         const float* mu_b, const float* rho_b, void* out, const BtxRng* rng, const BtxNoise* noise,
                         int act_dtype, int prec, uint32_t flags, void* ws, size_t ws_bytes, void* stream,
                         const BtxEpilogue* ep) {
+  return contract_fwd_impl(kind, g, x, mu_w, rho_w, mu_b, rho_b, out, rng, noise, act_dtype, prec,
+                           flags & ~BTX_FLAG_LANES_MASK, ws, ws_bytes, stream, ep, nullptr);
+}
+
+int btx_contract_fwd_lanes(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
+                           const float* mu_b, const float* rho_b, void* out, const BtxRng* rng, const BtxNoise* noise,
+                           int act_dtype, int prec, uint32_t flags, void* ws, size_t ws_bytes, void* stream,
+                           const BtxEpilogue* ep, const BtxLanes* lanes) {
+  if (!lanes) return BTX_E_NULL;
+  if (lanes->n < 1 || lanes->n > 255) return BTX_E_SHAPE;
+  if ((lanes->x_stride | lanes->out_stride | lanes->res_stride) & 15) return BTX_E_ALIGN;
+  if (noise && lanes->n > 1 && (noise->eps_w || noise->eps_b || noise->sign_in || noise->sign_out)) return BTX_E_UNSUPPORTED;
+  return contract_fwd_impl(kind, g, x, mu_w, rho_w, mu_b, rho_b, out, rng, noise, act_dtype, prec,
+                           (flags & ~BTX_FLAG_LANES_MASK) | BTX_FLAG_LANES(lanes->n), ws, ws_bytes, stream, ep, lanes);
+}
+
+static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const float* mu_w, const float* rho_w,
+                             const float* mu_b, const float* rho_b, void* out, const BtxRng* rng, const BtxNoise* noise,
+                             int act_dtype, int prec, uint32_t flags, void* ws, size_t ws_bytes, void* stream,
+                             const BtxEpilogue* ep, const BtxLanes* ln) {
   if (!g || !x || !mu_w || !rho_w || !out || !rng) return BTX_E_NULL;
+  const int lanes = ln ? ln->n : 1;
   if ((mu_b == nullptr) != (rho_b == nullptr)) return BTX_E_NULL;
   if (kind != BTX_KIND_REPARAM && kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
   if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
@@ -928,7 +1015,7 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     if (!dma) return BTX_E_UNSUPPORTED;
     out_bf16 = (flags & BTX_FLAG_OUT_BF16) ? 1 : 0;
   }
-  size_t need = plan_ws(pl, g);
+  size_t need = plan_ws(pl, g, lanes);
   // LDS-DMA and patch variants: the weights are sampled once per launch into the workspace (btx_presample.h),
   // behind the split-K partials
   size_t wt_off = 0, wt_one = 0, wt_all = 0;
@@ -936,14 +1023,14 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   if (sampled_w && (((uintptr_t)sampled_w) & 15)) return BTX_E_ALIGN;
   if (dma) {
     wt_off = pad256(need);
-    wt_all = patch_wt_bytes(pl, g, kind, prec, &wt_one);
+    wt_all = patch_wt_bytes(pl, g, kind, prec, &wt_one, lanes);
     if (sampled_w && wt_all < 0xfff00000ULL) wt_off = need;  // tiles live in the caller's buffer
     if (wt_off + wt_all >= 0xfff00000ULL) {  // 32-bit offsets inside the descriptor: register-staged kernel instead
       if (rowfuse || (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_OUT_BF16))) return BTX_E_UNSUPPORTED;
       dma = patch = false;
       rc = make_plan(g, prec, flags, BM, &pl);
       if (rc) return rc;
-      need = plan_ws(pl, g);
+      need = plan_ws(pl, g, lanes);
     } else if (!sampled_w) {
       need = wt_off + wt_all;
     }
@@ -955,6 +1042,12 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
   memset(&p, 0, sizeof(p));
   p.x = x; p.mu = mu_w; p.rho = rho_w; p.mu_b = mu_b; p.rho_b = rho_b; p.out = out;
   p.partial = pl.ksplits > 1 ? (float*)ws : nullptr;
+  p.lanes = lanes; p.lane_nwg = pl.nwg; p.fd_lane_nwg = make_fastdiv((uint32_t)(pl.nwg > 0 ? pl.nwg : 1));
+  if (lanes > 1) {
+    p.lane_x = ln->x_stride; p.lane_out = ln->out_stride; p.lane_res = ln->res_stride;
+    p.lane_partial = (long long)(plan_ws(pl, g, 1));
+    if ((long long)pl.nwg * lanes > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
+  }
   if (noise) {
     p.eps_w = noise->eps_w; p.eps_b = noise->eps_b;
     p.sign_in = noise->sign_in; p.sign_out = noise->sign_out;
@@ -1013,19 +1106,21 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.wt_ready = sampled_w ? 1 : 0;
     p.wt_bytes = (uint32_t)wt_all;
     p.wt_delta_off = (uint32_t)wt_one;
+    p.lane_wt = (long long)wt_one;  // Flipout: lane l's delta tiles at wt_delta_off + l*lane_wt; else its W tiles at l*lane_wt
+    p.lane_wt_delta = (kind == BTX_KIND_FLIPOUT) ? 1 : 0;
   }
   hipStream_t st = (hipStream_t)stream;
   if (want_pool) {
     p.pt_R = spp.PB; p.pt_rtiles = spp.bands; p.pt_Rp = spp.Rp; p.pt_astage = spp.astage; p.st_sbytes = spp.sbytes;
     p.pt_lds = spp.lds; p.pt_PP = spp.patch_bytes; p.sp_Hq = spp.Hq; p.sp_Wq = spp.Wq;
     p.fd_rtiles = make_fastdiv((uint32_t)spp.bands);
-    rc = launch_stem_pool_bf16(kind, p, pl.nwg, st);
+    rc = launch_stem_pool_bf16(kind, p, pl.nwg * lanes, st);
   } else if (stem) {
     p.pt_R = stp.R; p.pt_Rp = stp.Rp; p.pt_rtiles = stp.rtiles; p.pt_nw = stp.nw; p.pt_astage = stp.astage;
     p.st_sbytes = stp.sbytes; p.pt_lds = stp.lds; p.pt_PP = stp.patch_bytes;
     p.fd_rtiles = make_fastdiv((uint32_t)stp.rtiles);
-    rc = (prec == BTX_PREC_BF16) ? launch_contract_stem_bf16(kind, p, pl.nwg, st)
-                                 : launch_contract_stem_f32(kind, p, pl.nwg, st);
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_stem_bf16(kind, p, pl.nwg * lanes, st)
+                                 : launch_contract_stem_f32(kind, p, pl.nwg * lanes, st);
   } else if (patch) {
     p.pt_G = pt.G; p.pt_R = pt.R; p.pt_Rp = pt.Rp; p.pt_Wp = pt.Wp; p.pt_PP = pt.PP; p.pt_NI = pt.NI;
     p.fd_ptWp = make_fastdiv((uint32_t)pt.Wp); p.fd_ptRp = make_fastdiv((uint32_t)pt.Rp); p.fd_ptR = make_fastdiv((uint32_t)pt.R);
@@ -1033,17 +1128,19 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_mi = pt.mi; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
     { const char* tn = tune_env("BTX_TAPS_TUNE"); p.pt_tune = tn ? atoi(tn) : 0; }
     p.pt_taps = pt.taps; p.pt_kg = pt.kg; p.pt_lds_g = pt.lds_g;
-    rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg, st)
-                                 : launch_contract_patch_f32(kind, p, pl.nwg, st);
+    p.pt_tall = pt.tall; p.pt_P = pt.P; p.pt_Wt = pt.Wt; p.pt_ncs = pt.ncs;
+    p.fd_P = make_fastdiv((uint32_t)pt.P); p.fd_Wt = make_fastdiv((uint32_t)pt.Wt); p.fd_ncs = make_fastdiv((uint32_t)pt.ncs);
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg * lanes, st)
+                                 : launch_contract_patch_f32(kind, p, pl.nwg * lanes, st);
   } else if (dma)
-    rc = (prec == BTX_PREC_BF16) ? launch_contract_dma_bf16(kind, p, pl.nwg, st)
-                                 : launch_contract_dma_f32(kind, p, pl.nwg, st);
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_dma_bf16(kind, p, pl.nwg * lanes, st)
+                                 : launch_contract_dma_f32(kind, p, pl.nwg * lanes, st);
   else {
     // the register-staged fast kernel samples in registers and hashes its own s_in: explicit eps_w / sign_in need either
     // the LDS-DMA family above (pre-pass sampling, packed sign words) or the gather kernel
     const bool gen2 = gen || (noise && (noise->eps_w || noise->sign_in));
-    rc = (prec == BTX_PREC_BF16) ? launch_contract_bf16(kind, act_dtype == BTX_ACT_BF16, gen2, p, pl.nwg, st)
-                                 : launch_contract_f32(kind, act_dtype == BTX_ACT_BF16, gen2, p, pl.nwg, st);
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_bf16(kind, act_dtype == BTX_ACT_BF16, gen2, p, pl.nwg * lanes, st)
+                                 : launch_contract_f32(kind, act_dtype == BTX_ACT_BF16, gen2, p, pl.nwg * lanes, st);
   }
   if (rc) return rc;
   if (pl.ksplits > 1) {
@@ -1051,27 +1148,41 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g, const void* x, const float* 
     long long blocks = (total / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    if (out_bf16)
-      hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, (const float*)ws,
-                         (__bf16*)out, total, pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const __bf16*)p.ep_res,
-                         p.ep_relu);
-    else
-      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)ws,
-                         (float*)out, total, pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const float*)p.ep_res,
-                         p.ep_relu);
-    rc = (int)hipGetLastError();
+    for (int l = 0; l < lanes && !rc; ++l) {
+      const float* part = (const float*)((const unsigned char*)ws + (long long)l * p.lane_partial);
+      unsigned char* o = (unsigned char*)out + (long long)l * p.lane_out;
+      const unsigned char* r = p.ep_res ? (const unsigned char*)p.ep_res + (long long)l * p.lane_res : nullptr;
+      if (out_bf16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, part, (__bf16*)o, total,
+                           pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const __bf16*)r, p.ep_relu);
+      else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, st, part, (float*)o, total,
+                           pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const float*)r, p.ep_relu);
+      rc = (int)hipGetLastError();
+    }
   }
   return rc;
 }
 
-size_t btx_sampled_w_bytes(const BtxGeom* g, int kind, int prec) {
+size_t btx_sampled_w_bytes(const BtxGeom* g, int kind, int prec) { return btx_sampled_w_bytes_lanes(g, kind, prec, 1); }
+
+size_t btx_sampled_w_bytes_lanes(const BtxGeom* g, int kind, int prec, int lanes) {
   Plan pl;
-  if (!g || make_plan(g, prec, 0, DBM, &pl)) return 0;
-  return patch_wt_bytes(pl, g, kind, prec, nullptr);
+  if (!g || lanes < 1 || lanes > 255 || make_plan(g, prec, 0, DBM, &pl)) return 0;
+  size_t one = 0;
+  const size_t tiles = patch_wt_bytes(pl, g, kind, prec, &one, lanes);
+  // Flipout: + the sigma cache (f32 per weight, tile order) behind the tiles — what BTX_SAMPLE_SKIP_MU reads instead of rho
+  return tiles + (kind == BTX_KIND_FLIPOUT ? one * (prec == BTX_PREC_BF16 ? 2 : 1) : 0);
 }
 
 int btx_sample_weights(const BtxSampleItem* items, int n_items, const BtxRng* rng, int prec, void* stream) {
+  return btx_sample_weights_lanes(items, n_items, rng, prec, stream, 1, 0);
+}
+
+int btx_sample_weights_lanes(const BtxSampleItem* items, int n_items, const BtxRng* rng, int prec, void* stream, int lanes,
+                             uint32_t sflags) {
   if (!items || !rng) return BTX_E_NULL;
+  if (lanes < 1 || lanes > 255) return BTX_E_SHAPE;
   const uint64_t seed = rng->seed;
   const uint32_t sample_idx = rng->sample_idx;
   if (n_items <= 0) return n_items == 0 ? 0 : BTX_E_SHAPE;
@@ -1081,6 +1192,7 @@ int btx_sample_weights(const BtxSampleItem* items, int n_items, const BtxRng* rn
     memset(&b, 0, sizeof(b));
     b.n = n_items - base < PRESAMPLE_MAX_ITEMS ? n_items - base : PRESAMPLE_MAX_ITEMS;
     b.seed_lo = (uint32_t)seed; b.seed_hi = (uint32_t)(seed >> 32); b.sample = sample_idx; b.sample_ptr = rng->sample_idx_dev;
+    b.lanes = lanes; b.skip_mu = (sflags & BTX_SAMPLE_SKIP_MU) ? 1 : 0;
     uint32_t blocks = 0;
     for (int i = 0; i < b.n; ++i) {
       const BtxSampleItem& s = items[base + i];
@@ -1093,7 +1205,7 @@ int btx_sample_weights(const BtxSampleItem* items, int n_items, const BtxRng* rn
       if (rc) return rc;
       if (pl.K % (prec == BTX_PREC_BF16 ? 8 : 4)) return BTX_E_UNSUPPORTED;  // whole 16-byte granules of the tile image
       size_t one = 0;
-      if (patch_wt_bytes(pl, s.geom, s.kind, prec, &one) >= 0xfff00000ULL) return BTX_E_UNSUPPORTED;
+      if (patch_wt_bytes(pl, s.geom, s.kind, prec, &one, lanes) >= 0xfff00000ULL) return BTX_E_UNSUPPORTED;
       PresampleItem& it = b.it[i];
       it.mu = s.mu_w; it.rho = s.rho_w; it.wt = (unsigned char*)s.out;
       it.delta_off = (uint32_t)one;

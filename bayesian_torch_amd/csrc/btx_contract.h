@@ -135,7 +135,52 @@ struct ContractParams {
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off
   uint32_t wt_bytes, wt_delta_off;
   int wt_ready;  // wt was filled by btx_sample_weights: skip the per-launch sampling pre-pass
+  // "tall strip" tiles of the tap-unrolled kernel (btx_contract_taps.h): the batch is one tall image of pt_P virtual rows
+  // per image (the image's Ho output rows + dummy rows; on the input side pt_P - H zero rows separate consecutive
+  // images and serve as the bottom padding of one and the top padding of the next), cut into tiles of pt_R virtual rows
+  // x pt_Wt columns (pt_ncs column strips per row tile).  Tile sizes are then free of the divisors of Ho and Wo.
+  int pt_tall, pt_P, pt_Wt, pt_ncs;
+  FastDiv fd_P, fd_Wt, fd_ncs;
+  // MC sample lanes (BtxLanes): the grid holds `lanes` copies of the single-sample grid of `lane_nwg` workgroups; lane l
+  // reads x + l*lane_x, the weight tiles wt + l*lane_wt, the sample word sample_ptr[l] (or sample + l), and writes
+  // out + l*lane_out (residual + l*lane_res, split-K partials + l*lane_partial): byte strides
+  int lanes, lane_nwg;
+  FastDiv fd_lane_nwg;
+  long long lane_x, lane_out, lane_res, lane_wt, lane_partial;
+  int lane_wt_delta;  // 1 (Flipout): the lanes share the mu tiles at wt, lane l's delta tiles sit at wt_delta_off + l*lane_wt
 };
+
+// ---- workgroup id -> logical id, XCD-aware: block b runs on XCD b % 8; every XCD gets a contiguous range of logical ids,
+// so the workgroups that share an operand (and, with MC sample lanes, the workgroups of one lane) share an L2
+__device__ __forceinline__ int xcd_logical() {
+  const int nwg = gridDim.x, L = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// ---- MC sample lanes: the launch parameters as the lane of this workgroup sees them; `logical` becomes the id inside
+// the lane's own grid of lane_nwg workgroups.  Everything behind this call is the single-sample kernel, unchanged: the
+// noise indices are relative to the lane's own tensors, so a lane computes bit for bit what a launch of its own would.
+__device__ __forceinline__ ContractParams lane_view(const ContractParams& q, int& logical) {
+  ContractParams p = q;
+  if (q.lanes > 1) {
+    uint32_t lane, loc;
+    fdivmod((uint32_t)logical, q.fd_lane_nwg, (uint32_t)q.lane_nwg, lane, loc);
+    logical = (int)loc;
+    const long long l = (long long)lane;
+    p.x = (const unsigned char*)q.x + l * q.lane_x;
+    p.out = (unsigned char*)q.out + l * q.lane_out;
+    if (q.ep_res) p.ep_res = (const unsigned char*)q.ep_res + l * q.lane_res;
+    if (q.wt) {
+      if (q.lane_wt_delta) p.wt_delta_off = q.wt_delta_off + (uint32_t)(l * q.lane_wt);
+      else p.wt = (unsigned char*)q.wt + l * q.lane_wt;
+    }
+    if (q.partial) p.partial = (float*)((unsigned char*)q.partial + l * q.lane_partial);
+    if (q.sample_ptr) p.sample_ptr = q.sample_ptr + lane;
+    p.sample = q.sample + lane;
+  }
+  return p;
+}
 
 // ---- the (sample index, sign keys) a launch actually uses --------------------------------------------------------
 // BtxRng.sample_idx_dev lets a captured hipGraph be replayed for successive MC samples: the index — and the Flipout
@@ -146,8 +191,8 @@ struct RngLive {
 template <int KIND>
 __device__ __forceinline__ RngLive rng_live(const ContractParams& p) {
   RngLive r = {p.sample, p.kin_a, p.kin_b, p.kout_a, p.kout_b};
-  if (p.sample_ptr) {
-    r.sample = __builtin_amdgcn_readfirstlane(*p.sample_ptr);
+  if (p.sample_ptr || p.lanes > 1) {  // lanes: the host's keys are those of lane 0
+    if (p.sample_ptr) r.sample = __builtin_amdgcn_readfirstlane(*p.sample_ptr);
     if constexpr (KIND == 1) {
       const uint32_t si = p.swap_signs ? 3u : 2u, so = p.swap_signs ? 2u : 3u;  // BTX_STREAM_SIGN_IN = 2, _OUT = 3
       const BtxPhilox4 ki = btx_philox4x32_10(0u, r.sample, p.layer, si, p.seed_lo, p.seed_hi);
@@ -268,7 +313,9 @@ __device__ __forceinline__ int ws_bit(int e) { return ((e & 1) ? 31 : 15) - (e >
 
 // =========================================================================================================
 template <int PREC, typename ACT, int KIND, bool GEN>
-__global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractParams p) {
+__global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractParams pk) {
+  int logical = xcd_logical();
+  const ContractParams p = lane_view(pk, logical);
   const RngLive rl = rng_live<KIND>(p);
   constexpr int G = (PREC == 1) ? 8 : 4;   // elements per granule
   constexpr int BK = NG * G;               // k per stage
@@ -285,12 +332,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void contract_kernel(const ContractPar
 
   // ---- workgroup -> (m-tile, n-tile, group, k-split), XCD-aware (block b runs on XCD b%8: give every XCD a
   //      contiguous chunk of logical ids so the n-tiles / k-splits that share an activation tile share an L2)
-  int logical;
-  {
-    const int nwg = gridDim.x, L = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
   const int inner = p.ntiles * p.groups * p.ksplits;
   const int mtile = logical / inner;
   int rem = logical - mtile * inner;

@@ -89,7 +89,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 #undef BTX_VM
 
 template <int PREC, int KIND, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const ContractParams p) {
+__global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const ContractParams pk) {
+  int logical = xcd_logical();
+  const ContractParams p = lane_view(pk, logical);
   using LD = DmaLds<NW>;
   constexpr int TP = LD::TP, WD = LD::WD, DA_STAGE = LD::A_STAGE, DS_STAGE = LD::S_STAGE, DA_OFF = LD::A_OFF,
                 DS_OFF = LD::S_OFF, DW_OFF = LD::W_OFF;
@@ -110,12 +112,6 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool upper = (NW == 8) ? (wave >= 4) : ((wave & 1) != 0);  // these waves issue their DMAs after the MFMA block
 
-  int logical;
-  {
-    const int nwg = gridDim.x, L = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
   uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
   if (p.wg_order) fdivmod((uint32_t)logical, p.fd_mtiles, (uint32_t)p.mtiles, u_rem, u_mtile);  // weight-major (btx_api.hip)
   else fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);

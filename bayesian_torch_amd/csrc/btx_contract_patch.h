@@ -44,7 +44,9 @@ namespace btx {
 // accumulators — the unified 512-entry register file of a single wave per SIMD; every weight fragment read from LDS
 // then feeds twice as many MFMAs).
 template <int PREC, int KIND, int NW, int MI>
-__global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_kernel(const ContractParams p) {
+__global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_kernel(const ContractParams pk) {
+  int logical = xcd_logical();
+  const ContractParams p = lane_view(pk, logical);
   const RngLive rl = rng_live<KIND>(p);
   constexpr int NT = 64 * NW;
   constexpr int WPX = 32 * MI;                      // pixels per wave
@@ -65,12 +67,6 @@ __global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_ker
   const uint32_t tr_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
   uint32_t tr_ab = 0, tr_bc = 0, tr_cd = 0, tr_t1 = 0, tr_t2 = 0;
 #endif
-  int logical;
-  {
-    const int nwg = gridDim.x, L = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
   uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
   if (p.wg_order) fdivmod((uint32_t)logical, p.fd_mtiles, (uint32_t)p.mtiles, u_rem, u_mtile);  // weight-major (btx_api.hip)
   else fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);

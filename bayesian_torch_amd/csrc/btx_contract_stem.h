@@ -25,7 +25,9 @@ namespace btx {
 // bytes), pt_astage (patch bytes rounded to 1 KiB), st_sbytes (bytes of the sign-word array), pt_nw, pt_lds.
 // Geometry as the C-ABI hands it over with BTX_FLAG_ROWFUSE: p.Cg = KW*C elements per kernel row, pad 0, groups 1.
 template <int PREC, int KIND, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void contract_stem_kernel(const ContractParams p) {
+__global__ __launch_bounds__(64 * NW, 2) void contract_stem_kernel(const ContractParams pk) {
+  int logical = xcd_logical();
+  const ContractParams p = lane_view(pk, logical);
   constexpr int NT = 64 * NW;
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
@@ -40,12 +42,6 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_stem_kernel(const Contrac
   const int h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  int logical;
-  {
-    const int nwg = gridDim.x, L = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
   uint32_t u_mtile, u_ntile, u_img, u_rt;
   fdivmod((uint32_t)logical, p.fd_ntiles, (uint32_t)p.ntiles, u_mtile, u_ntile);
   fdivmod(u_mtile, p.fd_rtiles, (uint32_t)p.pt_rtiles, u_img, u_rt);

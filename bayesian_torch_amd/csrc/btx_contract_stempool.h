@@ -94,7 +94,9 @@ __device__ __forceinline__ void sp_mma(const SpFrag& f, f32x16 (&acc)[2][2]) {
 // (patch slot bytes, 1-KiB multiple), st_sbytes (bytes of one sign-word slot, 128-byte multiple), sp_Hq / sp_Wq (pooled
 // extent).  Geometry as for contract_stem_kernel (BTX_FLAG_ROWFUSE).
 template <int KIND>
-__global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams p) {
+__global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams pk) {
+  int logical = xcd_logical();
+  const ContractParams p = lane_view(pk, logical);
   constexpr int G = 8, BK = NG * G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef BTX_PT_TRACE
@@ -115,12 +117,6 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
   const int grp = wave >> 2, w4 = wave & 3;
   int gtid = tid & 255;  // thread index inside the group
 
-  int logical;
-  {
-    const int nwg = gridDim.x, L = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
   uint32_t u_rest, u_ntile, u_img, u_band;
   fdivmod((uint32_t)logical, p.fd_ntiles, (uint32_t)p.ntiles, u_rest, u_ntile);
   fdivmod(u_rest, p.fd_rtiles, (uint32_t)p.pt_rtiles, u_img, u_band);

@@ -77,7 +77,9 @@ constexpr int tp_pieces(int t) {
 // fragments, H2: the MFMAs — with a barrier after each, and group 1 runs half a stage behind group 0 (one extra barrier
 // before its first stage, group 0 one after its last): one group's MFMA half sits beside the other's load half.
 template <int PREC, int KIND, int KH, int KW, int KG>
-__global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const ContractParams p) {
+__global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const ContractParams pk) {
+  int logical = xcd_logical();
+  const ContractParams p = lane_view(pk, logical);
   constexpr int NW = 4, NT = 256, MI = 2, T = KH * KW;
   static_assert(T >= 5 && T <= 32, "tap-unrolled kernel: 5..32 taps");
   constexpr int MAXNI = TP_MAXNI;
@@ -107,12 +109,6 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   const uint32_t tr_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // constant 100 MHz reference clock
   uint32_t tr_t1 = 0, tr_t2 = 0, tr_s[4] = {0, 0, 0, 0};
 #endif
-  int logical;
-  {
-    const int nwg = gridDim.x, L = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
   uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
   if (p.wg_order) fdivmod((uint32_t)logical, p.fd_mtiles, (uint32_t)p.mtiles, u_rem, u_mtile);  // weight-major (btx_api.hip)
   else fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
@@ -120,9 +116,30 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   fdivmod(u_t, p.fd_ntiles, (uint32_t)p.ntiles, u_group, u_ntile);
   const int mtile = (int)u_mtile, split = (int)u_split, ntile = (int)u_ntile, group = (int)u_group;
 
+  // tile origin.  Plain tiles: pt_G whole images or pt_R rows of one image, full width.  Tall strips (pt_tall): pt_R rows
+  // of the batch seen as one tall image of pt_P virtual rows per image, pt_Wt columns wide (ContractParams).
+  const bool tall = p.pt_tall != 0;
   uint32_t u_ig, u_rt;
-  fdivmod((uint32_t)mtile, p.fd_rtiles, (uint32_t)p.pt_rtiles, u_ig, u_rt);
-  const int img0 = (int)u_ig * p.pt_G, row0 = (int)u_rt * p.pt_R;
+  if (tall) fdivmod((uint32_t)mtile, p.fd_ncs, (uint32_t)p.pt_ncs, u_rt, u_ig);  // u_ig = column strip
+  else fdivmod((uint32_t)mtile, p.fd_rtiles, (uint32_t)p.pt_rtiles, u_ig, u_rt);
+  const int img0 = tall ? 0 : (int)u_ig * p.pt_G, row0 = (int)u_rt * p.pt_R, col0 = tall ? (int)u_ig * p.pt_Wt : 0;
+  // patch pixel q -> input pixel index (image, row, column flattened), or "outside" (conv padding, tile tail)
+  auto patch_src = [&](int q, bool& ok) __attribute__((always_inline)) -> uint32_t {
+    uint32_t ut, upc, ugi, upr;
+    fdivmod((uint32_t)q, p.fd_ptWp, (uint32_t)p.pt_Wp, ut, upc);
+    int img, ih, iw;
+    if (tall) {  // patch row ut = virtual input row row0 + ut: rows [0, ph) of every period are the zero rows
+      fdivmod((uint32_t)row0 + ut, p.fd_P, (uint32_t)p.pt_P, ugi, upr);
+      img = (int)ugi; ih = (int)upr - p.ph; iw = col0 + (int)upc - p.pw;
+      ok = (int)ut < p.pt_Rp;
+    } else {
+      fdivmod(ut, p.fd_ptRp, (uint32_t)p.pt_Rp, ugi, upr);
+      img = img0 + (int)ugi; ih = row0 + (int)upr - p.ph; iw = (int)upc - p.pw;
+      ok = true;
+    }
+    ok = ok && img < p.NB && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    return (uint32_t)((img * p.H + ih) * p.W + iw);
+  };
   const int ncb_total = p.Cg / BK;
   const int cb_per = p.kper / BK;  // channel blocks of this workgroup (host: a multiple of KG and every split full when KG > 1)
   const int cb0 = split * cb_per + kg * (cb_per / KG);
@@ -158,14 +175,9 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     const int q = 16 * (wave + NW * j) + (lane >> 2);
     uint32_t bo = DMA_OOB;
     if (j < p.pt_NI && q < p.pt_PP) {
-      uint32_t ut, upc, ugi, upr;
-      fdivmod((uint32_t)q, p.fd_ptWp, (uint32_t)p.pt_Wp, ut, upc);
-      fdivmod(ut, p.fd_ptRp, (uint32_t)p.pt_Rp, ugi, upr);
-      const int pc = (int)upc, pr = (int)upr, gi = (int)ugi;
-      const int img = img0 + gi, ih = row0 + pr - p.ph, iw = pc - p.pw;
-      if (img < p.NB && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-        bo = ((uint32_t)((img * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) *
-             (uint32_t)ESZ;
+      bool ok;
+      const uint32_t ipix = patch_src(q, ok);
+      if (ok) bo = (ipix * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) * (uint32_t)ESZ;
     }
     pp_boff[j] = bo;
     if (j < p.pt_NI && 16 * (wave + NW * j) < p.pt_PP) {
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
 
   // ---- the sign keys of this (sample, layer): needed by the sign words and by the epilogue
   RngLive rl = {smp, p.kin_a, p.kin_b, p.kout_a, p.kout_b};
-  if (p.sample_ptr) {
+  if (p.sample_ptr || p.lanes > 1) {  // lanes: the host's keys are those of lane 0
     rl.sample = __builtin_amdgcn_readfirstlane(smp);
     if constexpr (KIND == 1) {
       const uint32_t si = p.swap_signs ? 3u : 2u, so = p.swap_signs ? 2u : 3u;  // BTX_STREAM_SIGN_IN = 2, _OUT = 3
@@ -200,15 +212,11 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   for (int j = 0; j < 2; ++j) {
     const int q = tid + NT * j;
     sg_ok[j] = q < p.pt_PP;
-    const int qq = sg_ok[j] ? q : 0;
-    uint32_t ut, upc, ugi, upr;
-    fdivmod((uint32_t)qq, p.fd_ptWp, (uint32_t)p.pt_Wp, ut, upc);
-    fdivmod(ut, p.fd_ptRp, (uint32_t)p.pt_Rp, ugi, upr);
-    const int pc = (int)upc, pr = (int)upr, gi = (int)ugi;
-    const int img = img0 + gi, ih = row0 + pr - p.ph, iw = pc - p.pw;
-    sg_off[j] = (uint32_t)((img * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+    bool inside;
+    const uint32_t ipix = patch_src(sg_ok[j] ? q : 0, inside);
+    sg_off[j] = ipix * (uint32_t)p.C + (uint32_t)(group * p.Cg);  // outside pixels hold zeros: any word will do
     if (p.sign_in)  // explicit signs (parity mode) are read from memory: only pixels inside the input exist
-      sg_ok[j] = sg_ok[j] && img < p.NB && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      sg_ok[j] = sg_ok[j] && inside;
   }
   auto write_signs = [&](int slot, int cb) __attribute__((always_inline)) {
     if constexpr (KIND == 1) {
@@ -233,11 +241,16 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   for (int mi = 0; mi < MI; ++mi) {
     const int pl = wave * 64 + mi * 32 + l31;
     uint32_t ut, uc, ugi, ur;
-    fdivmod((uint32_t)pl, p.fd_Wo, (uint32_t)p.Wo, ut, uc);
-    fdivmod(ut, p.fd_ptR, (uint32_t)p.pt_R, ugi, ur);
-    const int c = (int)uc, r = (int)ur, gi = (int)ugi;
-    const bool ok = (gi < p.pt_G) && (img0 + gi < p.NB) && (row0 + r < p.Ho);
-    q0[mi] = ok ? (gi * p.pt_Rp + r) * p.pt_Wp + c : 0;
+    if (tall) {  // pixels that do not exist (dummy rows, tile tail) multiply whatever the patch holds there: never stored
+      fdivmod((uint32_t)pl, p.fd_Wt, (uint32_t)p.pt_Wt, ur, uc);
+      q0[mi] = ((int)ur < p.pt_R) ? (int)ur * p.pt_Wp + (int)uc : 0;
+    } else {
+      fdivmod((uint32_t)pl, p.fd_Wo, (uint32_t)p.Wo, ut, uc);
+      fdivmod(ut, p.fd_ptR, (uint32_t)p.pt_R, ugi, ur);
+      const int c = (int)uc, r = (int)ur, gi = (int)ugi;
+      const bool ok = (gi < p.pt_G) && (img0 + gi < p.NB) && (row0 + r < p.Ho);
+      q0[mi] = ok ? (gi * p.pt_Rp + r) * p.pt_Wp + c : 0;
+    }
   }
   const int row_step = p.dh * p.pt_Wp;  // patch-pixel offset of tap (kh, kw) = kh*row_step + kw*dw (wave-uniform)
 
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     // The wave's second 32-pixel tile may be pure tile padding (224-pixel tiles: 4 rows of 56, wave 3; 196-pixel tiles:
     // wave 3 as well): its MFMAs, fragment reads and sign masks are skipped — an eighth of the block's matrix work.  The
     // choice is wave-uniform, so the K loop exists in two instantiations and every wave still meets every barrier.
-    const int nvalid_px = min(p.pt_G, p.NB - img0) * min(p.pt_R, p.Ho - row0) * p.Wo;
+    const int nvalid_px = tall ? p.pt_R * p.pt_Wt : min(p.pt_G, p.NB - img0) * min(p.pt_R, p.Ho - row0) * p.Wo;
     const bool mi1_dead = wave * 64 + 32 >= nvalid_px;
     auto kloop = [&](auto mia_tag) __attribute__((always_inline)) {
     constexpr int MIA = decltype(mia_tag)::value;
@@ -398,8 +411,10 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
     const int nvalid = nimg * nrow * p.Wo;
     const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
+    const PixTall pmt = {p, row0, col0};
     if constexpr (KG == 1) {
-      staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+      if (tall) staged_epilogue_pm<KIND, NW, PixTall>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pmt);
+      else staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
     } else {
       // Every wave is behind the barrier of its last stage: the whole LDS is free.  Group 1 -> exchange area
       // [chunk i][thread] x 16 B (a wave writes 1 KiB per instruction; 128 KiB Flipout, 64 KiB Reparameterization),
@@ -446,9 +461,12 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
             }
       }
       __syncthreads();  // the staging area of the store overlaps the exchange area
-      if (kg == 0)
-        staged_epilogue<KIND, NW>(p, rl, accm, accd, smem_all, tid, wave, lane, ntile, group, split, m0, nvalid, nullptr,
-                                  -1, true, ba_lds);
+      if (kg == 0) {
+        if (tall) staged_epilogue_pm<KIND, NW, PixTall>(p, rl, accm, accd, smem_all, tid, wave, lane, ntile, group, split, pmt,
+                                                        nullptr, -1, true, ba_lds);
+        else staged_epilogue<KIND, NW>(p, rl, accm, accd, smem_all, tid, wave, lane, ntile, group, split, m0, nvalid, nullptr,
+                                       -1, true, ba_lds);
+      }
     }
   }
 #ifdef BTX_PT_TRACE

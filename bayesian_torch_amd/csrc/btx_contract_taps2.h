@@ -45,7 +45,9 @@ constexpr int t2_p0(int s) { return (s == 1 || s == 6 || s == 8) ? 3 : 0; }     
 constexpr int t2_fseq(int s) { return s < 2 ? 2 : (s == 4 ? 3 : (s < 7 ? 4 : 5)); }  // plane it belongs to (4, 5: next block)
 
 template <int PREC, int KIND>
-__global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractParams p) {
+__global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractParams pk) {
+  int logical = xcd_logical();
+  const ContractParams p = lane_view(pk, logical);
   constexpr int NW = 4, NT = 256, MI = 2, T = T2_T, MAXNI = T2_MAXNI, WD = T2_WD;
   constexpr int WOPS = (KIND == 1) ? 2 : 1;  // weight DMA instructions per wave per stage
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
@@ -63,12 +65,6 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
   const int h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  int logical;
-  {
-    const int nwg = gridDim.x, L = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, slot = L >> 3;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
   uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
   if (p.wg_order) fdivmod((uint32_t)logical, p.fd_mtiles, (uint32_t)p.mtiles, u_rem, u_mtile);
   else fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
@@ -149,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
 
   // ---- sign keys
   RngLive rl = {smp, p.kin_a, p.kin_b, p.kout_a, p.kout_b};
-  if (p.sample_ptr) {
+  if (p.sample_ptr || p.lanes > 1) {  // lanes: the host's keys are those of lane 0
     rl.sample = __builtin_amdgcn_readfirstlane(smp);
     if constexpr (KIND == 1) {
       const uint32_t si = p.swap_signs ? 3u : 2u, so = p.swap_signs ? 2u : 3u;  // BTX_STREAM_SIGN_IN = 2, _OUT = 3

@@ -16,68 +16,6 @@
 
 namespace btx {
 
-// store 8 consecutive channels of one output pixel (stage 2); OUTK: 0 = f32 split-K partial, 1 = bf16 out, 2 = f32 out
-template <int OUTK, bool RES, bool RELU>
-__device__ __forceinline__ void ep_store8(const ContractParams& p, const f32x4 lo, const f32x4 hi, uint32_t idx,
-                                          int split, int nv, bool vec) {
-  float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  if constexpr (OUTK == 0) {
-    float* dst = p.partial + (size_t)split * p.M * p.N + idx;
-    if (vec) {
-      *(f32x4*)dst = lo;
-      *(f32x4*)(dst + 4) = hi;
-    } else {
-      for (int j = 0; j < nv; ++j) dst[j] = v[j];
-    }
-  } else if constexpr (OUTK == 1) {
-    __bf16* dst = (__bf16*)p.out + idx;
-    const __bf16* res = RES ? (const __bf16*)p.ep_res + idx : nullptr;
-    if (vec) {
-      if constexpr (RES) {
-        const u32x4 rv = *(const u32x4*)res;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[2 * j] += u2f(rv[j] << 16); v[2 * j + 1] += u2f(rv[j] & 0xffff0000u); }
-      }
-      if constexpr (RELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-      }
-      const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
-      const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(x0, bf16x4));
-      const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(x1, bf16x4));
-      *(u32x4*)dst = (u32x4){p0[0], p0[1], p1[0], p1[1]};
-    } else {
-      for (int j = 0; j < nv; ++j) {
-        float y = v[j] + (RES ? (float)res[j] : 0.f);
-        if (RELU) y = fmaxf(y, 0.f);
-        dst[j] = (__bf16)y;
-      }
-    }
-  } else {
-    float* dst = (float*)p.out + idx;
-    const float* res = RES ? (const float*)p.ep_res + idx : nullptr;
-    if (vec) {
-      if constexpr (RES) {
-        const f32x4 r0 = *(const f32x4*)res, r1 = *(const f32x4*)(res + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
-      }
-      if constexpr (RELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-      }
-      *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-      *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-    } else {
-      for (int j = 0; j < nv; ++j) {
-        float y = v[j] + (RES ? res[j] : 0.f);
-        if (RELU) y = fmaxf(y, 0.f);
-        dst[j] = y;
-      }
-    }
-  }
-}
-
 // per-channel constants of the tile in LDS: [bias_mean | bias_delta | scale | shift] x 64 (identity where absent);
 // written by threads t = 0..63 of the caller, who also provides the barrier before they are read
 template <int KIND>
@@ -101,12 +39,64 @@ __device__ __forceinline__ void ep_fill_constants(const ContractParams& p, const
   }
 }
 
-template <int KIND, int NW>
-__device__ __forceinline__ void staged_epilogue(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
-                                                const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int wave,
-                                                int lane, int ntile, int group, int split, uint32_t m0, int nvalid,
-                                                uint32_t* ep_t = nullptr, int pwave = -1, bool first = true,
-                                                float* ba_ext = nullptr) {
+// Tile pixel -> output pixel.  The default: the tile's pixels are consecutive output pixels from m0 on, the first `nvalid`
+// exist.  The tall-strip tiles of btx_contract_taps.h bring their own map (rows of a column strip, dummy rows between
+// images).
+struct PixContig {
+  uint32_t m0;
+  int nvalid;
+  __device__ __forceinline__ uint32_t operator()(int pl, bool& ok) const { ok = pl < nvalid; return m0 + (uint32_t)pl; }
+  __device__ __forceinline__ uint32_t first() const { return m0; }
+  // walk over tile pixels pl, pl + 8, pl + 16, ... (stage 2 of the store)
+  struct Walk {
+    uint32_t g; int pl, nvalid;
+    __device__ __forceinline__ uint32_t get(bool& ok) const { ok = pl < nvalid; return g; }
+    __device__ __forceinline__ void step8() { g += 8u; pl += 8; }
+  };
+  __device__ __forceinline__ Walk walk(int pl) const { return Walk{m0 + (uint32_t)pl, pl, nvalid}; }
+};
+struct PixTall {  // tile = pt_R virtual rows from row0 x pt_Wt columns from col0; virtual row k = image k / pt_P, row k % pt_P
+  const ContractParams& p;
+  int row0, col0;
+  __device__ __forceinline__ uint32_t operator()(int pl, bool& ok) const {
+    uint32_t r, c, img, oh;
+    fdivmod((uint32_t)pl, p.fd_Wt, (uint32_t)p.pt_Wt, r, c);
+    fdivmod((uint32_t)row0 + r, p.fd_P, (uint32_t)p.pt_P, img, oh);
+    const int ow = col0 + (int)c;
+    ok = (int)r < p.pt_R && (int)oh < p.Ho && (int)img < p.NB && ow < p.Wo;
+    return ok ? ((img * (uint32_t)p.Ho + oh) * (uint32_t)p.Wo + (uint32_t)ow) : 0u;
+  }
+  __device__ __forceinline__ uint32_t first() const { return 0u; }
+  // the same map, stepped 8 pixels at a time without divisions (pt_Wt >= 4: at most two row wraps per step)
+  struct Walk {
+    const ContractParams& p;
+    int r, c, oh, img, col0;
+    __device__ __forceinline__ uint32_t get(bool& ok) const {
+      const int ow = col0 + c;
+      ok = r < p.pt_R && oh < p.Ho && img < p.NB && ow < p.Wo;
+      return ok ? (uint32_t)((img * p.Ho + oh) * p.Wo + ow) : 0u;
+    }
+    __device__ __forceinline__ void step8() {
+      c += 8;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (c >= p.pt_Wt) { c -= p.pt_Wt; ++r; if (++oh >= p.pt_P) { oh -= p.pt_P; ++img; } }
+    }
+  };
+  __device__ __forceinline__ Walk walk(int pl) const {
+    uint32_t r, c, img, oh;
+    fdivmod((uint32_t)pl, p.fd_Wt, (uint32_t)p.pt_Wt, r, c);
+    fdivmod((uint32_t)row0 + r, p.fd_P, (uint32_t)p.pt_P, img, oh);
+    return Walk{p, (int)r, (int)c, (int)oh, (int)img, col0};
+  }
+};
+
+template <int KIND, int NW, class PM = PixContig>
+__device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
+                                                   const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int wave,
+                                                   int lane, int ntile, int group, int split, const PM& pm,
+                                                   uint32_t* ep_t = nullptr, int pwave = -1, bool first = true,
+                                                   float* ba_ext = nullptr) {
   // pwave: index of the 64-pixel group of the tile these fragments hold (default: the wave index); `wave` selects the
   // wave-private staging area.  first == false: the per-channel constants are already in LDS (second half of a wave
   // that owns 128 pixels).  ba_ext: the constants were written (and a barrier passed) by the caller, at this address.
@@ -132,11 +122,15 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
                     (KIND == 0 || (!p.sign_out && (p.N & 31) == 0 && ((group * p.Ng) & 31) == 0));
   if (fast) {
     uint32_t wsh[2][2];
+    // dl ^ (w & sign bit) as ONE v_bitop3 per value (the compiler's own selection is v_and + v_xor: 256 of the ~580
+    // instructions of this stage); the constant lives in an SGPR — a 32-bit literal does not fit the VOP3 encoding
+    uint32_t SB = 0x80000000u;
+    asm volatile("" : "+s"(SB));
     if constexpr (KIND == 1) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        const int pl_ = min(pwave * 64 + mi * 32 + l31, max(nvalid - 1, 0));
-        const uint32_t orow = (m0 + (uint32_t)pl_) * (uint32_t)p.N + (uint32_t)(group * p.Ng + ntile * BN);
+        bool pok;  // a pixel that does not exist hashes some word: its values are never stored
+        const uint32_t orow = pm(pwave * 64 + mi * 32 + l31, pok) * (uint32_t)p.N + (uint32_t)(group * p.Ng + ntile * BN);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
           wsh[mi][ni] = btx_sign_word((orow + 32u * ni) >> 5, rl.kout_a, rl.kout_b) << (2 * h);
@@ -169,7 +163,7 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
                 // element e = 8q + 4h + rr of the word sits at bit ((e&1) ? 31 : 15) - (e>>1); wsh is pre-shifted by 2h
                 constexpr int dummy = 0;
                 const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1)) + dummy;
-                val += u2f(f2u(dl) ^ ((wsh[mi][ni] << sft) & 0x80000000u));
+                val += u2f(__builtin_amdgcn_bitop3_b32(f2u(dl), wsh[mi][ni] << sft, SB, 0x78));  // dl ^ (w & SB)
               }
               if constexpr (BA) val = __builtin_fmaf(val, sc[rr], sh[rr]);
               v[rr] = val;
@@ -183,9 +177,9 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
     // generic path: ragged channel tiles, unaligned s_out words, explicit sign arrays (parity mode)
 #pragma unroll 1
     for (int mi = 0; mi < 2; ++mi) {
-      const int pl_ = pwave * 64 + mi * 32 + l31;
-      const bool pix_ok = pl_ < nvalid;
-      const uint32_t orow = (m0 + (uint32_t)(pix_ok ? pl_ : 0)) * (uint32_t)p.N + (uint32_t)(group * p.Ng);
+      bool pix_ok;
+      const uint32_t gp_ = pm(pwave * 64 + mi * 32 + l31, pix_ok);
+      const uint32_t orow = (pix_ok ? gp_ : pm.first()) * (uint32_t)p.N + (uint32_t)(group * p.Ng);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -225,45 +219,135 @@ __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const R
   if (ep_t) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ep_t[0] = (uint32_t)__builtin_amdgcn_s_memtime(); }
 #endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area is private to the wave
+  __builtin_amdgcn_sched_barrier(0);  // nothing of stage 2 (index arithmetic) above this line: the accumulators are dead only now
 
-  // ---- stage 2: LDS -> global, 8 lanes per pixel, whole 128-byte lines per instruction.  The output mode is uniform:
-  // one specialised loop per mode.  Element offsets fit 32 bits (host: M*N < 2^31).
+  // ---- stage 2: LDS -> global, 8 lanes per pixel, whole 128-byte lines per instruction.  Element offsets fit 32 bits
+  // (host: M*N < 2^31).
   {
     const int cg = lane & 7;
     const int col0 = ntile * BN + cg * 8;
     const int nv = min(8, p.Ng - col0);
-    const bool vec_ok = ((p.N & 7) == 0) && (((group * p.Ng) & 7) == 0) && (nv == 8);
     const uint32_t cbase = (uint32_t)(group * p.Ng + col0);
-    auto run = [&](auto outk_tag, auto res_tag, auto relu_tag) __attribute__((always_inline)) {
+    // the whole 64-channel tile exists and 8-channel runs are 16-byte aligned (wave-uniform): no per-lane tails
+    const bool all_vec = ((p.N & 7) == 0) && (((group * p.Ng) & 7) == 0) && (ntile * BN + BN <= p.Ng);
+    const bool res = !to_partial && p.ep_res != nullptr, relu = !to_partial && p.ep_relu;
+    // Straight-line form, one per output mode (uniform): the 8 residual loads of the lane go out first (a pixel that does
+    // not exist reads the tile's first pixel instead: no branch in front of a load), then the 16 LDS reads, then the
+    // arithmetic and the 8 predicated stores.  (A loop that handles one pixel per iteration waits for each residual load
+    // before the next LDS read: eight dependent L2 round trips per wave — measured 4.8k -> cycles of the store side.)
+    auto fast = [&](auto outk_tag, auto res_tag, auto relu_tag) __attribute__((always_inline)) {
       constexpr int OUTK = decltype(outk_tag)::value;
       constexpr bool RES = decltype(res_tag)::value, RELU = decltype(relu_tag)::value;
+      auto wk = pm.walk(pwave * 64 + (lane >> 3));
 #pragma unroll
-      for (int r8 = 0; r8 < 8; ++r8) {
-        const int pix = r8 * 8 + (lane >> 3);
-        const int pl = pwave * 64 + pix;
-        if (pl < nvalid && nv > 0) {
-          const f32x4 lo = *(const f32x4*)(ep + pix * EP_ROW + cg * 32);
-          const f32x4 hi = *(const f32x4*)(ep + pix * EP_ROW + cg * 32 + 16);
-          const uint32_t idx = (m0 + (uint32_t)pl) * (uint32_t)p.N + cbase;
-          ep_store8<OUTK, RES, RELU>(p, lo, hi, idx, split, nv, vec_ok);
+      for (int hf = 0; hf < 2; ++hf) {  // two rounds of four pixels: half the registers, still four loads in flight
+        uint32_t idx[4];
+        bool pk[4];
+        u32x4 r0[4], r1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t gp = wk.get(pk[i]);
+          wk.step8();
+          idx[i] = gp * (uint32_t)p.N + cbase;
+          if constexpr (RES) {
+            const uint32_t li = pk[i] ? idx[i] : cbase + pm.first() * (uint32_t)p.N;
+            if constexpr (OUTK == 1) r0[i] = *(const u32x4*)((const __bf16*)p.ep_res + li);
+            else { r0[i] = *(const u32x4*)((const float*)p.ep_res + li); r1[i] = *(const u32x4*)((const float*)p.ep_res + li + 4); }
+          }
+        }
+        f32x4 lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int pix = (hf * 4 + i) * 8 + (lane >> 3);
+          lo[i] = *(const f32x4*)(ep + pix * EP_ROW + cg * 32);
+          hi[i] = *(const f32x4*)(ep + pix * EP_ROW + cg * 32 + 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v[8] = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
+          if constexpr (RES) {
+            if constexpr (OUTK == 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[2 * j] += u2f(r0[i][j] << 16); v[2 * j + 1] += u2f(r0[i][j] & 0xffff0000u); }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[j] += u2f(r0[i][j]); v[4 + j] += u2f(r1[i][j]); }
+            }
+          }
+          if constexpr (RELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (pk[i]) {
+            if constexpr (OUTK == 0) {
+              float* dst = p.partial + (size_t)split * p.M * p.N + idx[i];
+              *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+              *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            } else if constexpr (OUTK == 1) {
+              const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+              const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(x0, bf16x4));
+              const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(x1, bf16x4));
+              *(u32x4*)((__bf16*)p.out + idx[i]) = (u32x4){p0[0], p0[1], p1[0], p1[1]};
+            } else {
+              float* dst = (float*)p.out + idx[i];
+              *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+              *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            }
+          }
         }
       }
     };
     using T = std::true_type;
     using F = std::false_type;
-    const bool res = !to_partial && p.ep_res != nullptr, relu = !to_partial && p.ep_relu;
-    if (to_partial) run(std::integral_constant<int, 0>{}, F{}, F{});
-    else if (p.out_bf16) {
-      if (res) { if (relu) run(std::integral_constant<int, 1>{}, T{}, T{}); else run(std::integral_constant<int, 1>{}, T{}, F{}); }
-      else { if (relu) run(std::integral_constant<int, 1>{}, F{}, T{}); else run(std::integral_constant<int, 1>{}, F{}, F{}); }
+    if (all_vec) {
+      if (to_partial) fast(std::integral_constant<int, 0>{}, F{}, F{});
+      else if (p.out_bf16) {
+        if (res) { if (relu) fast(std::integral_constant<int, 1>{}, T{}, T{}); else fast(std::integral_constant<int, 1>{}, T{}, F{}); }
+        else { if (relu) fast(std::integral_constant<int, 1>{}, F{}, T{}); else fast(std::integral_constant<int, 1>{}, F{}, F{}); }
+      } else {
+        if (res) { if (relu) fast(std::integral_constant<int, 2>{}, T{}, T{}); else fast(std::integral_constant<int, 2>{}, T{}, F{}); }
+        else { if (relu) fast(std::integral_constant<int, 2>{}, F{}, T{}); else fast(std::integral_constant<int, 2>{}, F{}, F{}); }
+      }
     } else {
-      if (res) { if (relu) run(std::integral_constant<int, 2>{}, T{}, T{}); else run(std::integral_constant<int, 2>{}, T{}, F{}); }
-      else { if (relu) run(std::integral_constant<int, 2>{}, F{}, T{}); else run(std::integral_constant<int, 2>{}, F{}, F{}); }
+      // ragged channel tiles / unaligned runs: one loop with run-time modes, element by element (rare shapes)
+      auto wk = pm.walk(pwave * 64 + (lane >> 3));
+#pragma unroll 1
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int pix = r8 * 8 + (lane >> 3);
+        bool pok;
+        const uint32_t gp = wk.get(pok);
+        wk.step8();
+        if (pok && nv > 0) {
+          const uint32_t idx = gp * (uint32_t)p.N + cbase;
+          const float* row = (const float*)(ep + pix * EP_ROW + cg * 32);
+#pragma unroll 1
+          for (int j = 0; j < nv; ++j) {
+            float y = row[j];
+            if (to_partial) { p.partial[(size_t)split * p.M * p.N + idx + j] = y; continue; }
+            if (res) y += p.out_bf16 ? (float)((const __bf16*)p.ep_res)[idx + j] : ((const float*)p.ep_res)[idx + j];
+            if (relu) y = fmaxf(y, 0.f);
+            if (p.out_bf16) ((__bf16*)p.out)[idx + j] = (__bf16)y;
+            else ((float*)p.out)[idx + j] = y;
+          }
+        }
+      }
     }
   }
 #ifdef BTX_EP_TRACE
   if (ep_t) { __builtin_amdgcn_sched_barrier(0); ep_t[1] = (uint32_t)__builtin_amdgcn_s_memtime(); }
 #endif
+}
+
+// the contiguous-tile form every other kernel uses
+template <int KIND, int NW>
+__device__ __forceinline__ void staged_epilogue(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
+                                                const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int wave,
+                                                int lane, int ntile, int group, int split, uint32_t m0, int nvalid,
+                                                uint32_t* ep_t = nullptr, int pwave = -1, bool first = true,
+                                                float* ba_ext = nullptr) {
+  const PixContig pm = {m0, nvalid};
+  staged_epilogue_pm<KIND, NW, PixContig>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pm, ep_t, pwave,
+                                          first, ba_ext);
 }
 
 }  // namespace btx

@@ -20,7 +20,11 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
                                                unsigned char* __restrict__ wt, uint32_t delta_off, int Ng, int K,
                                                int ntiles, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
                                                uint32_t sample, uint32_t layer, int Cp = 0, int KWp = 0, int src_KW = 0,
-                                               int src_C = 0, const float* __restrict__ eps_w = nullptr) {
+                                               int src_C = 0, const float* __restrict__ eps_w = nullptr,
+                                               bool write_mu = true, float* __restrict__ sig = nullptr) {
+  // sig (btx_sample_weights_lanes): sigma = softplus(rho) of every weight in tile order, f32.  write_mu: this call
+  // computes sigma from rho and stores it beside the mean tiles; !write_mu (BTX_SAMPLE_SKIP_MU): mu is not needed and
+  // sigma is READ from there — per MC sample the pre-pass is one load, Philox + Box-Muller, one multiply, one store.
   constexpr int G = (PREC == 1) ? 8 : 4;
   // t enumerates the OUTPUT image linearly — (tile, k-granule, channel, quad of the granule), quad fastest — so a wave
   // writes 512 (bf16) / 1024 (f32) contiguous bytes; its reads are 32-byte (bf16) / 16-byte runs, one per channel
@@ -32,7 +36,19 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
   const int group = (int)tile / ntiles, ntile = (int)tile - group * ntiles;
   const int col = ntile * BN + (int)ch;
   float wm[4] = {0.f, 0.f, 0.f, 0.f}, wd[4] = {0.f, 0.f, 0.f, 0.f};
-  if (col < Ng) {
+  const uint32_t kg_ = (4u * quad) / G;
+  const uint32_t o_ = (((uint32_t)tile * ((uint32_t)K / G) + kg_) * 64u + (uint32_t)ch) * 16u;
+  const uint32_t so_ = (PREC == 1) ? (o_ + (quad & 1u) * 8u) * 2u : o_;  // byte offset of this quad's f32 sigmas
+  float sg4[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool cached = (sig != nullptr) && !write_mu && (kind == 1);
+  if (col < Ng && cached) {
+    const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
+    const f32x4 s4 = *(const f32x4*)((const unsigned char*)sig + so_);
+    float eps[4];
+    btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wd[e] = s4[e] * eps[e];
+  } else if (col < Ng) {
     const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
     f32x4 mu4, rho4;
     if (Cp == 0) {
@@ -62,18 +78,19 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float sg = btx_softplus_hw(rho4[e]);
+      sg4[e] = sg;
       if (kind == 0) wm[e] = __builtin_fmaf(sg, eps[e], mu4[e]);
       else { wm[e] = mu4[e]; wd[e] = sg * eps[e]; }
     }
   }
-  const uint32_t kg = (4u * quad) / G;
-  const uint32_t o = (((uint32_t)tile * ((uint32_t)K / G) + kg) * 64u + (uint32_t)ch) * 16u;
+  if (sig != nullptr && write_mu && kind == 1) *(f32x4*)((unsigned char*)sig + so_) = (f32x4){sg4[0], sg4[1], sg4[2], sg4[3]};
+  const uint32_t o = o_;
   if constexpr (PREC == 1) {
     const uint32_t oo = o + (quad & 1u) * 8u;
-    *(u32x2*)(wt + oo) = pack_quad_bf16(wm);
+    if (write_mu) *(u32x2*)(wt + oo) = pack_quad_bf16(wm);
     if (kind == 1) *(u32x2*)(wt + delta_off + oo) = pack_quad_bf16(wd);
   } else {
-    *(u32x4*)(wt + o) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
+    if (write_mu) *(u32x4*)(wt + o) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
     if (kind == 1) *(u32x4*)(wt + delta_off + o) = (u32x4){f2u(wd[0]), f2u(wd[1]), f2u(wd[2]), f2u(wd[3])};
   }
 }
@@ -84,11 +101,11 @@ __global__ __launch_bounds__(256) void presample_kernel(const float* __restrict_
                                                         int K, int ntiles, uint32_t nquads_total, uint32_t seed_lo,
                                                         uint32_t seed_hi, uint32_t sample, uint32_t layer,
                                                         const uint32_t* __restrict__ sample_ptr,
-                                                        const float* __restrict__ eps_w) {
+                                                        const float* __restrict__ eps_w, int write_mu) {
   if (sample_ptr) sample = __builtin_amdgcn_readfirstlane(*sample_ptr);
   for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < nquads_total; t += gridDim.x * 256u)
     presample_quad<PREC>(KIND, mu, rho, wt, delta_off, Ng, K, ntiles, t, seed_lo, seed_hi, sample, layer, 0, 0, 0, 0,
-                         eps_w);
+                         eps_w, write_mu != 0);
 }
 
 // Batched form (btx_sample_weights): the weights of up to PRESAMPLE_MAX_ITEMS layers in ONE launch — a model's
@@ -107,18 +124,35 @@ struct PresampleBatch {
   int n;
   uint32_t seed_lo, seed_hi, sample, total_blocks;
   const uint32_t* sample_ptr;
+  // MC sample lanes: the grid is `lanes` copies of the item grid; lane l samples for index sample + l (sample_ptr[l]) into
+  // the lane's tiles — Flipout: delta tiles at delta_off * (1 + l), the shared mu tiles written by lane 0 (never when
+  // skip_mu: they are current); Reparameterization: W tiles at delta_off * l
+  int lanes, skip_mu;
 };
 template <int PREC>
 __global__ __launch_bounds__(256) void presample_batch_kernel(const PresampleBatch b) {
+  const uint32_t lane = blockIdx.x / b.total_blocks, blk = blockIdx.x - lane * b.total_blocks;
   int i = 0;
   for (int j = 1; j < b.n; ++j)
-    if (blockIdx.x >= b.it[j].first_block) i = j;
+    if (blk >= b.it[j].first_block) i = j;
   const PresampleItem& it = b.it[i];
-  const uint32_t sample = b.sample_ptr ? __builtin_amdgcn_readfirstlane(*b.sample_ptr) : b.sample;
+  const uint32_t sample = b.sample_ptr ? __builtin_amdgcn_readfirstlane(b.sample_ptr[lane]) : b.sample + lane;
   const uint32_t nblk = (i + 1 < b.n ? b.it[i + 1].first_block : b.total_blocks) - it.first_block;
-  for (uint32_t t = (blockIdx.x - it.first_block) * 256u + threadIdx.x; t < it.nquads; t += nblk * 256u)
-    presample_quad<PREC>(it.kind, it.mu, it.rho, it.wt, it.delta_off, it.Ng, it.K, it.ntiles, t, b.seed_lo, b.seed_hi,
-                         sample, it.layer, it.Cp, it.KWp, it.src_KW, it.src_C);
+  unsigned char* wt = it.wt;
+  uint32_t doff = it.delta_off;
+  bool write_mu = true;
+  float* sig = nullptr;
+  if (it.kind == 1) {
+    doff = it.delta_off * (1u + lane);
+    // the sigma cache sits behind the lanes' delta tiles.  Without skip_mu lane 0 writes it (and the mean tiles) while
+    // the other lanes, which may run before lane 0 has, take sigma from rho themselves.
+    sig = (float*)(it.wt + (size_t)it.delta_off * (size_t)(1 + b.lanes));
+    write_mu = (lane == 0) && !b.skip_mu;
+    if (!b.skip_mu && lane != 0) sig = nullptr;
+  } else wt += (size_t)it.delta_off * lane;
+  for (uint32_t t = (blk - it.first_block) * 256u + threadIdx.x; t < it.nquads; t += nblk * 256u)
+    presample_quad<PREC>(it.kind, it.mu, it.rho, wt, doff, it.Ng, it.K, it.ntiles, t, b.seed_lo, b.seed_hi,
+                         sample, it.layer, it.Cp, it.KWp, it.src_KW, it.src_C, nullptr, write_mu, sig);
 }
 
 template <int PREC>
@@ -127,12 +161,18 @@ static int launch_presample_impl(int kind, const ContractParams& p, hipStream_t 
   const uint32_t nq = (uint32_t)(p.groups * p.ntiles * 64) * ((uint32_t)p.K >> 2);
   uint32_t blocks = (nq + 255u) / 256u;
   if (blocks > 4096u) blocks = 4096u;
-  if (kind == 0)
-    hipLaunchKernelGGL((presample_kernel<PREC, 0>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
-                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer, p.sample_ptr, p.eps_w);
-  else
-    hipLaunchKernelGGL((presample_kernel<PREC, 1>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
-                       p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo, p.seed_hi, p.sample, p.layer, p.sample_ptr, p.eps_w);
+  const int lanes = p.lanes > 1 ? p.lanes : 1;
+  for (int l = 0; l < lanes; ++l) {  // one pre-pass per MC sample lane (callers that care sample ahead: btx_sample_weights)
+    const uint32_t* sp = p.sample_ptr ? p.sample_ptr + l : nullptr;
+    if (kind == 0)
+      hipLaunchKernelGGL((presample_kernel<PREC, 0>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho,
+                         (unsigned char*)p.wt + (size_t)l * (size_t)p.lane_wt, p.wt_delta_off, p.Ng, p.K, p.ntiles, nq, p.seed_lo,
+                         p.seed_hi, p.sample + (uint32_t)l, p.layer, sp, p.eps_w, 1);
+    else
+      hipLaunchKernelGGL((presample_kernel<PREC, 1>), dim3(blocks), dim3(256), 0, st, p.mu, p.rho, (unsigned char*)p.wt,
+                         p.wt_delta_off + (uint32_t)((size_t)l * (size_t)p.lane_wt), p.Ng, p.K, p.ntiles, nq, p.seed_lo,
+                         p.seed_hi, p.sample + (uint32_t)l, p.layer, sp, p.eps_w, l == 0 ? 1 : 0);
+  }
   return (int)hipGetLastError();
 }
 

@@ -231,11 +231,14 @@ def _weight_geom(op):
     return g
 
 
-def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None):
-    """btx_sample_weights: ONE launch samples the weights of every layer in `items` for MC sample `sample_idx`.
+def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None, lanes=1, bufs=None, skip_mu=False):
+    """btx_sample_weights[_lanes]: ONE launch samples the weights of every layer in `items` for MC sample `sample_idx`
+    (lanes > 1: for the samples sample_idx .. sample_idx + lanes - 1, or the `lanes` indices in `sample_dev`).
     items = [(kind, op, mu_p, rho_p, layer_id[, src_kw, src_c])] with GEMM-major f32 mu/rho as handed to contract_hip —
     or, with (src_kw, src_c), the UNPADDED weights of the padded geometry `op` (BtxSampleItem.src_KW/src_C); returns
-    the list of uint8 tile buffers, to be passed as contract_hip(..., sampled_w=buf)."""
+    the list of uint8 tile buffers, to be passed as contract_hip(..., sampled_w=buf).  `bufs`: buffers of an earlier
+    call with the same items to fill again; with skip_mu the mean tiles they hold are kept (BTX_SAMPLE_SKIP_MU: the
+    caller vouches that mu has not changed since)."""
     L = _lib.lib()
     if not items:
         return []
@@ -245,10 +248,12 @@ def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None):
     for i, (kind, op, mu_p, rho_p, layer_id, *src) in enumerate(items):
         g = _weight_geom(op)
         geoms.append(g)
-        nbytes = L.btx_sampled_w_bytes(ctypes.byref(g), kind, prec_c)
+        nbytes = L.btx_sampled_w_bytes_lanes(ctypes.byref(g), kind, prec_c, int(lanes))
         if nbytes == 0:
             raise _lib.BtxError("btx_sampled_w_bytes: unsupported geometry")
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        buf = bufs[i] if bufs is not None else torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if buf.numel() != nbytes:
+            raise _lib.BtxError("sample_weights: buffer %d does not match the item (bytes %d != %d)" % (i, buf.numel(), nbytes))
         outs.append(buf)
         arr[i].geom = ctypes.pointer(g)
         arr[i].mu_w, arr[i].rho_w, arr[i].out = mu_p.data_ptr(), rho_p.data_ptr(), buf.data_ptr()
@@ -257,14 +262,19 @@ def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None):
             arr[i].src_KW, arr[i].src_C = int(src[0]), int(src[1])
     stream = torch.cuda.current_stream(device).cuda_stream
     r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, 0, sample_dev.data_ptr() if sample_dev is not None else None)
-    _lib.check(L.btx_sample_weights(arr, len(items), ctypes.byref(r), prec_c, stream))
+    _lib.check(L.btx_sample_weights_lanes(arr, len(items), ctypes.byref(r), prec_c, stream, int(lanes),
+                                          _lib.SAMPLE_SKIP_MU if skip_mu else 0))
     return outs
 
 
 def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_id, prec=None, noise=None,
-                 extra_flags=0, out_dtype=None, epilogue=None, sampled_w=None, sample_dev=None):
+                 extra_flags=0, out_dtype=None, epilogue=None, sampled_w=None, sample_dev=None, lanes=1, lane_batch=None):
     """One fused sample-and-contract forward on the GPU (btx_contract_fwd).  `mu_p`/`rho_p` are GEMM-major packed.
-    `noise` (parity mode) = dict with optional eps_w (logical weight layout), eps_b, sign_in, sign_out."""
+    `noise` (parity mode) = dict with optional eps_w (logical weight layout), eps_b, sign_in, sign_out.
+    lanes > 1 (btx_contract_fwd_lanes): `lanes` MC samples in one launch.  x holds either the lanes' inputs back to
+    back along the batch axis (lanes * lane_batch rows / images) or ONE input shared by all lanes (lane_batch rows);
+    the output always holds the lanes back to back.  Sample indices: sample_idx + lane, or the `lanes` words of
+    sample_dev."""
     L = _lib.lib()
     if not x.is_cuda:
         raise _lib.BtxError("contract_hip needs a CUDA (ROCm) tensor")
@@ -280,7 +290,22 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     out_sp = op.out_spatial(spatial)
     if min(out_sp) <= 0:
         raise ValueError("output size is too small")
+    lanes = int(lanes)
+    nb_out, x_shared = nb, False
+    if lanes > 1:
+        if noise:
+            raise _lib.BtxError("explicit noise tensors are single-sample (lanes == 1)")
+        if lane_batch is None:
+            raise _lib.BtxError("lanes > 1 needs lane_batch")
+        rows = int(lane_batch) * (nb // x.shape[0] if (op.nd == 0 and x.dim() > 1 and x.shape[0] > 0) else 1)
+        if nb == rows:
+            x_shared, nb_out = True, rows * lanes
+        elif nb != rows * lanes:
+            raise _lib.BtxError("lanes=%d x lane_batch=%d does not match the input batch %d" % (lanes, lane_batch, x.shape[0]))
+        nb = rows  # the geometry of ONE lane
     flags = (_lib.FLAG_TRANSPOSED if op.transposed else 0) | extra_flags | (_lib.FLAG_CONCURRENT if _CONCURRENT else 0)
+    if lanes > 1:
+        flags |= lanes << _lib.FLAG_LANES_SHIFT
     if out_dtype is not None and out_dtype != x.dtype:
         flags |= _lib.FLAG_OUT_BF16 if out_dtype == torch.bfloat16 else _lib.FLAG_OUT_F32
     # the geometry struct and the workspace size depend on shapes only: built once per (op, batch, extent, modes)
@@ -304,7 +329,7 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
         if not L.btx_contract_pool_shape(ctypes.byref(g), act, prec_c, flags, ctypes.byref(hq), ctypes.byref(wq)):
             raise _lib.BtxError("the fused stem max-pool is not available for this geometry (contract_pool_ok)")
         out_sp = (1, hq.value, wq.value)
-    out = _alloc_out(op, nb, out_sp, out_dtype or x.dtype, x.device)
+    out = _alloc_out(op, nb_out, out_sp, out_dtype or x.dtype, x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     ws = _workspace(x.device, need, stream) if need else None
     r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF,
@@ -357,18 +382,25 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
             ep.residual = rp.data_ptr()
         ep.relu = 1 if epilogue.get("relu") else 0
         ep.pool = 1 if epilogue.get("pool") else 0
-    rc = L.btx_contract_fwd_ex(kind, ctypes.byref(g), xp.data_ptr(), mu_p.data_ptr(), rho_p.data_ptr(),
-                               mu_b.data_ptr() if mu_b is not None else None,
-                               rho_b.data_ptr() if rho_b is not None else None,
-                               out.data_ptr(), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None,
-                               act, prec_c, flags, ws.data_ptr() if ws is not None else None,
-                               ws.numel() if ws is not None else 0, stream,
-                               ctypes.byref(ep) if ep is not None else None)
+    args = (kind, ctypes.byref(g), xp.data_ptr(), mu_p.data_ptr(), rho_p.data_ptr(),
+            mu_b.data_ptr() if mu_b is not None else None, rho_b.data_ptr() if rho_b is not None else None,
+            out.data_ptr(), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None,
+            act, prec_c, flags, ws.data_ptr() if ws is not None else None,
+            ws.numel() if ws is not None else 0, stream, ctypes.byref(ep) if ep is not None else None)
+    if lanes > 1:
+        ln = _lib.Lanes()
+        ln.n = lanes
+        ln.x_stride = 0 if x_shared else (xp.numel() // lanes) * xp.element_size()
+        ln.out_stride = (out.numel() // lanes) * out.element_size()
+        ln.res_stride = ln.out_stride
+        rc = L.btx_contract_fwd_lanes(*args, ctypes.byref(ln))
+    else:
+        rc = L.btx_contract_fwd_ex(*args)
     _lib.check(rc)
     if ev0 is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record(torch.cuda.current_stream(x.device))
-        m_rows = nb * out_sp[0] * out_sp[1] * out_sp[2]
+        m_rows = nb_out * out_sp[0] * out_sp[1] * out_sp[2]
         k_red = op.kernel[0] * op.kernel[1] * op.kernel[2] * (op.in_channels // op.groups)
         flops = 2.0 * m_rows * op.out_channels * k_red * (2 if kind == _lib.KIND_FLIPOUT else 1)
         tag = "%s/%s/%s k%dx%dx%d cin%d cout%d M%d" % ("flipout" if kind else "reparam", prec,

@@ -183,7 +183,7 @@ class _VariationalNd(BaseVariationalLayer_):
         for k, v in self.__dict__.items():
             new.__dict__[k] = copy.deepcopy(v, memo)
         new.__dict__["_btx_layer_id"] = _rng.next_layer_id()
-        for k in ("_btx_pre", "_btx_sample_dev", "_btx_prior_state", "_btx_plans"):
+        for k in ("_btx_pre", "_btx_sample_dev", "_btx_prior_state", "_btx_plans", "_btx_lanes", "_btx_lane_batch"):
             new.__dict__.pop(k, None)
         return new
 
@@ -221,6 +221,8 @@ class _VariationalNd(BaseVariationalLayer_):
             return_kl = False
         if self._use_hip(input):
             if self._needs_grad(input):
+                if self.__dict__.get("_btx_lanes", 1) > 1:
+                    raise _lib.BtxError("MC sample lanes are an inference feature: clear them before a training step")
                 from .. import autograd as _ag
                 s_idx = self._btx_sample
                 self.__dict__["_btx_sample"] = s_idx + 1
@@ -268,9 +270,14 @@ class _VariationalNd(BaseVariationalLayer_):
         key = (_rng.seed(), self._sample_key(sample_idx), self._btx_layer_id, self.precision or prec, tag)
         return key, (kind, op, mu_p, rho_p, self._btx_layer_id) + tuple(src)
 
+    def _lanes(self):
+        """MC sample lanes of the next forward (rng.set_sample_lanes): (n, images per lane)"""
+        return self.__dict__.get("_btx_lanes", 1), self.__dict__.get("_btx_lane_batch")
+
     def _sample_key(self, sample_idx):
         sdev = getattr(self, "_btx_sample_dev", None)  # graph mode (mc.GraphedMC): the index lives on the device
-        return ("dev", sdev.data_ptr()) if sdev is not None else int(sample_idx)
+        n = self.__dict__.get("_btx_lanes", 1)
+        return ("dev", sdev.data_ptr(), n) if sdev is not None else (int(sample_idx), n)
 
     def _take_presampled(self, sample_idx, prec, tag):
         """one-shot: the buffer bayesian_torch_amd.presample() left for exactly this (seed, sample, layer, prec, layout)"""
@@ -283,9 +290,12 @@ class _VariationalNd(BaseVariationalLayer_):
     def _forward_hip(self, x, noise=None, sample_idx=None, epilogue=None, gather=False):
         mu, rho = self._w()
         mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
+        lanes, lane_batch = self._lanes()
+        if lanes > 1 and noise is not None:
+            raise _lib.BtxError("explicit noise is single-sample: clear the sample lanes first (rng.set_sample_lanes)")
         if sample_idx is None:
             sample_idx = self._btx_sample
-            self.__dict__["_btx_sample"] = sample_idx + 1
+            self.__dict__["_btx_sample"] = sample_idx + lanes
         kind = _lib.KIND_FLIPOUT if self._family == "flipout" else _lib.KIND_REPARAM
         mb = self.mu_bias.detach() if self.mu_bias is not None else None
         rb = self.rho_bias.detach() if self.rho_bias is not None else None
@@ -306,7 +316,8 @@ class _VariationalNd(BaseVariationalLayer_):
                 raise _lib.BtxError("residual epilogue is not available for this row-fused stem geometry")
             out = BF.contract_hip(kind, xin, mu_f, rho_f, mb, rb, plan["op"], _rng.seed(), sample_idx,
                                   self._btx_layer_id, prec=prec, extra_flags=_lib.FLAG_ROWFUSE, out_dtype=x.dtype,
-                                  epilogue=epilogue, sampled_w=pre, sample_dev=getattr(self, "_btx_sample_dev", None))
+                                  epilogue=epilogue, sampled_w=pre, sample_dev=getattr(self, "_btx_sample_dev", None),
+                                  lanes=lanes, lane_batch=lane_batch)
             if epilogue is not None and epilogue.get("pool"):
                 return out  # pooled inside the launch (pool_fusable() vouched for the geometry)
             return out[:, :, :plan["Ho"], :plan["Wo"]]
@@ -325,7 +336,7 @@ class _VariationalNd(BaseVariationalLayer_):
         return BF.contract_hip(kind, x, mu_p, rho_p, mb, rb, op, _rng.seed(), sample_idx,
                                self._btx_layer_id, prec=self.precision, noise=noise, epilogue=epilogue, sampled_w=pre,
                                sample_dev=getattr(self, "_btx_sample_dev", None),
-                               extra_flags=_lib.FLAG_GATHER if gather else 0)
+                               extra_flags=_lib.FLAG_GATHER if gather else 0, lanes=lanes, lane_batch=lane_batch)
 
     def pool_fusable(self, x):
         """True when forward_fused(..., pool=True) can fold nn.MaxPool2d(3, 2, 1) into this layer's launch: a row-fused

@@ -62,22 +62,40 @@ def unpack(packed, bs, num_classes):
 
 
 @torch.no_grad()
-def mc_forward(model, x, num_samples, sample_offset=0, with_kl=False, group=None, reduce=True):
+def mc_forward(model, x, num_samples, sample_offset=0, with_kl=False, group=None, reduce=True, lanes=1, rank=None,
+               world=None):
     """Run `num_samples` MC forward passes of `model` on `x`, sharded over the ranks of `group` (or the default
-    group when torch.distributed is initialised), and return the all-reduced packed statistics tensor."""
-    rank, world = 0, 1
+    group when torch.distributed is initialised), and return the all-reduced packed statistics tensor.
+    lanes > 1 (GPU): this rank evaluates its samples `lanes` at a time, one launch per layer for all of them
+    (rng.set_sample_lanes) — the same numbers as one at a time.  rank / world: override the process group's (tests that
+    play several ranks in one process, with reduce=False)."""
+    r0, w0 = 0, 1
     if dist.is_available() and dist.is_initialized():
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        r0, w0 = dist.get_rank(group), dist.get_world_size(group)
+    rank = r0 if rank is None else int(rank)
+    world = w0 if world is None else int(world)
     packed = None
     kl = float(get_kl_loss(model)) if with_kl else 0.0  # RNG-free: identical for every sample
-    for s in range(rank, num_samples, world):
-        _rng.set_sample_index(model, sample_offset + s, presample=x.is_cuda)
+    mine = list(range(rank, num_samples, world))
+    lanes = max(1, int(lanes)) if x.is_cuda else 1
+    bs = x.shape[0]
+    for g0 in range(0, len(mine), lanes):
+        grp = [sample_offset + s for s in mine[g0:g0 + lanes]]
+        if len(grp) > 1:
+            _rng.set_sample_lanes(model, grp, batch=bs, presample=True)
+        else:
+            if lanes > 1:
+                _rng.set_sample_lanes(model, None)
+            _rng.set_sample_index(model, grp[0], presample=x.is_cuda)
         logits = model(x)
         if isinstance(logits, tuple):
             logits = logits[0]
         if packed is None:
-            packed = torch.zeros(packed_numel(*logits.shape), dtype=torch.float32, device=logits.device)
-        accumulate(packed, logits, kl)
+            packed = torch.zeros(packed_numel(bs, logits.shape[1]), dtype=torch.float32, device=logits.device)
+        for k in range(len(grp)):
+            accumulate(packed, logits[k * bs:(k + 1) * bs], kl)
+    if lanes > 1:
+        _rng.set_sample_lanes(model, None)
     if packed is None:  # this rank got no sample: it still takes part in the collective
         with torch.no_grad():
             _rng.set_sample_index(model, sample_offset)
@@ -130,13 +148,22 @@ class GraphedMC:
 
     The parameters must not be re-allocated while the graph is alive (in-place updates are seen by the replays)."""
 
-    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1, keep_logits=False, concurrent_hint=None):
-        """lanes > 1: one replay evaluates `lanes` MC samples, each on its own stream inside the graph (independent noise:
-        the same results as one at a time) — the kernels of one sample fill the GPU while those of another are in their
-        ramp-up / tail; use run_many()."""
+    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1, keep_logits=False, concurrent_hint=None, lane_mode="launch"):
+        """lanes > 1: one replay evaluates `lanes` MC samples (independent noise: the same results as one at a time); use
+        run_many().  lane_mode "launch" (default): the samples are lanes of ONE launch per layer (rng.set_sample_lanes:
+        4x the workgroups per launch fill the 256 CUs where one sample of a 7x7 / 14x14 layer cannot, and one
+        workgroup's prologue / store overlaps another's MFMA loop); the mean tiles of the Flipout layers are written
+        once (refresh_weights() after a parameter update), a replay samples sigma*eps only.  "streams": each sample on
+        its own stream inside the graph, one launch per (layer, sample) — the round-2 form, kept for A/B."""
         if not x.is_cuda:
             raise ValueError("GraphedMC needs CUDA (ROCm) tensors")
+        if lane_mode not in ("launch", "streams"):
+            raise ValueError("lane_mode must be 'launch' or 'streams'")
         self.model, self.x, self.kl, self.lanes = model, x, float(kl), int(lanes)
+        self.lane_mode = lane_mode
+        if self.lanes > 1 and lane_mode == "launch":
+            self._init_launch_lanes(warmup, keep_logits)
+            return
         # keep_logits: lane_logits[k] is the (static) logits tensor of lane k — after a replay it holds the logits of the
         # sample that lane just evaluated (parity tests of the graphed configuration)
         self.keep_logits, self.lane_logits = bool(keep_logits), [None] * int(lanes)
@@ -182,6 +209,52 @@ class GraphedMC:
         for m in self._layers:
             m._btx_sample_dev = self.sample_dev
 
+    # ---- lane_mode "launch": the MC samples of a replay are lanes of every layer's launch -----------------------------
+    def _init_launch_lanes(self, warmup, keep_logits):
+        model, x, dev = self.model, self.x, self.x.device
+        self.keep_logits, self.lane_logits = bool(keep_logits), [None] * self.lanes
+        self._layers = [m for m in model.modules() if hasattr(m, "_btx_layer_id")]
+        self.sample_dev = torch.zeros(self.lanes, dtype=torch.int32, device=dev)
+        self.sample_devs = [self.sample_dev]
+        self._tiles = {}  # tile buffers of this graph (rng._presample cache): the mean tiles live here between replays
+        self.packed, self._streams = None, []
+        self.bs = x.shape[0]
+        _rng.set_sample_lanes(model, list(range(self.lanes)), batch=self.bs, sample_dev=self.sample_dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for i in range(max(1, warmup) + 1):  # 1st pass records the input shapes presample() needs
+                self._launch_lanes(skip_mu=False)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self._launch_lanes(skip_mu=True)
+        self.packed.zero_()
+
+    def _launch_lanes(self, skip_mu):
+        _rng.presample(self.model, 0, cache=self._tiles, skip_mu=skip_mu)
+        logits = self.model(self.x)
+        if isinstance(logits, tuple):
+            logits = logits[0]
+        bs = self.bs
+        if self.packed is None:
+            self.logits_shape = (bs, logits.shape[1])
+            self.packed = torch.zeros(packed_numel(bs, logits.shape[1]), dtype=torch.float32, device=logits.device)
+        for k in range(self.lanes):
+            accumulate(self.packed, logits[k * bs:(k + 1) * bs], self.kl)
+            if self.keep_logits:
+                self.lane_logits[k] = logits[k * bs:(k + 1) * bs]
+
+    def refresh_weights(self):
+        """lane_mode "launch": rewrite the cached mean tiles after an in-place parameter update (the replays sample
+        sigma*eps only).  The sample words keep their values."""
+        if self.lanes > 1 and self.lane_mode == "launch":
+            with torch.no_grad():
+                _rng.presample(self.model, 0, cache=self._tiles, skip_mu=False)
+                for m in self._layers:
+                    m.__dict__["_btx_pre"] = None
+
     def _lane(self, k):
         for m in self._layers:
             m.__dict__["_btx_sample_dev"] = self.sample_devs[k]
@@ -208,11 +281,17 @@ class GraphedMC:
         """one replay = len(sample_indices) == lanes MC samples"""
         if len(sample_indices) != self.lanes:
             raise ValueError("expected %d sample indices" % self.lanes)
-        for w, i in zip(self.sample_devs, sample_indices):
-            w.fill_(int(i) & 0x7FFFFFFF)
+        if self.lane_mode == "launch" and self.lanes > 1:
+            self.sample_dev.copy_(torch.tensor([int(i) & 0x7FFFFFFF for i in sample_indices], dtype=torch.int32))
+        else:
+            for w, i in zip(self.sample_devs, sample_indices):
+                w.fill_(int(i) & 0x7FFFFFFF)
         self.graph.replay()
 
     def close(self):
         for m in self._layers:
             m._btx_sample_dev = None
             m._btx_pre = None
+            m.__dict__.pop("_btx_lanes", None)
+            m.__dict__.pop("_btx_lane_batch", None)
+        self._tiles = {}

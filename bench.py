@@ -155,7 +155,8 @@ def cpu_baseline(typ, bs, budget_s=24.0):
 # ------------------------------------------------------------------------------------------------------------------
 # per-launch roofline: record the contraction launches of one step, re-issue each inside a hipGraph
 # ------------------------------------------------------------------------------------------------------------------
-def record_launches(model, x, sample_idx):
+def record_launches(model, x, sample_idx, lanes=1):
+    """the contraction launches of one forward (`lanes` MC samples per launch, as the timed loop issues them)"""
     import bayesian_torch_amd as bt
     from bayesian_torch_amd import functional as BF
     recs = []
@@ -167,11 +168,16 @@ def record_launches(model, x, sample_idx):
     BF.contract_hip = rec
     try:
         with torch.no_grad():
-            bt.set_sample_index(model, sample_idx, presample=True)
+            if lanes > 1:
+                bt.set_sample_lanes(model, list(range(sample_idx, sample_idx + lanes)), batch=x.shape[0], presample=True)
+            else:
+                bt.set_sample_index(model, sample_idx, presample=True)
             model(x)
         torch.cuda.synchronize()
     finally:
         BF.contract_hip = orig
+        if lanes > 1:
+            bt.set_sample_lanes(model, None)
     # row-fused stems run on a zero-padded geometry (3 -> 4 channels, 7 -> 8 taps per kernel row): their ALGORITHMIC
     # contraction length is the layer's own KH*KW*Cin, not the padded one
     algo_k = {}
@@ -214,7 +220,7 @@ def time_launches(recs, prec, reps=10, algo_k=None):
         if (k.get("epilogue") or {}).get("pool"):  # the stem's max-pool is folded into the launch: y is the pooled tensor,
             sp = (1,) * (3 - op.nd) + tuple(xin.shape[2:])  # the contraction still produces every conv pixel
             osp = op.out_spatial(sp)
-            m_rows = xin.shape[0] * osp[0] * osp[1] * osp[2]
+            m_rows = y.shape[0] * osp[0] * osp[1] * osp[2]  # y holds every lane; the stem's input may be shared by them
         k_red = op.kernel[0] * op.kernel[1] * op.kernel[2] * (op.in_channels // op.groups)
         k_red = (algo_k or {}).get(id(op), k_red)
         nmm = 2 if kind == _lib.KIND_FLIPOUT else 1
@@ -222,17 +228,53 @@ def time_launches(recs, prec, reps=10, algo_k=None):
         ep = k.get("epilogue") or {}
         nbytes = (xin.numel() * xin.element_size() + y.numel() * y.element_size() +
                   (y.numel() * y.element_size() if ep.get("residual") is not None else 0) +
-                  8 * op.out_channels * k_red)
+                  8 * op.out_channels * k_red * int(k.get("lanes") or 1))
         t_mfma, t_hbm = flops / (MFMA_PEAK_TFLOPS[prec] * 1e12), nbytes / (HBM_PEAK_TBS * 1e12)
         out.append({"launch": "%s k%dx%d s%d cin%d cout%d M%d" % ("flipout" if nmm == 2 else "reparam", op.kernel[1],
                                                                   op.kernel[2], op.stride[2], op.in_channels,
                                                                   op.out_channels, m_rows),
+                    "lanes": int(k.get("lanes") or 1), "weights": op.out_channels * k_red,
                     "us": us, "gflop": flops / 1e9, "mbytes": nbytes / 1e6, "tflops": flops / (us * 1e-6) / 1e12,
                     "tbs": nbytes / (us * 1e-6) / 1e12, "bound": "mfma" if t_mfma >= t_hbm else "hbm",
                     "frac": max(t_mfma, t_hbm) / (us * 1e-6),
                     "dominant": bool(op.nd == 2 and op.kernel[1:] == (3, 3) and op.stride[1:] == (1, 1))})
         del g
     return out
+
+
+def time_sampling(model, lanes, reps=10):
+    """GPU time of the weight-sampling launch of one forward (all layers, `lanes` MC samples; the mean tiles cached as in
+    the timed loop: BTX_SAMPLE_SKIP_MU), re-issued `reps` times inside a hipGraph -> us per launch"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import rng as _rng
+    dev = next(model.parameters()).device
+    cache = {}
+    side = torch.cuda.Stream(dev)
+    with torch.no_grad():
+        if lanes > 1:
+            bt.set_sample_lanes(model, list(range(7, 7 + lanes)), batch=1)
+        with torch.cuda.stream(side):
+            _rng.presample(model, 7, cache=cache, skip_mu=False)
+            _rng.presample(model, 7, cache=cache, skip_mu=True)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                _rng.presample(model, 7, cache=cache, skip_mu=True)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        for m_ in model.modules():
+            if hasattr(m_, "_btx_pre"):
+                m_._btx_pre = None
+        if lanes > 1:
+            bt.set_sample_lanes(model, None)
+    return e0.elapsed_time(e1) / (2 * reps) * 1e3
 
 
 def measure_traffic(timeout_s=150):
@@ -290,17 +332,22 @@ def measure_traffic(timeout_s=150):
 class Runner:
     """`steps` MC samples of `model` on `x`: hipGraph replays (`lanes` samples in flight) or eager launches"""
 
-    def __init__(self, model, x, kl, num_classes, lanes, graph, presample=True, sizes=(), concurrent_hint=None):
+    def __init__(self, model, x, kl, num_classes, lanes, graph, presample=True, sizes=(), concurrent_hint=None,
+                 lane_mode="launch"):
         from bayesian_torch_amd import mc
         import bayesian_torch_amd as bt
         self.model, self.x, self.kl, self.graphed, self.rest = model, x, kl, None, {}
         self.presample = presample
         if graph:
             try:
-                self.graphed = mc.GraphedMC(model, x, kl=kl, lanes=max(1, lanes), concurrent_hint=concurrent_hint)
-                # ragged last groups (counts that are not a multiple of the lane count): one smaller graph per remainder
-                self.rest = {r: mc.GraphedMC(model, x, kl=kl, lanes=r, concurrent_hint=concurrent_hint)
-                             for r in sorted({s % self.graphed.lanes for s in sizes} - {0})}
+                # ragged last groups (counts that are not a multiple of the lane count): one smaller graph per remainder.
+                # Built FIRST: a graph with launch lanes leaves the lane state on the layers it was captured with, and
+                # the main graph must be the last one to set it (replays do not depend on it, captures do).
+                rests = sorted({s % max(1, lanes) for s in sizes} - {0})
+                self.rest = {r: mc.GraphedMC(model, x, kl=kl, lanes=r, concurrent_hint=concurrent_hint, lane_mode=lane_mode)
+                             for r in rests}
+                self.graphed = mc.GraphedMC(model, x, kl=kl, lanes=max(1, lanes), concurrent_hint=concurrent_hint,
+                                            lane_mode=lane_mode)
             except Exception as e:  # a runtime that cannot capture: measure the eager path rather than nothing
                 print("bench: hipGraph capture failed (%s: %s) - falling back to eager launches" % (type(e).__name__, e),
                       file=sys.stderr)
@@ -347,29 +394,31 @@ class Runner:
                 gr.close()
 
 
-def timed_mc(runner, my_indices, warm_indices, world, dev):
+def timed_mc(runner, my_indices, warm_indices, world, dev, repeats=1):
     def barrier():
         if world > 1:
             dist.barrier()
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
+    runs = []
     with torch.no_grad():
         runner.run(warm_indices)
         if world > 1:
             dist.all_reduce(runner.packed)  # warm the communicator too
-        runner.zero()
-        barrier()
-        t0 = time.perf_counter()
-        runner.run(my_indices)
-        runner.fold()
-        if world > 1:
-            dist.all_reduce(runner.packed, op=dist.ReduceOp.SUM)
-        barrier()
-        elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        for _ in range(max(1, repeats)):  # the SAME timed region `repeats` times: a 20-step region is ~10 ms of GPU time
+            runner.zero()
+            barrier()
+            t0 = time.perf_counter()
+            runner.run(my_indices)
+            runner.fold()
+            if world > 1:
+                dist.all_reduce(runner.packed, op=dist.ReduceOp.SUM)
+            barrier()
+            runs.append(time.perf_counter() - t0)
+    t = torch.tensor(runs, dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # per region: the slowest rank
+    return [float(v) for v in t]
 
 
 def logits_parity(model_fn, x, prec, sample=3):
@@ -395,7 +444,7 @@ def logits_parity(model_fn, x, prec, sample=3):
 
 def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, world=1, rank=0, graph=True, fuse=True,
                       presample=True, scaling="weak", total=None, per_launch=True, parity=False, prewarm=PREWARM_STEPS,
-                      concurrent_hint=None):
+                      concurrent_hint=None, lane_mode="launch", repeats=5):
     import bayesian_torch_amd as bt
     from bayesian_torch_amd import mc
     bt.manual_seed(2024)
@@ -413,8 +462,10 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
         mine = [k * world + rank for k in range(steps)]
         n_global = steps * world
     warm = [20_000_000 + w * world + rank for w in range(prewarm)] + [10_000_000 + w * world + rank for w in range(warmup)]
-    runner = Runner(model, x, kl, 1000, lanes, graph, presample, sizes=(len(mine), len(warm)), concurrent_hint=concurrent_hint)
-    elapsed = timed_mc(runner, mine, warm, world, dev)
+    runner = Runner(model, x, kl, 1000, lanes, graph, presample, sizes=(len(mine), len(warm)), concurrent_hint=concurrent_hint,
+                    lane_mode=lane_mode)
+    runs = timed_mc(runner, mine, warm, world, dev, repeats=repeats)
+    elapsed = sorted(runs)[len(runs) // 2]  # median of the repeated regions; every region is reported
     stats = runner.packed.clone()
     lanes_used = runner.graphed.lanes if runner.graphed is not None else 0
     runner.close()
@@ -422,19 +473,36 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
     assert abs(float(u["samples"]) - n_global) < 0.5, "work was skipped inside the timed region"
     assert torch.isfinite(u["mean_prob"]).all()
     res = {"elapsed": elapsed, "n_global": n_global, "per_rank": len(mine), "kl": kl, "lanes": lanes_used,
-           "ms_per_step": 1e3 * elapsed / max(len(mine), 1), "value": n_global / elapsed}
+           "lane_mode": lane_mode if lanes_used > 1 else "single",
+           "ms_per_step": 1e3 * elapsed / max(len(mine), 1), "value": n_global / elapsed,
+           "ms_per_step_runs": [1e3 * r / max(len(mine), 1) for r in runs]}
     known = KL_KNOWN.get((arch, moped))
     if known:
         res["kl_rel_err"] = abs(kl - known) / known
     if per_launch and dev.type == "cuda":
-        recs, algo_k = record_launches(model, x, 7)
+        # the launches as the timed loop issues them: `ll` MC samples per launch when the lanes ride inside the launch
+        ll = lanes_used if (lanes_used > 1 and lane_mode == "launch") else 1
+        recs, algo_k = record_launches(model, x, 7, lanes=ll)
         table = time_launches(recs, prec, algo_k=algo_k)
+        # the sampling launch of the same forward (one launch for all layers and lanes), charged to each contraction by
+        # its share of the weights: a contraction's roofline figure counts the sampling that feeds it
+        samp_us = time_sampling(model, ll) if presample else 0.0
+        wsum = float(sum(r["weights"] for r in table)) or 1.0
+        for r in table:
+            r["sampling_us"] = samp_us * r["weights"] / wsum
+            r["frac_incl_sampling"] = r["frac"] * r["us"] / (r["us"] + r["sampling_us"])
         dom = [r for r in table if r["dominant"]] or table
         res["per_launch"] = table
-        res["gflop_per_step"] = sum(r["gflop"] for r in table)
-        res["kernel_us_per_step"] = sum(r["us"] for r in table)
-        res["dominant_tflops"] = sum(r["gflop"] for r in dom) / sum(r["us"] for r in dom) * 1e3  # GFLOP/us = 1e15 FLOP/s
-        res["dominant_avg_us"] = sum(r["us"] for r in dom) / len(dom)
+        res["launch_lanes"] = ll
+        res["sampling_us_per_launch"] = samp_us
+        res["gflop_per_step"] = sum(r["gflop"] for r in table) / ll
+        res["kernel_us_per_step"] = (sum(r["us"] for r in table) + samp_us) / ll
+        dom_us = sum(r["us"] for r in dom)
+        dom_samp = sum(r["sampling_us"] for r in dom)
+        res["dominant_tflops_contraction_only"] = sum(r["gflop"] for r in dom) / dom_us * 1e3  # GFLOP/us = 1e15 FLOP/s
+        res["dominant_tflops"] = sum(r["gflop"] for r in dom) / (dom_us + dom_samp) * 1e3
+        res["dominant_avg_us"] = dom_us / len(dom)
+        res["dominant_sampling_us"] = dom_samp / len(dom)
         res["dominant_n"] = len(dom)
         res["achieved_e2e_tflops"] = res["gflop_per_step"] / res["ms_per_step"]
     if parity and dev.type == "cuda":
@@ -516,7 +584,7 @@ def run_train_step(dev, steps=5):
 def summarise_extra(name, r, prec):
     peak = MFMA_PEAK_TFLOPS[prec]
     out = {"workload": name, "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "MC-samples/s", "dtype": prec,
-           "kl": r["kl"], "lanes": r["lanes"]}
+           "kl": r["kl"], "lanes": r["lanes"], "lane_mode": r.get("lane_mode"), "ms_per_step_runs": r.get("ms_per_step_runs")}
     for k in ("kl_rel_err", "logits_rel_l2_vs_unfused_f32"):
         if k in r:
             out[k] = r[k]
@@ -564,7 +632,7 @@ def dry_run(args, world, rank):
     x = torch.randn(8, 32)
     runner = Runner(net, x, 0.0, 10, 1, graph=False, presample=False)
     mine = [k * world + rank for k in range(args.steps)]
-    elapsed = timed_mc(runner, mine, [10_000 + rank], world, dev)
+    elapsed = timed_mc(runner, mine, [10_000 + rank], world, dev)[0]
     u = mc.unpack(runner.packed, 8, 10)
     if rank == 0:
         assert abs(float(u["samples"]) - args.steps * world) < 0.5
@@ -592,8 +660,13 @@ def main():
                     "(BASELINE cfg4: 32 over 8 GPUs)")
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/residual as separate torch ops")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every MC sample from Python")
-    ap.add_argument("--lanes", type=int, default=4, help="MC samples evaluated concurrently (one stream each) inside one "
-                    "hipGraph replay; independent noise, identical results to one at a time")
+    ap.add_argument("--lanes", type=int, default=4, help="MC samples evaluated by one hipGraph replay; independent noise, "
+                    "identical results to one at a time")
+    ap.add_argument("--lane-mode", default="launch", choices=["launch", "streams"], help="launch: the samples of a replay "
+                    "are lanes of ONE launch per layer (btx_contract_fwd_lanes); streams: one launch per (layer, sample), "
+                    "each sample on its own stream (the round-2 form)")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region (the same --steps MC samples) is run this many "
+                    "times; value / ms_per_step are the median region, every region is listed in ms_per_step_runs")
     ap.add_argument("--no-presample", action="store_true")
     ap.add_argument("--latency-plan", action="store_true", help="A/B: plan every launch for its own latency (split-K to fill "
                     "idle CUs) although several MC samples are in flight")
@@ -644,7 +717,8 @@ def main():
                              presample=not args.no_presample, scaling=args.scaling, total=args.total_samples,
                              per_launch=not args.no_launch_timing and rank == 0,
                              concurrent_hint=False if args.latency_plan else None,
-                             parity=(rank == 0 and world == 1 and not args.no_extras))
+                             parity=(rank == 0 and world == 1 and not args.no_extras), lane_mode=args.lane_mode,
+                             repeats=args.repeats)
     if rank == 0:
         peak = MFMA_PEAK_TFLOPS[args.prec]
         roofline = None
@@ -665,15 +739,22 @@ def main():
                 "bound": "mfma", "achieved": head["dominant_tflops"], "peak": peak, "unit": "TFLOP/s",
                 "frac": head["dominant_tflops"] / peak,
                 "traffic": (traffic or {}).get("hbm_bytes"), "traffic_detail": traffic, "traffic_source": tsrc,
-                "kernel": "btx::contract_taps_kernel<%s,%s,3,3> — the %d stride-1 3x3 launches of a step (incl. their split-K "
-                          "reduce where the plan splits K)" % (args.prec, args.type, head["dominant_n"]),
-                "avg_launch_us": head["dominant_avg_us"], "launches_per_step": len(head["per_launch"]),
+                "kernel": "btx::contract_taps_kernel<%s,%s,3,3> — the %d stride-1 3x3 launches of a forward, %d MC sample "
+                          "lane(s) per launch, plus their share (by weight count) of the weight-sampling launch" % (
+                              args.prec, args.type, head["dominant_n"], head["launch_lanes"]),
+                "achieved_contraction_only": head["dominant_tflops_contraction_only"],
+                "frac_contraction_only": head["dominant_tflops_contraction_only"] / peak,
+                "mc_samples_per_launch": head["launch_lanes"], "sampling_us_per_launch": head["sampling_us_per_launch"],
+                "avg_launch_us": head["dominant_avg_us"], "avg_sampling_share_us": head["dominant_sampling_us"],
+                "launches_per_forward": len(head["per_launch"]),
                 "algorithmic_gflop_per_step": head["gflop_per_step"], "kernel_us_per_step": head["kernel_us_per_step"],
                 "achieved_all_launches": head["gflop_per_step"] / head["kernel_us_per_step"] * 1e3,
                 "achieved_e2e": head["achieved_e2e_tflops"], "frac_e2e": head["achieved_e2e_tflops"] / peak,
-                "measured": "every contraction launch of a step re-issued 10x inside a hipGraph, HIP events on the launch "
-                            "stream around 2 replays (GPU time, no host gaps); achieved_e2e = algorithmic FLOP of a step / "
-                            "ms_per_step of the timed region",
+                "measured": "every contraction launch of a forward (as the timed loop issues it: mc_samples_per_launch MC "
+                            "samples per launch) re-issued 10x inside a hipGraph, HIP events on the launch stream around 2 "
+                            "replays (GPU time, no host gaps); the sampling launch timed the same way; achieved = "
+                            "algorithmic FLOP / (contraction time + sampling share); achieved_e2e = algorithmic FLOP of a "
+                            "step / ms_per_step of the timed region",
                 "per_launch": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "dominant"}
                                for r in head["per_launch"]]}
         out = {
@@ -681,6 +762,7 @@ def main():
                                                                       args.batch),
             "value": head["value"], "unit": "MC-samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
             "steps": head["per_rank"], "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "ms_per_step_runs": head["ms_per_step_runs"], "timed_regions": len(head["ms_per_step_runs"]),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "dnn_to_bnn(%s) %s%s, 224x224, batch %d, %d MC samples per GPU (%d in total), %s init "
                                    "(seed 0), activations %s, eval-BN/ReLU/residual %s, %s" % (
@@ -688,7 +770,9 @@ def main():
                                        head["n_global"], "MOPED(delta 0.5)" if args.moped else "default", args.prec,
                                        "as torch ops" if args.no_fuse else "folded into the kernel epilogue",
                                        "eager launches" if head["lanes"] == 0 else
-                                       "hipGraph replay, %d MC samples in flight (one stream each)" % head["lanes"]),
+                                       ("hipGraph replay, %d MC samples per replay as lanes of one launch per layer" if
+                                        head["lane_mode"] == "launch" else
+                                        "hipGraph replay, %d MC samples in flight (one stream each)") % head["lanes"]),
                        "global_batch": args.batch * world, "parallelism": "mc-sample-shard x%d" % world},
             "image_samples_per_s": args.batch * head["n_global"] / head["elapsed"],
             "kl": head["kl"], "kl_rel_err": head.get("kl_rel_err"), "roofline": roofline,

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BTX_ABI_VERSION 4
+#define BTX_ABI_VERSION 5
 
 /* argument-error codes (negative) */
 #define BTX_E_NULL        (-1)   /* required pointer is NULL */
@@ -77,6 +77,13 @@ extern "C" {
 #define BTX_FLAG_GATHER      32u  /* force the element-wise gather kernel (any shape / alignment; samples in registers).
                                      The library picks it by itself whenever a fast kernel does not apply; the flag
                                      exists so tests can exercise it on shapes the fast kernels would take. */
+
+/* MC sample lanes (btx_contract_fwd_lanes): n independent Monte-Carlo samples of the SAME layer in one launch.  Whoever
+ * asks for a workspace size or a pool shape for such a launch ORs BTX_FLAG_LANES(n) into the flags (the entry point sets
+ * it from BtxLanes.n itself). */
+#define BTX_FLAG_LANES_SHIFT 16
+#define BTX_FLAG_LANES_MASK  (0xffu << BTX_FLAG_LANES_SHIFT)
+#define BTX_FLAG_LANES(n)    (((uint32_t)(n) & 0xffu) << BTX_FLAG_LANES_SHIFT)
 
 /* RNG streams of BTX-RNG v1 */
 #define BTX_STREAM_EPS_W    0u
@@ -204,6 +211,29 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g,
                         void* ws, size_t ws_bytes, void* stream,
                         const BtxEpilogue* epilogue /* nullable */);
 
+/* MC sample lanes.  The Monte-Carlo loop of the reference (examples/main_bayesian_imagenet_dnn2bnn.py:480-499:
+ * `for mc_run in range(num_monte_carlo): output = model(images)`) evaluates the same layer once per sample with fresh
+ * noise; on a 256-CU GPU one sample of a 7x7 or 14x14 layer is a few hundred workgroups — too few to fill the chip and
+ * to overlap one workgroup's prologue / store with another's MFMA loop.  btx_contract_fwd_lanes runs `n` samples of one
+ * layer in ONE launch: lane l reads x + l*x_stride (x_stride 0: the lanes share the input, e.g. the network's first
+ * layer), uses the MC sample index rng->sample_idx + l (rng->sample_idx_dev[l] when given: n consecutive words) and
+ * writes out + l*out_stride (residual + l*res_stride).  Strides in bytes, multiples of 16.  Every lane computes bit for
+ * bit what btx_contract_fwd_ex would for its sample (the noise indices are relative to the lane's own tensors).
+ * noise->sampled_w: the buffer btx_sample_weights_lanes filled for the same n.  Explicit noise tensors: n == 1 only.
+ * ws: btx_contract_workspace_bytes(..., flags | BTX_FLAG_LANES(n)). */
+typedef struct BtxLanes {
+  int32_t n;
+  int64_t x_stride, out_stride, res_stride;
+} BtxLanes;
+int btx_contract_fwd_lanes(int kind, const BtxGeom* g,
+                           const void* x, const float* mu_w, const float* rho_w,
+                           const float* mu_b, const float* rho_b,
+                           void* out,
+                           const BtxRng* rng, const BtxNoise* noise /* nullable */,
+                           int act_dtype, int prec, uint32_t flags,
+                           void* ws, size_t ws_bytes, void* stream,
+                           const BtxEpilogue* epilogue /* nullable */, const BtxLanes* lanes);
+
 /* Weight gradient of one variational contraction (training; what autograd derives for the F.conv*d / F.linear calls of
  * conv_flipout.py:376-417, conv_variational.py:379-380, linear_flipout.py:168-174):
  *   dw_mu   [n][tap][c] = sum_p dy[p][n] * x[p @ tap][c]
@@ -242,6 +272,15 @@ typedef struct BtxSampleItem {
 size_t btx_sampled_w_bytes(const BtxGeom* g, int kind, int prec);
 int btx_sample_weights(const BtxSampleItem* items_host, int n_items, const BtxRng* rng /* layer_id unused */,
                        int prec, void* stream);
+/* The same for `lanes` MC samples at once (sample indices rng->sample_idx + l, or rng->sample_idx_dev[l]); `out` of each
+ * item holds btx_sampled_w_bytes_lanes(...) bytes.  The mean tiles of a Flipout layer do not depend on the sample: the
+ * buffer keeps ONE set for all lanes, and with BTX_SAMPLE_SKIP_MU in `sflags` the call leaves them untouched — for
+ * callers that know mu has not changed since the call that last wrote them into this buffer (an MC loop over frozen
+ * parameters): per sample the pre-pass then reads rho and writes sigma*eps, nothing else. */
+#define BTX_SAMPLE_SKIP_MU 1u
+size_t btx_sampled_w_bytes_lanes(const BtxGeom* g, int kind, int prec, int lanes);
+int btx_sample_weights_lanes(const BtxSampleItem* items_host, int n_items, const BtxRng* rng /* layer_id unused */,
+                             int prec, void* stream, int lanes, uint32_t sflags);
 
 /* §8(f): the data format in front of the path.  Small-C stems (BTX_FLAG_ROWFUSE) take channels-last [NB][Hp][Wp][cp]
  * activations with the conv padding materialised and the channels zero-padded to cp (4 or 8), in the MFMA dtype.

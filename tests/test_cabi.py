@@ -28,7 +28,7 @@ def test_abi_version_and_argument_errors_without_gpu():
     """pure host-side calls: version, strerror, shape arithmetic, argument validation (no kernel is launched)"""
     from bayesian_torch_amd import _lib
     L = _lib.lib()
-    assert L.btx_abi_version() == 4
+    assert L.btx_abi_version() == 5
     assert b"NULL" in L.btx_strerror(-1)
     g = _lib.Geom()
     g.NB, g.D, g.H, g.W, g.C, g.N = 64, 1, 56, 56, 64, 128
@@ -71,10 +71,15 @@ def test_argument_errors_of_the_sampling_and_format_entry_points():
     g.sd = g.sh = g.sw = 1
     g.dd = g.dh = g.dw = 1
     g.groups = 1
-    # tile image of a 128 x (3*3*64) weight matrix: 2 n-tiles x 64 channels x K elements, bf16, mu + delta for Flipout
-    assert L.btx_sampled_w_bytes(ctypes.byref(g), 1, 1) == 2 * 128 * 576 * 2
-    assert L.btx_sampled_w_bytes(ctypes.byref(g), 0, 1) == 128 * 576 * 2
-    assert L.btx_sampled_w_bytes(ctypes.byref(g), 1, 0) == 2 * 128 * 576 * 4
+    # tile image of a 128 x (3*3*64) weight matrix: 2 n-tiles x 64 channels x K elements.  Flipout: mu tiles + delta tiles
+    # (one set per MC sample lane) + the f32 sigma cache BTX_SAMPLE_SKIP_MU reads; Reparameterization: W tiles per lane
+    w = 128 * 576
+    assert L.btx_sampled_w_bytes(ctypes.byref(g), 1, 1) == 2 * w * 2 + w * 4
+    assert L.btx_sampled_w_bytes(ctypes.byref(g), 0, 1) == w * 2
+    assert L.btx_sampled_w_bytes(ctypes.byref(g), 1, 0) == 2 * w * 4 + w * 4
+    assert L.btx_sampled_w_bytes_lanes(ctypes.byref(g), 1, 1, 4) == (1 + 4) * w * 2 + w * 4
+    assert L.btx_sampled_w_bytes_lanes(ctypes.byref(g), 0, 1, 4) == 4 * w * 2
+    assert L.btx_sampled_w_bytes_lanes(ctypes.byref(g), 1, 1, 0) == 0
     g.N = 100  # ragged n-tile: padded to 128 channels
     assert L.btx_sampled_w_bytes(ctypes.byref(g), 0, 1) == 128 * 576 * 2
     r = _lib.Rng(1, 2, 3, None)

@@ -1,0 +1,185 @@
+"""GPU: MC sample lanes (btx_contract_fwd_lanes / btx_sample_weights_lanes, ABI 5) and the tall-strip tiles of the
+tap-unrolled kernel.
+
+A lane must compute BIT FOR BIT what a single-sample launch with its sample index computes: the noise indices are
+relative to the lane's own tensors, the accumulation order of an output element does not depend on the tiling.  That is
+what lets MC samples be evaluated 4 at a time per launch, and sharded over ranks, without the results depending on how
+they were grouped."""
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+LAYER_CASES = [
+    # (class, kwargs, input shape per lane, what it exercises)
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=False), (4, 64, 56, 56)),   # taps, tall 9x28 strips
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=3, padding=1, bias=True), (3, 64, 28, 28)),   # taps, tall 9 rows
+    ("Conv2dFlipout", dict(in_channels=128, out_channels=64, kernel_size=3, padding=1, bias=False), (5, 128, 14, 14)),  # tall 18 rows, 4 channel blocks
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=False), (40, 64, 7, 7)),    # tall 36 rows over many images
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=64, kernel_size=3, padding=1, bias=False), (2, 32, 13, 11)),   # odd extents
+    ("Conv2dReparameterization", dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=True), (4, 64, 28, 28)),
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=3, stride=2, padding=1, bias=False), (4, 64, 28, 28)),  # taps2
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=1, stride=2, bias=False), (4, 64, 28, 28)),   # LDS-DMA kernel
+    ("Conv2dFlipout", dict(in_channels=32, out_channels=32, kernel_size=5, padding=2, bias=False), (2, 32, 12, 12)),    # run-time-tap patch kernel
+    ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 64, 64)),  # row-fused stem
+    ("LinearFlipout", dict(in_features=512, out_features=1000), (8, 512)),
+    ("LinearReparameterization", dict(in_features=128, out_features=64), (8, 128)),
+    ("Conv2dFlipout", dict(in_channels=20, out_channels=24, kernel_size=3, padding=1), (2, 20, 9, 9)),                 # channel-padded -> gather/regstage
+]
+
+
+@pytest.mark.parametrize("prec,act", [("bf16", torch.bfloat16), ("f32", torch.float32)])
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] + str(c[2]) for c in LAYER_CASES])
+def test_lanes_equal_single_sample_launches(case, prec, act):
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    cls, kw, xshape = case
+    dev = _dev()
+    bt.manual_seed(1234)
+    torch.manual_seed(7)
+    layer = getattr(L, cls)(**kw).to(dev)
+    layer.precision = prec
+    S = 3
+    bs = xshape[0]
+    shared = cls.endswith("Flipout") and kw.get("in_channels") in (3, 20)  # first-layer style: one input for all lanes
+    xs = [torch.randn(*xshape, device=dev).to(act) for _ in range(1 if shared else S)]
+    if len(xshape) == 4:
+        xs = [x.contiguous(memory_format=torch.channels_last) for x in xs]
+    idx = [11, 12, 40]
+    with torch.no_grad():
+        singles = []
+        from bayesian_torch_amd import functional as BF
+        with BF.concurrent_plan():  # the K split of a launch with lanes is that of the throughput plan of ONE lane
+            for l in range(S):
+                bt.set_sample_lanes(layer, None)
+                singles.append(layer._forward_hip(xs[0 if shared else l], sample_idx=idx[l]).float())
+        for presample in (False, True):
+            x_all = xs[0] if shared else torch.cat(xs, 0)
+            if len(xshape) == 4:
+                x_all = x_all.contiguous(memory_format=torch.channels_last)
+            bt.set_sample_lanes(layer, idx, batch=bs)
+            if presample:
+                layer._forward_hip(x_all)   # records the input shape presample_item needs
+                bt.set_sample_lanes(layer, idx, batch=bs, presample=True)
+            out = layer._forward_hip(x_all).float()
+            assert out.shape[0] == S * bs
+            for l in range(S):
+                assert torch.equal(out[l * bs:(l + 1) * bs], singles[l]), "lane %d differs (presample=%s)" % (l, presample)
+        bt.set_sample_lanes(layer, None)
+
+
+@pytest.mark.parametrize("cin,cout,hw,bs", [(64, 64, 56, 8), (128, 128, 28, 8), (256, 256, 14, 16), (512, 512, 7, 64), (64, 64, 30, 3)])
+def test_tall_strip_tiles_vs_oracle_chain(cin, cout, hw, bs):
+    """the tall-strip tiling (tile rows / widths that do not divide the map) against the reference op chain evaluated by
+    torch in f32 with the noise BTX-RNG v1 defines: same bars as tests/test_gpu_at_size.py"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    from oracle import bt_ref
+    dev = _dev()
+    bt.manual_seed(5)
+    torch.manual_seed(3)
+    layer = L.Conv2dFlipout(cin, cout, 3, padding=1, bias=True).to(dev)
+    x = torch.randn(bs, cin, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    for prec, bar in (("f32", 1e-5), ("bf16", 1e-2)):
+        layer.precision = prec
+        xin = x if prec == "f32" else x.to(torch.bfloat16)
+        with torch.no_grad():
+            out = layer._forward_hip(xin, sample_idx=9).float()
+            nz = layer.materialize_noise(9, tuple(x.shape), tuple(out.shape), x.dtype)
+            mu, rho = layer._w()
+            ref = bt_ref.flipout_forward(xin.float(), mu, rho, layer.mu_bias, layer.rho_bias, nz["eps_w"], nz.get("eps_b"),
+                                         nz["sign_in"].float(), nz["sign_out"].float(), dict(kind="conv", nd=2, stride=(1, 1), padding=(1, 1),
+                                                                             dilation=(1, 1), groups=1))
+        rel = float((out - ref).norm() / ref.norm())
+        assert rel < bar, (prec, rel)
+
+
+def test_graphed_mc_launch_lanes_equal_eager_samples():
+    """mc.GraphedMC(lanes=4, lane_mode="launch") on the fused ResNet18: the per-sample logits of a replay are those of
+    eager single-sample forwards (bit-exact), with and without cached mean tiles"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd.models.resnet import resnet18
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    dev = _dev()
+    bt.manual_seed(99)
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Flipout",
+                          moped_enable=False, moped_delta=0.5))
+    m = m.to(dev).eval()
+    for mod in m.modules():  # bf16 activations: the stock BN layers follow, the variational parameters stay f32
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.to(torch.bfloat16)
+    bt.assign_layer_ids(m)
+    bt.set_precision("bf16")
+    fuse_resnet(m)
+    x = torch.randn(8, 3, 224, 224, device=dev).to(torch.bfloat16)
+    idx = [3, 4, 21, 22]
+    try:
+        from bayesian_torch_amd import functional as BF
+        with torch.no_grad(), BF.concurrent_plan():
+            eager = []
+            for i in idx:
+                bt.set_sample_index(m, i, presample=True)
+                eager.append(m(x).float().clone())
+        g = mc.GraphedMC(m, x, kl=0.0, lanes=4, keep_logits=True)
+        for rep in range(2):  # second replay: the mean tiles are the cached ones
+            g.run_many(idx)
+            torch.cuda.synchronize()
+            for l in range(4):
+                assert torch.equal(g.lane_logits[l].float(), eager[l]), (rep, l)
+        stats = mc.unpack(g.packed, 8, 1000)
+        assert abs(float(stats["samples"]) - 8.0) < 0.5
+        g.close()
+        # and the eager lanes driver
+        packed = mc.mc_forward(m, x, 6, sample_offset=100, lanes=4, reduce=False)
+        with BF.concurrent_plan():
+            ref = mc.mc_forward(m, x, 6, sample_offset=100, lanes=1, reduce=False)
+        assert torch.allclose(packed, ref, rtol=1e-6, atol=1e-7)
+    finally:
+        bt.set_precision("f32")
+
+
+def test_rank_partition_of_samples_is_rank_count_independent():
+    """SURVEY §8e on the real HIP ResNet18: R emulated ranks each run {s : s mod R == r} (mc_forward(reduce=False, rank,
+    world)); the SUM of their packed vectors — what the one RCCL all-reduce computes — equals the single-rank result.
+    Per-sample logits are bit-identical whatever R (previous test); the sums differ by f32 summation order only."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd.models.resnet import resnet18
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    dev = _dev()
+    bt.manual_seed(5)
+    torch.manual_seed(1)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Flipout",
+                          moped_enable=False, moped_delta=0.5))
+    m = m.to(dev).eval()
+    for mod in m.modules():  # bf16 activations: the stock BN layers follow, the variational parameters stay f32
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.to(torch.bfloat16)
+    bt.assign_layer_ids(m)
+    bt.set_precision("bf16")
+    fuse_resnet(m)
+    x = torch.randn(4, 3, 224, 224, device=dev).to(torch.bfloat16)
+    S = 16
+    try:
+        one = mc.mc_forward(m, x, S, with_kl=True, reduce=False, lanes=4, rank=0, world=1)
+        for R in (2, 4, 8):
+            tot = torch.zeros_like(one)
+            for r in range(R):
+                tot += mc.mc_forward(m, x, S, with_kl=True, reduce=False, lanes=4 if R < 8 else 2, rank=r, world=R)
+            assert abs(float(tot[-1]) - S) < 0.5
+            assert torch.allclose(tot, one, rtol=1e-5, atol=1e-6), R
+    finally:
+        bt.set_precision("f32")

@@ -203,10 +203,14 @@ if __name__ == "__main__":
     ap.add_argument("--shape", default="64,64,56,1,3")
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--warm", type=int, default=3)
+    ap.add_argument("--throughput-plan", action="store_true")
     a = ap.parse_args()
+    if a.throughput_plan:
+        from bayesian_torch_amd import functional as _BF
+        _BF._CONCURRENT = True
     if "one" in a.what or "timeone" in a.what:
         c = [int(v) for v in a.shape.split(",")]
-        us = one(a.prec.split(",")[0], a.iters, *c)
+        us = one(a.prec.split(",")[0], a.iters, *c, bs=a.bs)
         if "timeone" in a.what:
             print("shape %s: %.1f us / launch" % (a.shape, us))
     if "gtime" in a.what:

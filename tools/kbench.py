@@ -60,10 +60,13 @@ def main():
     ap.add_argument("--typ", default="Flipout")
     ap.add_argument("--prec", default="bf16")
     ap.add_argument("--bs", type=int, default=64)
+    ap.add_argument("--throughput-plan", action="store_true", help="BTX_FLAG_CONCURRENT on every launch: the K split of launches that share the GPU / carry MC sample lanes")
     a = ap.parse_args()
     if a.shapes == ["all"]:
         a.shapes = RN18_ALL
     from bayesian_torch_amd import layers as L
+    from bayesian_torch_amd import functional as BF
+    BF._CONCURRENT = bool(a.throughput_plan)
     dev = torch.device("cuda:0")
     act = torch.bfloat16 if a.prec == "bf16" else torch.float32
     for sh in a.shapes:
