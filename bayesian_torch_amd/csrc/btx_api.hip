@@ -1130,6 +1130,38 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     p.pt_taps = pt.taps; p.pt_kg = pt.kg; p.pt_lds_g = pt.lds_g;
     p.pt_tall = pt.tall; p.pt_P = pt.P; p.pt_Wt = pt.Wt; p.pt_ncs = pt.ncs;
     p.fd_P = make_fastdiv((uint32_t)pt.P); p.fd_Wt = make_fastdiv((uint32_t)pt.Wt); p.fd_ncs = make_fastdiv((uint32_t)pt.ncs);
+    // Persistent form of the tap-unrolled kernel (btx_contract_taps3.h): about two workgroups per CU, each walking one
+    // tile position through the images of all lanes; the K loop runs across tile boundaries and the store side works
+    // from the fragment registers.  bf16 in and out, 3x3, plain tiles, one K split, an even number of channel blocks,
+    // whole 64-channel n-tiles, 32-aligned s_out words, hashed signs.  MEASUREMENT ONLY (BTX_PERSIST=1 in tuning builds;
+    // the shipped library never takes it): bit-identical results, but hipcc cannot hold the Flipout K loop plus the
+    // cross-tile state in 256 VGPRs — one or two spill reloads per K-stage, each a vmcnt(0) that drains the DMA ring
+    // (profiles/r03_persistent_ab.txt: 359 vs 135 us on the 56x56 layer at batch 256).  The Reparameterization
+    // instantiation allocates cleanly (222 VGPRs, no scratch).
+    {
+      const int bk = NG * 8;
+      const int ncb = pl.Cg / bk;
+      const long long x_all = (long long)p.x_bytes + (long long)(lanes - 1) * (lanes > 1 ? ln->x_stride : 0);
+      const bool ok = pt.taps == 33 && pt.kg == 1 && !pt.tall && (g->NB % pt.G) == 0 && pl.ksplits == 1 && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 &&
+                      out_bf16 && (ncb % 2) == 0 && (pl.Ng % 64) == 0 && (g->N % 32) == 0 && !(noise && (noise->sign_in || noise->sign_out)) &&
+                      (pt.astage / 16) >= 1024 && x_all < 0xfff00000LL && tune_env("BTX_PERSIST") && !tune_env("BTX_NO_PERSIST");
+      if (ok) {
+        static int n_cu = 0;
+        if (!n_cu) {
+          int dev = 0;
+          hipDeviceProp_t prop;
+          if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+          if (n_cu <= 0) n_cu = 256;
+        }
+        // a workgroup = one (row tile, n-tile, group) position x a range of image groups: `nseg` ranges per position
+        const long long combos = (long long)pt.rtiles * pl.ntiles * g->groups;
+        const long long igt = (long long)lanes * (g->NB / pt.G);
+        long long nseg = (2LL * n_cu) / combos;
+        if (nseg < 1) nseg = 1;
+        if (nseg > igt) nseg = igt;
+        p.pt_persist = (int)(combos * nseg);
+      }
+    }
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg * lanes, st)
                                  : launch_contract_patch_f32(kind, p, pl.nwg * lanes, st);
   } else if (dma)

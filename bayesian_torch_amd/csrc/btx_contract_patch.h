@@ -28,6 +28,7 @@
 #include "btx_mma.h"
 #include "btx_contract_taps.h"
 #include "btx_contract_taps2.h"
+#include "btx_contract_taps3.h"
 
 namespace btx {
 
@@ -378,6 +379,24 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
     if (kind == 0) BTX_LAUNCH_T2(0); else BTX_LAUNCH_T2(1);
 #undef BTX_LAUNCH_T2
     return (int)hipGetLastError();
+  }
+  if constexpr (PREC == 1) {
+    if (p.pt_taps == 33 && p.pt_persist > 0) {  // persistent form (btx_contract_taps3.h): the grid is pt_persist workgroups
+#define BTX_LAUNCH_T3(KIND)                                                                                       \
+  do {                                                                                                            \
+    auto kfn = contract_taps3_kernel<KIND>;                                                                       \
+    static bool attr_done = false;                                                                                \
+    if (!attr_done) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);   \
+      if (e != hipSuccess) return (int)e;                                                                         \
+      attr_done = true;                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kfn, dim3(p.pt_persist), dim3(256), p.pt_lds, st, p);                                      \
+  } while (0)
+      if (kind == 0) BTX_LAUNCH_T3(0); else BTX_LAUNCH_T3(1);
+#undef BTX_LAUNCH_T3
+      return (int)hipGetLastError();
+    }
   }
   if (p.pt_taps == 33) {  // 3x3, 4-wave K-groups: the tap-unrolled kernel (btx_contract_taps.h)
 #define BTX_LAUNCH_TP(KIND, KG)                                                                                    \
