@@ -670,10 +670,10 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
     const double eff_old = (double)pl->M / ((double)mt_old * 256.0);
     PatchPlan tp = *pt;
     const double eff_tall = tall_tile(g, *pl, 256, 352, &tp);
-    // measured (tools/kbench.py --throughput-plan, batch 256 / 512): the heavier tile (4 full waves, a store side 50 %
-    // longer) pays off only where it removes >= ~15 % of the workgroups (28x28: 19 %, 14x14: 16 %; 56x56: 9 % and 7x7:
-    // 6 % lose)
-    if (eff_tall > eff_old * 1.12) *pt = tp;
+    // measured (tools/kbench.py --throughput-plan, batch 256 / 512 = the tiles of 4 / 8 MC sample lanes): the heavier
+    // tile (4 full waves, a store side 50 % longer) pays off only where it removes >= ~15 % of the workgroups (28x28:
+    // 19 %, +3 / +8 %; 14x14: 16 %, -5 / +2 %); on 56x56 (9 % fewer workgroups) and 7x7 (6 %) it loses 4-7 %
+    if (eff_tall > eff_old * 1.15) *pt = tp;
   }
   const int pieces = (pt->PP + 15) / 16;
   pt->NI = (pieces + pt->nw - 1) / pt->nw;

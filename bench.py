@@ -660,7 +660,7 @@ def main():
                     "(BASELINE cfg4: 32 over 8 GPUs)")
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/residual as separate torch ops")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every MC sample from Python")
-    ap.add_argument("--lanes", type=int, default=4, help="MC samples evaluated by one hipGraph replay; independent noise, "
+    ap.add_argument("--lanes", type=int, default=8, help="MC samples evaluated by one hipGraph replay; independent noise, "
                     "identical results to one at a time")
     ap.add_argument("--lane-mode", default="launch", choices=["launch", "streams"], help="launch: the samples of a replay "
                     "are lanes of ONE launch per layer (btx_contract_fwd_lanes); streams: one launch per (layer, sample), "
