@@ -15,32 +15,16 @@ the backward: eps and the Flipout signs are regenerated.
                  drho = dW_delta * eps * sigmoid(rho) are elementwise follow-ups here.
 """
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 from . import functional as BF
 from . import rng as _rng
 
 
-def _weight_grad(x, dy, w_shape, op):
-    """corr(x, dy) in the layer's logical weight layout (ATen)"""
-    nd = op.nd
-    if nd == 0:
-        return dy.reshape(-1, dy.shape[-1]).t().float() @ x.reshape(-1, x.shape[-1]).float()
-    st, pd, dl = op.stride[3 - nd:], op.padding[3 - nd:], op.dilation[3 - nd:]
-    if not op.transposed:
-        fn = {1: torch.nn.grad.conv1d_weight, 2: torch.nn.grad.conv2d_weight, 3: torch.nn.grad.conv3d_weight}[nd]
-        return fn(x, w_shape, dy, st, pd, dl, op.groups).float()
-    w = torch.zeros(w_shape, dtype=x.dtype, device=x.device, requires_grad=True)
-    with torch.enable_grad():
-        out = BF.contract_aten(x, w, None, op)
-    return torch.autograd.grad(out, w, dy)[0].float()
-
-
-def _data_grad_hip(layer, dy, x_shape, nz, sample_idx, hashed_signs):
-    """dx through libbtx: the contraction of dy with the layer's own (mu, sigma*eps) on the transposed geometry"""
+def _data_grad_hip(layer, dy, x_shape, nz, sample_idx, hashed_signs, mu, rho):
+    """dx through libbtx: the contraction of dy with the (mu, sigma*eps) the FORWARD used (the tensors autograd saved) on
+    the transposed geometry"""
     op = layer._op
-    mu, rho = layer._w()
     mu, rho, eps = mu.detach(), rho.detach(), nz["eps_w"]
     kind = _lib.KIND_FLIPOUT if layer._family == "flipout" else _lib.KIND_REPARAM
     nd = op.nd
@@ -87,13 +71,13 @@ class ContractFn(torch.autograd.Function):
         with torch.no_grad():
             out = layer._forward_hip(x, sample_idx=sample_idx)
         ctx.layer, ctx.sample_idx = layer, sample_idx
-        ctx.save_for_backward(x, rho, rho_b)
+        ctx.save_for_backward(x, mu, rho, rho_b)  # mu: the data gradient contracts with it (autograd's version check applies)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         layer, s = ctx.layer, ctx.sample_idx
-        x, rho, rho_b = ctx.saved_tensors
+        x, mu_s, rho, rho_b = ctx.saved_tensors
         op = layer._op
         flip = layer._family == "flipout"
         dy = dy.contiguous() if op.nd == 0 else dy
@@ -145,7 +129,7 @@ class ContractFn(torch.autograd.Function):
                     drho_b = (dbd if flip else db) * nz["eps_b"] * torch.sigmoid(rho_b.detach())
             if ctx.needs_input_grad[2]:
                 hashed = flip and not padded
-                dx = _data_grad_hip(layer, dy, tuple(x.shape), nz, s, hashed)
+                dx = _data_grad_hip(layer, dy, tuple(x.shape), nz, s, hashed, mu_s, rho)
                 if dx.dtype != x.dtype:
                     dx = dx.to(x.dtype)
         return None, None, dx, dmu, drho, dmu_b, drho_b
@@ -169,9 +153,16 @@ class KlFn(torch.autograd.Function):
         grads, outs = [], []
         for i, (pm, ps, pmt, pst, op) in enumerate(meta):
             mu, rho = params[2 * i], params[2 * i + 1]
-            if pmt is None and op is not None:  # storage-order views: gradients share the parameter's strides
-                gm, gr = torch.empty_like(mu), torch.empty_like(rho)
-                grads.append((BF.gemm_major_view(gm, op), BF.gemm_major_view(gr, op)))
+            if pmt is None and op is not None:
+                # The kernel reads (mu, rho) in GEMM-major order (_entries) — a zero-copy view of the parameter's storage or,
+                # for parameters that are not stored that way (ConvTranspose with groups > 1, a parameter re-assigned
+                # contiguous), a packed copy — and writes the gradients in the SAME element order: into GEMM-major buffers,
+                # handed back as logical-shape views of those buffers.
+                shape = tuple(mu.shape)
+                gpm = torch.empty_like(BF.gemm_major_view(mu, op))
+                gpr = torch.empty_like(gpm)
+                grads.append((gpm, gpr))
+                gm, gr = BF.gemm_major_logical_view(gpm, shape, op), BF.gemm_major_logical_view(gpr, shape, op)
             else:
                 gm = torch.empty(mu.shape, dtype=torch.float32, device=mu.device)
                 gr = torch.empty(rho.shape, dtype=torch.float32, device=rho.device)

@@ -627,6 +627,21 @@ def fill_sign_hip(n, device, seed, sample_idx, layer_id, rng_stream):
     return out
 
 
+def gemm_major_logical_view(buf, w_shape, op):
+    """The logical-shape tensor (reference layout [out,in] / [Cout,Cin/g,*k] / [Cin,Cout/g,*k]) over a GEMM-major buffer
+    `buf` (what gemm_major_view / pack_gemm_major produce): a strided VIEW of `buf` where one exists — the inverse of
+    gemm_major_param — else (ConvTranspose with groups > 1) an unpacked copy."""
+    nd = op.nd
+    if nd == 0:
+        return buf.reshape(w_shape)
+    k = tuple(w_shape[2:])
+    if not op.transposed:
+        return buf.reshape((w_shape[0],) + k + (w_shape[1],)).permute((0, nd + 1) + tuple(range(1, nd + 1)))
+    if op.groups == 1:
+        return buf.reshape((w_shape[1],) + k + (w_shape[0],)).permute((nd + 1, 0) + tuple(range(1, nd + 1)))
+    return unpack_gemm_major(buf.reshape(-1), w_shape, op)
+
+
 def unpack_gemm_major(flat, w_shape, op):
     """inverse of pack_gemm_major for a flat [N*taps*Cg] tensor -> logical parameter layout."""
     if op.nd == 0:

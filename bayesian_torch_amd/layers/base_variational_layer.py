@@ -288,6 +288,10 @@ class _VariationalNd(BaseVariationalLayer_):
         return None
 
     def _forward_hip(self, x, noise=None, sample_idx=None, epilogue=None, gather=False):
+        if self._op.nd > 0 and x.dim() == self._op.nd + 1:  # unbatched [C,*sp], as ATen's convolutions accept
+            if epilogue is not None and epilogue.get("residual") is not None:
+                epilogue = dict(epilogue, residual=epilogue["residual"].unsqueeze(0))
+            return self._forward_hip(x.unsqueeze(0), noise, sample_idx, epilogue, gather).squeeze(0)
         mu, rho = self._w()
         mu_p, rho_p = BF.gemm_major_view(mu, self._op), BF.gemm_major_view(rho, self._op)
         lanes, lane_batch = self._lanes()
@@ -355,12 +359,15 @@ class _VariationalNd(BaseVariationalLayer_):
     def forward_fused(self, x, scale=None, shift=None, residual=None, relu=False, pool=False):
         """`relu?(forward(x) * scale[c] + shift[c] (+ residual))` with the affine / residual / ReLU
         folded into the store of the HIP contraction (eval-mode BatchNorm folds into scale/shift).  Returns `out` only.
-        CPU tensors / autograd evaluate the same expression with ATen ops."""
-        if self._use_hip(x):
+        With autograd (any of x / the parameters requires grad) the contraction runs through ContractFn and the affine,
+        residual and ReLU as ATen ops, so gradients flow; CPU tensors evaluate the whole expression with ATen ops."""
+        if self._use_hip(x) and not self._needs_grad(x):
             return self._forward_hip(x, epilogue=dict(scale=scale, shift=shift, residual=residual, relu=relu, pool=pool))
         if pool:
-            raise _lib.BtxError("forward_fused(pool=True) is a GPU path (pool_fusable)")
-        out = self._forward_aten(x, False)
+            raise _lib.BtxError("forward_fused(pool=True) is an inference-only GPU path (pool_fusable)")
+        # autograd (a fused model run with grad enabled) or CPU: the same expression as differentiable ops — the
+        # contraction through ContractFn on the GPU, the affine / residual / ReLU as ATen ops
+        out = self.forward(x, return_kl=False) if self._use_hip(x) else self._forward_aten(x, False)
         shape = (1, -1) + (1,) * self._op.nd if self._op.nd else (1, -1)
         if scale is not None:
             out = out * scale.view(shape).to(out.dtype)
@@ -500,3 +507,60 @@ class _VariationalNd(BaseVariationalLayer_):
         if return_kl:
             return out, kl
         return out
+
+
+class _VariationalLSTM(BaseVariationalLayer_):
+    """LSTM cell unrolled over time on two Bayesian Linear layers (input-to-hidden `ih`, hidden-to-hidden `hh`, both
+    in -> 4*out) — reference layers/variational_layers/rnn_variational.py:46-153 and layers/flipout_layers/
+    rnn_flipout.py:46-153.  X is [batch, seq, in_features]; every time step calls both Linear layers, i.e. draws fresh
+    weight noise per step as the reference does (on a GPU: two fused sample-and-GEMM launches per step, consecutive
+    BTX-RNG sample indices).  Returns (hidden_seq, (hidden_seq, cell_seq)[, kl]), kl = the per-step KL terms summed over
+    the steps — the reference's accounting.  `_linear_cls` is the Linear class of the family."""
+
+    _linear_cls = None
+
+    def __init__(self, in_features, out_features, prior_mean=0, prior_variance=1, posterior_mu_init=0,
+                 posterior_rho_init=-3.0, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.prior_mean, self.prior_variance = prior_mean, prior_variance
+        self.posterior_mu_init = posterior_mu_init,   # 1-tuples: a quirk of the reference's attribute surface
+        self.posterior_rho_init = posterior_rho_init,
+        self.bias = bias
+        kw = dict(prior_mean=prior_mean, prior_variance=prior_variance, posterior_mu_init=posterior_mu_init,
+                  posterior_rho_init=posterior_rho_init, bias=bias)
+        self.ih = self._linear_cls(in_features=in_features, out_features=out_features * 4, **kw)
+        self.hh = self._linear_cls(in_features=out_features, out_features=out_features * 4, **kw)
+
+    def kl_loss(self):
+        return self.ih.kl_loss() + self.hh.kl_loss()
+
+    def forward(self, X, hidden_states=None, return_kl=True):
+        if self.dnn_to_bnn_flag:
+            return_kl = False
+        nb, steps, _ = X.size()
+        hs = self.out_features
+        if hidden_states is None:
+            h_t = torch.zeros(nb, hs, device=X.device, dtype=X.dtype)
+            c_t = torch.zeros(nb, hs, device=X.device, dtype=X.dtype)
+        else:
+            h_t, c_t = hidden_states
+        hidden, cells, kl = [], [], 0
+        for t in range(steps):
+            gi, kl_i = self.ih(X[:, t, :])
+            gh, kl_h = self.hh(h_t)
+            gates = gi + gh
+            kl = kl + kl_i + kl_h
+            i_t, f_t = torch.sigmoid(gates[:, :hs]), torch.sigmoid(gates[:, hs:2 * hs])
+            g_t, o_t = torch.tanh(gates[:, 2 * hs:3 * hs]), torch.sigmoid(gates[:, 3 * hs:])
+            c_t = f_t * c_t + i_t * g_t
+            h_t = o_t * torch.tanh(c_t)
+            hidden.append(h_t)
+            cells.append(c_t)
+        hidden_seq = torch.stack(hidden, dim=1).contiguous()  # [batch, seq, out]
+        c_ts = torch.stack(cells, dim=1).contiguous()
+        if self._family == "flipout":
+            self.kl = kl  # reference rnn_flipout.py:150
+        if return_kl:
+            return hidden_seq, (hidden_seq, c_ts), kl
+        return hidden_seq, (hidden_seq, c_ts)

@@ -1,2 +1,3 @@
 from .conv_variational import *
 from .linear_variational import *
+from .rnn_variational import *

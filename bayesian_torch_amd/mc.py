@@ -175,9 +175,15 @@ class GraphedMC:
         self._lane_packed = [None] * self.lanes
         self._streams = [torch.cuda.Stream(dev) for _ in range(self.lanes)] if self.lanes > 1 else []
         from . import functional as BF
-        conc_prev = BF._CONCURRENT
         # several samples in flight: plan every launch for device throughput (no split-K through HBM to fill idle CUs)
-        BF._CONCURRENT = (self.lanes > 1) if concurrent_hint is None else bool(concurrent_hint)
+        with BF.concurrent_plan((self.lanes > 1) if concurrent_hint is None else bool(concurrent_hint)):
+            self._capture_streams(dev, warmup)
+        for pk in self._lane_packed:
+            pk.zero_()
+        for m in self._layers:
+            m._btx_sample_dev = self.sample_dev
+
+    def _capture_streams(self, dev, warmup):
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
@@ -203,11 +209,6 @@ class GraphedMC:
                 for k in range(1, self.lanes):  # fold the lanes' statistics into lane 0's buffer
                     self._lane_packed[0].add_(self._lane_packed[k])
                     self._lane_packed[k].zero_()
-        BF._CONCURRENT = conc_prev
-        for pk in self._lane_packed:
-            pk.zero_()
-        for m in self._layers:
-            m._btx_sample_dev = self.sample_dev
 
     # ---- lane_mode "launch": the MC samples of a replay are lanes of every layer's launch -----------------------------
     def _init_launch_lanes(self, warmup, keep_logits):

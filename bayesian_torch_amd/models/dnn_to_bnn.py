@@ -5,7 +5,7 @@ NAME contains "Conv" or "Linear" (so ConvTranspose* and look-alike user classes 
 looked up as `<ClassName><params["type"]>` in `bayesian_torch_amd.layers`; the required dict keys are
 prior_mu, prior_sigma, posterior_mu_init, posterior_rho_init, type, moped_enable (KeyError if absent), moped_delta;
 `output_padding` / `padding_mode` are NOT forwarded; converted layers get `dnn_to_bnn_flag = True` (forward returns
-only `out`).  LSTM layers are outside this build's scope and raise.
+only `out`).  nn.LSTM children become LSTM<type> (two Bayesian Linear layers per time step).
 """
 import torch
 
@@ -47,6 +47,19 @@ def bnn_conv_layer(params, d):
     return bnn_layer
 
 
+def bnn_lstm_layer(params, d):
+    """reference models/dnn_to_bnn.py:106-122: nn.LSTM(input_size, hidden_size) -> LSTM<type>(in, out); MOPED is not
+    defined for LSTM layers (the reference prints the same warning and converts with the default init)."""
+    layer_fn = getattr(bayesian_layers, d.__class__.__name__ + params["type"])
+    bnn_layer = layer_fn(in_features=d.input_size, out_features=d.hidden_size, prior_mean=params["prior_mu"],
+                         prior_variance=params["prior_sigma"], posterior_mu_init=params["posterior_mu_init"],
+                         posterior_rho_init=params["posterior_rho_init"], bias=d.bias is not None)
+    if params["moped_enable"]:
+        print("WARNING: MOPED method is not supported for LSTM layers!!!")
+    bnn_layer.dnn_to_bnn_flag = True
+    return bnn_layer
+
+
 def dnn_to_bnn(m, bnn_prior_parameters):
     for name, child in list(m._modules.items()):
         if child is None:
@@ -59,7 +72,7 @@ def dnn_to_bnn(m, bnn_prior_parameters):
         elif "Linear" in cname:
             setattr(m, name, bnn_linear_layer(bnn_prior_parameters, child).to(child.weight.device))
         elif "LSTM" in cname:
-            raise NotImplementedError("LSTM conversion is outside the MI355X hot-path build (SURVEY.md §2 #9)")
+            setattr(m, name, bnn_lstm_layer(bnn_prior_parameters, child).to(next(child.parameters()).device))
     return
 
 

@@ -112,8 +112,9 @@ def fuse_resnet(model):
                     and mp.padding in (1, (1, 1)) and mp.dilation in (1, (1, 1)) and not mp.ceil_mode
                     and not mp.return_indices and not torch.is_grad_enabled()):
                 return False
+            from .. import functional as BF
             cache = self.__dict__.setdefault("_stem_pool_ok", {})
-            key = (tuple(x.shape), x.dtype, x.device)
+            key = (tuple(x.shape), x.dtype, x.device, self.conv1.precision or BF.get_precision())
             if key not in cache:
                 cache[key] = bool(self.conv1.pool_fusable(x))
             return cache[key]

@@ -54,10 +54,13 @@ def MOPED(model, det_model, det_checkpoint, delta):
             if hasattr(layer, "refresh_priors"):
                 layer.refresh_priors()
         elif name.startswith("Batch"):
-            layer.weight.data.copy_(det_layer.weight.data)
-            if layer.bias is not None:
-                layer.bias.data.copy_(det_layer.bias.data)
-            layer.running_mean.data.copy_(det_layer.running_mean.data)
-            layer.running_var.data.copy_(det_layer.running_var.data)
-            layer.num_batches_tracked.data.copy_(det_layer.num_batches_tracked.data)
+            # through the tensors themselves (not .data): the in-place writes bump _version, which is what the folded
+            # BatchNorm of models.fuse keys its cached (scale, shift) on
+            with torch.no_grad():
+                layer.weight.copy_(det_layer.weight)
+                if layer.bias is not None:
+                    layer.bias.copy_(det_layer.bias)
+                layer.running_mean.copy_(det_layer.running_mean)
+                layer.running_var.copy_(det_layer.running_var)
+                layer.num_batches_tracked.copy_(det_layer.num_batches_tracked)
     return model

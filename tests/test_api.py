@@ -258,3 +258,34 @@ def test_presample_skips_layers_the_dma_kernels_do_not_take():
     ok = L.Conv2dFlipout(64, 64, 3, padding=1)
     ok._btx_last_xshape = (2, 64, 8, 8)
     assert ok.presample_item(0, "bf16") is not None and ok.presample_item(0, "f32") is not None
+
+
+LSTM_CASES = [("lstm_reparam", "LSTMReparameterization", dict(in_features=12, out_features=10), 11, 22),
+              ("lstm_flipout", "LSTMFlipout", dict(in_features=16, out_features=8, bias=False), 33, 44)]
+
+
+@pytest.mark.parametrize("name,cls,kw,s_init,s_fwd", LSTM_CASES)
+def test_lstm_wrappers_match_the_reference(name, cls, kw, s_init, s_fwd):
+    """LSTM{Reparameterization,Flipout} (reference rnn_variational.py:46-153, rnn_flipout.py:46-153) on CPU: same init
+    draws, same per-step noise draws, same outputs as the reference for the same torch seeds (tests/golden/lstm.npz,
+    tools/make_golden_lstm.py) — and dnn_to_bnn converts nn.LSTM instead of raising"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lstm.npz"))
+    torch.manual_seed(s_init)
+    layer = getattr(L, cls)(**kw)
+    sd = layer.state_dict()
+    ref_sd = {k[len(name) + 4:]: z[k] for k in z.files if k.startswith(name + "/sd/")}
+    assert set(sd) == set(ref_sd)
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), ref_sd[k]), k
+    x = torch.from_numpy(z[name + "/x"])
+    torch.manual_seed(s_fwd)
+    with torch.no_grad():
+        hs, (hs2, cs), kl = layer(x)
+    assert np.array_equal(hs.numpy(), z[name + "/hidden"]) and np.array_equal(cs.numpy(), z[name + "/cells"])
+    assert float(kl) == float(z[name + "/kl"]) and float(layer.kl_loss()) == float(z[name + "/kl_loss"])
+    m = torch.nn.Sequential(torch.nn.LSTM(kw["in_features"], kw["out_features"]))
+    bt.dnn_to_bnn(m, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0,
+                          type=cls[4:], moped_enable=False, moped_delta=0.5))
+    assert m[0].__class__.__name__ == cls and m[0].dnn_to_bnn_flag
+    assert len(m[0](x)) == 2  # converted layers return no KL

@@ -209,3 +209,72 @@ def test_bf16_activations_train_with_f32_weight_gradients(kw, xshape):
             assert _rel(layer.mu_bias.grad, mbr.grad) < 1e-4 and _rel(layer.rho_bias.grad, rbr.grad) < 1e-4
     finally:
         bt.set_precision("f32")
+
+
+def test_kl_gradient_of_parameters_that_are_not_stored_gemm_major():
+    """round-2 advisor finding: KlFn.backward wrote into a packed COPY for parameters without a zero-copy GEMM-major view
+    (ConvTranspose with groups > 1; a parameter re-assigned contiguous) and returned uninitialised memory"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    from oracle import bt_ref
+    dev = _dev()
+    torch.manual_seed(0)
+    cases = [L.ConvTranspose2dFlipout(8, 12, 3, stride=2, padding=1, groups=2).to(dev),
+             L.Conv2dFlipout(16, 24, 3, padding=1).to(dev)]
+    w = cases[1].mu_kernel.data.clone(memory_format=torch.contiguous_format)
+    cases[1].mu_kernel.data = w  # reference-style MOPED: `layer.mu_kernel.data = w` (plain contiguous storage)
+    for layer in cases:
+        mu, rho = layer._w()
+        kl = layer.kl_loss()
+        g = torch.autograd.grad(kl, [mu, rho, layer.mu_bias, layer.rho_bias])
+        mu_r, rho_r = mu.detach().clone().requires_grad_(), rho.detach().clone().requires_grad_()
+        mb, rb = layer.mu_bias.detach().clone().requires_grad_(), layer.rho_bias.detach().clone().requires_grad_()
+        klr = bt_ref.kl_loss(mu_r, rho_r, mb, rb, layer.prior_mean, layer.prior_variance)
+        gr = torch.autograd.grad(klr, [mu_r, rho_r, mb, rb])
+        assert abs(float(kl) - float(klr)) <= 1e-5 * abs(float(klr))
+        for a, b in zip(g, gr):
+            assert a.shape == b.shape and _rel(a, b) < 1e-5, (layer.__class__.__name__, _rel(a, b))
+
+
+def test_fused_resnet_with_grad_enabled_gives_gradients_to_every_conv():
+    """round-2 advisor finding: forward_fused() returned a detached tensor under autograd — loss.backward() succeeded and
+    silently left every fused conv without a gradient"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.resnet import resnet18
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    dev = _dev()
+    bt.set_precision("f32")
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Flipout",
+                          moped_enable=False, moped_delta=0.5))
+    m = m.to(dev).eval()
+    bt.assign_layer_ids(m)
+    fuse_resnet(m)
+    x = torch.randn(2, 3, 64, 64, device=dev, requires_grad=True)
+    out = m(x)
+    assert out.grad_fn is not None
+    out.float().square().mean().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+    for mod in m.modules():
+        if hasattr(mod, "kl_loss"):
+            mu, rho = mod._w()
+            assert mu.grad is not None and rho.grad is not None, mod.__class__.__name__
+            assert float(mu.grad.abs().sum()) > 0
+
+
+def test_unbatched_inputs_on_the_padded_layouts():
+    """round-2 advisor finding: [C,*sp] inputs only worked for plain layers (row-fused stems and channel-padded layers
+    indexed a 4-D shape)"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    torch.manual_seed(0)
+    for layer, shape in ((L.Conv2dFlipout(3, 32, 7, stride=2, padding=3).to(dev), (3, 40, 36)),
+                         (L.Conv2dFlipout(20, 24, 3, padding=1).to(dev), (20, 9, 9)),
+                         (L.Conv2dReparameterization(16, 16, 3, padding=1).to(dev), (16, 8, 8))):
+        x = torch.randn(*shape, device=dev)
+        with torch.no_grad():
+            a = layer._forward_hip(x, sample_idx=5)
+            b = layer._forward_hip(x.unsqueeze(0), sample_idx=5)
+        assert a.dim() == 3 and torch.equal(a, b[0])

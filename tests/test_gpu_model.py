@@ -581,3 +581,41 @@ def test_unbatched_input_and_contiguous_output_layout():
         finally:
             bt.set_output_layout("channels_last")
         assert not y.is_contiguous()
+
+
+def test_lstm_wrappers_on_the_hip_linear_kernels():
+    """LSTM{Reparameterization,Flipout} on the GPU: every time step is two fused sample-and-GEMM launches with their own
+    MC sample index; the recurrence against a torch evaluation of the same cell fed with the layers' own outputs"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    bt.set_precision("f32")
+    for cls in ("LSTMReparameterization", "LSTMFlipout"):
+        torch.manual_seed(0)
+        layer = getattr(L, cls)(24, 16).to(dev)
+        x = torch.randn(5, 7, 24, device=dev)
+        calls = []
+        hooks = [m.register_forward_hook(lambda mod, inp, out: calls.append((mod, inp[0].detach(), out[0].detach())))
+                 for m in (layer.ih, layer.hh)]
+        with torch.no_grad():
+            hs, (hs2, cs), kl = layer(x)
+        for h_ in hooks:
+            h_.remove()
+        assert hs.shape == (5, 7, 16) and cs.shape == (5, 7, 16) and torch.isfinite(hs).all()
+        assert len(calls) == 14
+        # same weights, fresh noise per step: the ih outputs of two steps differ even for identical inputs
+        with torch.no_grad():
+            a, _ = layer.ih(x[:, 0, :])
+            b, _ = layer.ih(x[:, 0, :])
+        assert not torch.equal(a, b)
+        # the recurrence itself, from the gate pre-activations the two Linear layers actually produced
+        h = torch.zeros(5, 16, device=dev)
+        c = torch.zeros(5, 16, device=dev)
+        for t in range(7):
+            g = calls[2 * t][2] + calls[2 * t + 1][2]
+            assert torch.equal(calls[2 * t + 1][1], h)
+            i, f, gg, o = torch.sigmoid(g[:, :16]), torch.sigmoid(g[:, 16:32]), torch.tanh(g[:, 32:48]), torch.sigmoid(g[:, 48:])
+            c = f * c + i * gg
+            h = o * torch.tanh(c)
+            assert torch.allclose(hs[:, t], h, atol=1e-6) and torch.allclose(cs[:, t], c, atol=1e-6)
+        assert abs(float(kl) - 7 * float(layer.kl_loss())) <= 1e-4 * abs(float(kl))
