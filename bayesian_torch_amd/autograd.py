@@ -158,18 +158,22 @@ class KlFn(torch.autograd.Function):
                 # for parameters that are not stored that way (ConvTranspose with groups > 1, a parameter re-assigned
                 # contiguous), a packed copy — and writes the gradients in the SAME element order: into GEMM-major buffers,
                 # handed back as logical-shape views of those buffers.
-                shape = tuple(mu.shape)
                 gpm = torch.empty_like(BF.gemm_major_view(mu, op))
                 gpr = torch.empty_like(gpm)
                 grads.append((gpm, gpr))
-                gm, gr = BF.gemm_major_logical_view(gpm, shape, op), BF.gemm_major_logical_view(gpr, shape, op)
+                outs.append((gpm, gpr, tuple(mu.shape), op))
             else:
                 gm = torch.empty(mu.shape, dtype=torch.float32, device=mu.device)
                 gr = torch.empty(rho.shape, dtype=torch.float32, device=rho.device)
                 grads.append((gm, gr))
-            outs += [gm, gr]
+                outs.append((gm, gr, None, None))
         BF.kl_model_bwd_hip(entries, grads, g)
-        return (None,) + tuple(outs)
+        res = []
+        for gm, gr, shape, op in outs:  # (views where the layout has one, unpacked copies — made NOW — where it does not)
+            if op is not None:
+                gm, gr = BF.gemm_major_logical_view(gm, shape, op), BF.gemm_major_logical_view(gr, shape, op)
+            res += [gm, gr]
+        return (None,) + tuple(res)
 
 
 def _entries(meta, params):

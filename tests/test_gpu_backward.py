@@ -251,7 +251,7 @@ def test_fused_resnet_with_grad_enabled_gives_gradients_to_every_conv():
     m = m.to(dev).eval()
     bt.assign_layer_ids(m)
     fuse_resnet(m)
-    x = torch.randn(2, 3, 64, 64, device=dev, requires_grad=True)
+    x = torch.randn(1, 3, 224, 224, device=dev, requires_grad=True)
     out = m(x)
     assert out.grad_fn is not None
     out.float().square().mean().backward()
