@@ -861,6 +861,7 @@ static size_t patch_wt_bytes(const Plan& pl, const BtxGeom* g, int kind, int pre
   return arr * (size_t)(kind == BTX_KIND_FLIPOUT ? 1 + lanes : lanes);
 }
 static size_t pad256(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr size_t BTX_QUEUE_BYTES = 4096;  // image-group queues of the persistent kernel: one counter per tile position (<= 1024)
 
 static size_t plan_ws(const Plan& pl, const BtxGeom* g, int lanes = 1) {  // split-K partials [lane][split][M][N]
   return pl.ksplits > 1 ? (size_t)lanes * (size_t)pl.ksplits * (size_t)pl.M * (size_t)g->N * sizeof(float) : 0;
@@ -898,6 +899,7 @@ size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, i
   if (make_patch_plan(g, act_dtype, prec, flags, &c, &pt) || make_patch2_plan(g, act_dtype, prec, flags, &c, &pt)) {
     const size_t wc = pad256(plan_ws(c, g, lanes)) + patch_wt_bytes(c, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
     if (wc > wa) wa = wc;
+    if (pt.taps == 33) wa = pad256(wa) + BTX_QUEUE_BYTES;
   }
   return wa;
 }
@@ -1037,6 +1039,10 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   }
   if (need && (!ws || ws_bytes < need)) return BTX_E_WORKSPACE;
   if (need && (((uintptr_t)ws) & 15)) return BTX_E_ALIGN;
+  // the persistent tap-unrolled kernel keeps its image-group queues (BTX_QUEUE_BYTES, zeroed per launch) behind everything
+  // else; a caller whose workspace has no room for them gets the plain kernel
+  const size_t queue_off = pad256(need);
+  const bool queue_fits = ws && !(((uintptr_t)ws) & 15) && ws_bytes >= queue_off + BTX_QUEUE_BYTES;
 
   ContractParams p;
   memset(&p, 0, sizeof(p));
@@ -1144,7 +1150,8 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
       const long long x_all = (long long)p.x_bytes + (long long)(lanes - 1) * (lanes > 1 ? ln->x_stride : 0);
       const bool ok = pt.taps == 33 && pt.kg == 1 && !pt.tall && (g->NB % pt.G) == 0 && pl.ksplits == 1 && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 &&
                       out_bf16 && (ncb % 2) == 0 && (pl.Ng % 64) == 0 && (g->N % 32) == 0 && !(noise && (noise->sign_in || noise->sign_out)) &&
-                      (pt.astage / 16) >= 1024 && x_all < 0xfff00000LL && tune_env("BTX_PERSIST") && !tune_env("BTX_NO_PERSIST");
+                      (pt.astage / 16) >= 1024 && x_all < 0xfff00000LL && !mu_b && queue_fits && pt.lds + 16 <= 81920 &&
+                      (long long)g->NB * pl.Do * pl.Ho * pl.Wo * g->N * 2 < 0x7ff00000LL && tune_env("BTX_PERSIST") && !tune_env("BTX_NO_PERSIST");
       if (ok) {
         static int n_cu = 0;
         if (!n_cu) {
@@ -1159,7 +1166,12 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
         long long nseg = (2LL * n_cu) / combos;
         if (nseg < 1) nseg = 1;
         if (nseg > igt) nseg = igt;
-        p.pt_persist = (int)(combos * nseg);
+        if (combos * 4 <= (long long)BTX_QUEUE_BYTES) {
+          p.pt_persist = (int)(combos * nseg);
+          p.pt_queue = (uint32_t*)((unsigned char*)ws + queue_off);
+          hipError_t e = hipMemsetAsync(p.pt_queue, 0, (size_t)combos * 4, st);
+          if (e != hipSuccess) return (int)e;
+        }
       }
     }
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg * lanes, st)

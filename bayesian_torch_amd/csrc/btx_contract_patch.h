@@ -391,7 +391,7 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
       if (e != hipSuccess) return (int)e;                                                                         \
       attr_done = true;                                                                                           \
     }                                                                                                             \
-    hipLaunchKernelGGL(kfn, dim3(p.pt_persist), dim3(256), p.pt_lds, st, p);                                      \
+    hipLaunchKernelGGL(kfn, dim3(p.pt_persist), dim3(256), p.pt_lds + 16, st, p);                                      \
   } while (0)
       if (kind == 0) BTX_LAUNCH_T3(0); else BTX_LAUNCH_T3(1);
 #undef BTX_LAUNCH_T3

@@ -77,9 +77,16 @@ constexpr int tp_pieces(int t) {
 // fragments, H2: the MFMAs — with a barrier after each, and group 1 runs half a stage behind group 0 (one extra barrier
 // before its first stage, group 0 one after its last): one group's MFMA half sits beside the other's load half.
 template <int PREC, int KIND, int KH, int KW, int KG>
-__global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const ContractParams pk) {
+__global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const ContractParams) {
+  // The launch parameters (~180 dwords) are read through a pointer to the kernel-argument segment, once per SECTION of
+  // the kernel (prologue + K loop here, the store side at the end through a pointer the compiler cannot connect to this
+  // one): taken by value, every field any section uses is loaded at entry and stays live to its last use — 140 SGPRs
+  // spilt into VGPR lanes, and ~40 % of the prologue's and store side's VALU instructions were v_readlane/v_writelane.
+  using KArg = const __attribute__((address_space(4))) ContractParams*;
+  KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(karg));
   int logical = xcd_logical();
-  const ContractParams p = lane_view(pk, logical);
+  const ContractParams p = lane_view(*(const ContractParams*)karg, logical);
   constexpr int NW = 4, NT = 256, MI = 2, T = KH * KW;
   static_assert(T >= 5 && T <= 32, "tap-unrolled kernel: 5..32 taps");
   constexpr int MAXNI = TP_MAXNI;
@@ -108,6 +115,10 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   const uint32_t tr_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
   const uint32_t tr_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();  // constant 100 MHz reference clock
   uint32_t tr_t1 = 0, tr_t2 = 0, tr_s[4] = {0, 0, 0, 0};
+  uint32_t tr_p[6] = {0, 0, 0, 0, 0, 0};  // prologue sub-stamps (pt_tune bit 7)
+#define BTX_TR_P(i) do { __builtin_amdgcn_sched_barrier(0); tr_p[i] = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define BTX_TR_P(i) do { } while (0)
 #endif
   uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
   if (p.wg_order) fdivmod((uint32_t)logical, p.fd_mtiles, (uint32_t)p.mtiles, u_rem, u_mtile);  // weight-major (btx_api.hip)
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     }
   }
   pmask = __builtin_amdgcn_readfirstlane(pmask);
+  BTX_TR_P(0);  // patch DMAs issued
   if (ncb > 0) {  // stages 1 and 2 (taps 1, 2 of the first block)
     issue_w(1u, (uint32_t)cb0, 1);
     issue_w(2u, (uint32_t)cb0, 2);
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     }
   }
 
+  BTX_TR_P(1);  // sign keys derived (sample word arrived)
   // ---- sign role: thread t owns the words of patch pixels t and t+256 (element offset of channel 0 of the group)
   uint32_t sg_off[2];
   bool sg_ok[2];
@@ -285,11 +298,14 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     }
   };
 
+  BTX_TR_P(2);  // index arithmetic of the sign and MFMA roles
   if (ncb > 0) {
     write_signs(0, cb0);
+    BTX_TR_P(3);
     // KG == 1: patch of the first block, W(0) and W(1) landed — iteration 0 prefetches the fragments of stage 1; W(2),
     // issued last, may still be in flight.  KG == 2: a stage reads its own fragments: W(1) may be in flight as well.
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(KG == 1 ? WOPS : 2 * WOPS) : "memory");
+    BTX_TR_P(4);  // first patch + W(0), W(1) landed, all waves met
     Frag fa, fb;
     // The wave's second 32-pixel tile may be pure tile padding (224-pixel tiles: 4 rows of 56, wave 3; 196-pixel tiles:
     // wave 3 as well): its MFMAs, fragment reads and sign masks are skipped — an eighth of the block's matrix work.  The
@@ -408,22 +424,26 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
 
   // =================== epilogue (btx_epilogue.h) ============================================================
   {
-    const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
-    const int nvalid = nimg * nrow * p.Wo;
-    const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
-    const PixTall pmt = {p, row0, col0};
+    KArg karg2 = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(karg2));
+    int logical2 = xcd_logical();
+    const ContractParams pe = lane_view(*(const ContractParams*)karg2, logical2);  // the store side's own reads
+    const int nimg = min(pe.pt_G, pe.NB - img0), nrow = min(pe.pt_R, pe.Ho - row0);
+    const int nvalid = nimg * nrow * pe.Wo;
+    const uint32_t m0 = (uint32_t)(img0 * pe.Ho + row0) * (uint32_t)pe.Wo;
+    const PixTall pmt = {pe, row0, col0};
     if constexpr (KG == 1) {
-      if (tall) staged_epilogue_pm<KIND, NW, PixTall>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pmt);
-      else staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+      if (tall) staged_epilogue_pm<KIND, NW, PixTall>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pmt);
+      else staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
     } else {
       // Every wave is behind the barrier of its last stage: the whole LDS is free.  Group 1 -> exchange area
       // [chunk i][thread] x 16 B (a wave writes 1 KiB per instruction; 128 KiB Flipout, 64 KiB Reparameterization),
       // group 0 adds and runs the store.  The per-channel constants sit behind both the exchange area and the 68-KiB
       // staging area of the store.
       float* ba_lds = (float*)(smem_all + 131072);
-      const bool to_partial = p.ksplits > 1;
-      const bool has_bias = (split == 0) && (p.mu_b != nullptr);
-      const bool has_aff = !to_partial && ((p.ep_scale != nullptr) || (p.ep_shift != nullptr));
+      const bool to_partial = pe.ksplits > 1;
+      const bool has_bias = (split == 0) && (pe.mu_b != nullptr);
+      const bool has_aff = !to_partial && ((pe.ep_scale != nullptr) || (pe.ep_shift != nullptr));
       if (kg == 1) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
                     (f32x4){accd[mi][ni][4 * c], accd[mi][ni][4 * c + 1], accd[mi][ni][4 * c + 2], accd[mi][ni][4 * c + 3]};
             }
       } else if (has_bias || has_aff) {
-        ep_fill_constants<KIND>(p, rl, ba_lds, tid, ntile, group, has_bias, has_aff);
+        ep_fill_constants<KIND>(pe, rl, ba_lds, tid, ntile, group, has_bias, has_aff);
       }
       __syncthreads();
       if (kg == 0) {
@@ -462,9 +482,9 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
       }
       __syncthreads();  // the staging area of the store overlaps the exchange area
       if (kg == 0) {
-        if (tall) staged_epilogue_pm<KIND, NW, PixTall>(p, rl, accm, accd, smem_all, tid, wave, lane, ntile, group, split, pmt,
+        if (tall) staged_epilogue_pm<KIND, NW, PixTall>(pe, rl, accm, accd, smem_all, tid, wave, lane, ntile, group, split, pmt,
                                                         nullptr, -1, true, ba_lds);
-        else staged_epilogue<KIND, NW>(p, rl, accm, accd, smem_all, tid, wave, lane, ntile, group, split, m0, nvalid, nullptr,
+        else staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem_all, tid, wave, lane, ntile, group, split, m0, nvalid, nullptr,
                                        -1, true, ba_lds);
       }
     }
@@ -478,6 +498,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
       tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = (uint32_t)__builtin_amdgcn_s_memrealtime() - tr_r0; tr[3] = 0;
       tr[4] = tr_t3 - tr_t2; tr[5] = tr_t3 - tr_t0;
       if (p.pt_tune & 64) { tr[0] = tr_s[0]; tr[1] = tr_s[1]; tr[3] = tr_s[2]; tr[4] = tr_s[3]; }  // stage split instead
+      if (p.pt_tune & 128) { tr[0] = tr_p[0] - tr_t0; tr[1] = tr_p[1] - tr_t0; tr[2] = tr_p[2] - tr_t0; tr[3] = tr_p[3] - tr_t0; tr[4] = tr_p[4] - tr_t0; tr[5] = tr_t1 - tr_t0; }
       tr[6] = tr_t0; tr[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
     }
   }

@@ -45,34 +45,54 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
   const int h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nlanes = p.lanes > 1 ? p.lanes : 1;
+#ifdef BTX_PT_TRACE
+  // phase timers (tools/gpu_diag.py trace): prologue | sum of the K loops | sum of the store sides, split in five
+  const uint32_t tr_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+  const uint32_t tr_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+  uint32_t tr_pro = 0, tr_k = 0, tr_st[5] = {0, 0, 0, 0, 0}, tr_n = 0, tr_mark = 0;
+#define BTX_T3_MARK(acc) do { __builtin_amdgcn_sched_barrier(0); const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); acc += t_ - tr_mark; tr_mark = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define BTX_T3_MARK(acc) do { } while (0)
+#endif
   // The per-tile code (tile decode, patch / sign offsets of the next tile, the store side) reads the launch parameters
   // through `kp`, a pointer to the kernel-argument segment that is made opaque at the head of each of those sections:
   // the fields are then s_load-ed where they are used instead of living in SGPRs across the K loop (the by-value struct
   // is ~180 dwords: kept in registers it spilt ~500 SGPRs into VGPR lanes, and those VGPRs into scratch).
-  const ContractParams* kp = (const ContractParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  // wave-uniform values that change from tile to tile are pinned to SGPRs: left to itself the compiler carries them in
+  // VGPRs (and wraps every weight DMA, whose scalar offset they feed, in a v_readfirstlane waterfall loop)
+  auto U = [](uint32_t v) __attribute__((always_inline)) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  using KP = const __attribute__((address_space(4))) ContractParams*;  // constant address space: the reads are s_loads
+  KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
   auto refresh_q = [&]() __attribute__((always_inline)) {
-    kp = (const ContractParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
   };
   refresh_q();
+  // the same pointer as a generic one, for callees that take references (the address space is inferred back after inlining)
+  auto KPG = [&]() __attribute__((always_inline)) -> const ContractParams* { return (const ContractParams*)kp; };
 
   // ---- this workgroup's position and its range of image groups (an image group = the pt_G images of one tile)
   const uint32_t IG = (uint32_t)(p.NB / p.pt_G);             // image groups per lane (host: NB % pt_G == 0)
   const uint32_t combos = (uint32_t)(p.pt_rtiles * p.ntiles * p.groups);
-  uint32_t ig_cur, ig_end;
+  // The workgroups of a position share a queue of image groups: group `seg` is a workgroup's first tile, the following
+  // ones are drawn from the position's counter (pt_queue, zeroed by the host before the launch), one per tile, a tile
+  // ahead.  (Fixed ranges per workgroup: the slowest of the 512 workgroups took 1.24x the mean — kernel time = its time.)
+  uint32_t ig_cur, ig_end, q_first, q_combo;
   Taps3Tile cur;
   {
     const uint32_t b = (uint32_t)xcd_logical(), nseg = gridDim.x / combos, seg = b / combos, combo = b - seg * combos;
     const uint32_t rt = combo % (uint32_t)p.pt_rtiles, rest = combo / (uint32_t)p.pt_rtiles;
     const uint32_t igt = (uint32_t)nlanes * IG;
-    ig_cur = (uint32_t)(((unsigned long long)seg * igt) / nseg);
-    ig_end = (uint32_t)(((unsigned long long)(seg + 1) * igt) / nseg);
+    ig_cur = U(seg);      // host: nseg <= igt
+    ig_end = U(igt);
+    q_first = U(nseg); q_combo = U(combo);
     cur.ntile = (int)(rest % (uint32_t)p.ntiles); cur.group = (int)(rest / (uint32_t)p.ntiles);
     cur.row0 = (int)rt * p.pt_R; cur.col0 = 0;
-    cur.lane = (int)(ig_cur / IG); cur.img0 = (int)(ig_cur % IG) * p.pt_G;
+    cur.lane = (int)U(ig_cur / IG); cur.img0 = (int)U((ig_cur % IG) * (uint32_t)p.pt_G);
+    cur.ntile = (int)U((uint32_t)cur.ntile); cur.group = (int)U((uint32_t)cur.group); cur.row0 = (int)U((uint32_t)cur.row0);
   }
   if (ig_cur >= ig_end) return;
-  const uint32_t img_elems = (uint32_t)(p.H * p.W * p.C);   // elements of one input image
+  const uint32_t img_elems = U((uint32_t)(p.H * p.W * p.C));   // elements of one input image
   // byte offset in x (all lanes behind one descriptor) / element offset in the lane's own tensor of an image group
   auto xoff_of = [&](int ln, int img0) __attribute__((always_inline)) -> uint32_t {
     return (uint32_t)ln * (uint32_t)p.lane_x + (uint32_t)img0 * img_elems * (uint32_t)ESZ;
@@ -82,8 +102,8 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
   const int g_lane = (lane & 3) ^ ((lane >> 4) & 3);
   auto patch_pix = [&](const Taps3Tile& tl, int q, bool& ok) __attribute__((always_inline)) -> uint32_t {
     uint32_t ut, upc, ugi, upr;
-    fdivmod((uint32_t)q, kp->fd_ptWp, (uint32_t)kp->pt_Wp, ut, upc);
-    fdivmod(ut, kp->fd_ptRp, (uint32_t)kp->pt_Rp, ugi, upr);
+    fdivmod((uint32_t)q, KPG()->fd_ptWp, (uint32_t)kp->pt_Wp, ut, upc);
+    fdivmod(ut, KPG()->fd_ptRp, (uint32_t)kp->pt_Rp, ugi, upr);
     const int img = tl.img0 + (int)ugi, ih = tl.row0 + (int)upr - kp->ph, iw = (int)upc - kp->pw;
     ok = img < kp->NB && (unsigned)ih < (unsigned)kp->H && (unsigned)iw < (unsigned)kp->W;
     return (uint32_t)((img * kp->H + ih) * kp->W + iw);
@@ -136,15 +156,16 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
   };
   int wslot = 0;
   auto issue_w = [&](uint32_t sbase, uint32_t doff, uint32_t tap, uint32_t cb, int slot) __attribute__((always_inline)) {
-    const uint32_t soff = sbase + (tap * CgG + cb * (uint32_t)NG) * 1024u;
+    const uint32_t soff = U(sbase + (tap * CgG + cb * (uint32_t)NG) * 1024u);
     unsigned char* ld = smem + w_lds + slot * DW_STAGE;
     dma16s(wt_rsrc, w_voff, soff, ld);
-    if constexpr (KIND == 1) dma16s(wt_rsrc, w_voff, soff + doff, ld + 4096);
+    if constexpr (KIND == 1) dma16s(wt_rsrc, w_voff, U(soff + doff), ld + 4096);
   };
 
   // ---- first tile: prologue as in contract_taps_kernel
   uint32_t w_sbase, w_doff;
   w_sbase = w_base_of(cur, w_doff);
+  w_sbase = U(w_sbase); w_doff = U(w_doff);
   issue_w(w_sbase, w_doff, 0u, 0u, 0);
   uint32_t pp_boff[MAXNI];
   uint32_t pmask = 0;
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
   // stage's get their s_in signs in place between the two passes).  The weights are NOT: one set for the mean pass, one
   // for the delta pass — the mean set is refilled with the NEXT stage's tile as soon as this stage's mean MFMAs have
   // consumed it (the reads land while the delta MFMAs run), the delta set at the head of its stage while the mean
-  // MFMAs run.  48 registers of weight fragments become 32: what keeps the persistent K loop free of spills.
+  // MFMAs run.  48 registers of weight fragments become 32.
   struct AFrag { u32x4 a[NG / 2][MI]; uint32_t sw[MI]; };
   using WFrag = u32x4[NG / 2][2];
   auto load_a = [&](AFrag& f, int aslot, int toffv) __attribute__((always_inline)) {
@@ -233,6 +254,10 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
   load_a(fa, 0, 0);
   load_w(wm, 0, 0);
   bool after_store = false;
+#ifdef BTX_PT_TRACE
+  tr_mark = tr_t0;
+  BTX_T3_MARK(tr_pro);
+#endif
 
   // One channel block = T unrolled stages, exactly contract_taps_kernel's: stage t multiplies tap t, fetches W three
   // stages ahead and its share of the NEXT block's patch (+ the next block's sign words at t = 0), reads the next
@@ -335,22 +360,30 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
   uint32_t n_sbase = w_sbase, n_doff = w_doff;
   RngLive rl_n = rl;
   uint32_t dx_next = 0, ds_next = 0;  // byte / element advance of the patch offsets to the next tile
-  auto plan_next = [&]() __attribute__((always_inline)) {  // ig_cur + 1 < ig_end
+  uint32_t ig_next = ig_end;
+  auto plan_next = [&]() __attribute__((always_inline)) {  // ig_next < ig_end
     refresh_q();
-    const uint32_t ig = ig_cur + 1;
+    const uint32_t ig = ig_next;
     nxt = cur;
-    nxt.lane = (int)(ig / IG); nxt.img0 = (int)(ig % IG) * kp->pt_G;
-    dx_next = xoff_of(nxt.lane, nxt.img0) - xoff_of(cur.lane, cur.img0);
-    ds_next = (uint32_t)(nxt.img0 - cur.img0) * img_elems;
+    nxt.lane = (int)U(ig / IG); nxt.img0 = (int)U((ig % IG) * (uint32_t)kp->pt_G);
+    dx_next = U(xoff_of(nxt.lane, nxt.img0) - xoff_of(cur.lane, cur.img0));
+    ds_next = U((uint32_t)(nxt.img0 - cur.img0) * img_elems);
     n_sbase = w_base_of(nxt, n_doff);
+    n_sbase = U(n_sbase); n_doff = U(n_doff);
     rl_n = rl;
     if (nxt.lane != cur.lane) rl_n = lane_keys(nxt.lane);
   };
-  if (ig_cur + 1 < ig_end) plan_next();
-
+  uint32_t* const q_word = (uint32_t*)(smem + PT_X_OFF + 1024);  // 16 bytes behind the layout of contract_taps_kernel (host)
   for (;;) {
-    const bool has_next = ig_cur + 1 < ig_end;
+    // draw the next image group (wave 0, one lane), a tile ahead: the reply is back long before block 0 ends
+    uint32_t drawn = 0;
+    if (wave == 0 && lane == 0) drawn = __hip_atomic_fetch_add(kp->pt_queue + q_combo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     block(P0{}, std::true_type{}, 0, false, false, w_sbase, w_doff, 1u, rl.kin_a, rl.kin_b);
+    if (wave == 0 && lane == 0) *q_word = drawn + q_first;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ig_next = U(*(volatile uint32_t*)q_word);
+    const bool has_next = ig_next < ig_end;
+    if (has_next) plan_next();
     for (int cbi = 1; cbi + 1 < ncb; cbi += 2) {
       block(P1{}, std::false_type{}, cbi, false, false, w_sbase, w_doff, (uint32_t)(cbi + 1), rl.kin_a, rl.kin_b);
       block(P0{}, std::false_type{}, cbi + 1, false, false, w_sbase, w_doff, (uint32_t)(cbi + 2), rl.kin_a, rl.kin_b);
@@ -365,7 +398,9 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
 
     // ============ store side of tile `cur`, straight from the fragment registers =======================================
     // (everything in flight — the next tile's W(2) — lands first: the relaxed wait of the next stage relies on it)
+    BTX_T3_MARK(tr_k);
     if (has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BTX_T3_MARK(tr_st[0]);  // everything in flight landed
     refresh_q();
     {
       // Opaque copies of the thread's ids: without them the compiler hoists the store side's address arithmetic (loop-
@@ -377,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
       const bool has_aff = (kp->ep_scale != nullptr) || (kp->ep_shift != nullptr);
       float* ba_lds = (float*)(smem + PT_S_OFF + s_stage);  // the sign slot of the tile's last block: dead by now
       // per-channel constants [bias mean | bias delta | scale | shift] x 64, identities where absent
-      ep_fill_constants<KIND>(*kp, rl, ba_lds, tid, cur.ntile, cur.group, has_bias, has_aff);
+      ep_fill_constants<KIND>(*KPG(), rl, ba_lds, tid, cur.ntile, cur.group, has_bias, has_aff);
       uint32_t gp[MI];
       bool gok[MI];
       {
@@ -391,19 +426,27 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
         }
       }
       const uint32_t cbase = (uint32_t)(cur.group * kp->Ng + cur.ntile * BN);
-      __bf16* outp = (__bf16*)((unsigned char*)kp->out + (size_t)cur.lane * (size_t)kp->lane_out);
-      uint32_t eo[MI];  // element offset of the lane's 8-channel run of (pixel mi, half 0, pair 0)
+      // output / residual rows behind buffer descriptors (scalar base of the MC sample lane's tensor, 32-bit byte offsets,
+      // the (ni, k) part in the instruction's immediate): 64-bit per-store addresses were two VGPRs each and got spilt.
+      // A pixel outside the tile gets an out-of-range offset: its loads return zeros, its stores are dropped.
+      const uint32_t out_bytes = (uint32_t)kp->NB * (uint32_t)(kp->Ho * kp->Wo) * (uint32_t)kp->N * 2u;  // host: < 2 GiB
+      const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (unsigned char*)kp->out + (size_t)cur.lane * (size_t)kp->lane_out, 0, out_bytes, 0x00020000);
+      uint32_t eo[MI];  // byte offset of the lane's 8-channel run of (pixel mi, half 0, pair 0)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) eo[mi] = gp[mi] * (uint32_t)kp->N + cbase + 8u * (uint32_t)h;
+      for (int mi = 0; mi < MI; ++mi)  // (0x80000000, not DMA_OOB: the (ni, k) immediate is added to it and must not wrap)
+        eo[mi] = gok[mi] ? (gp[mi] * (uint32_t)kp->N + cbase + 8u * (uint32_t)h) * 2u : 0x80000000u;
       // the residual loads of the lane go out first: (pixel mi) x (32-channel half ni) x (16-channel pair k); pixel 1's
       // follow while pixel 0 is being stored (16 registers at a time)
       const bool res = kp->ep_res != nullptr;
-      const __bf16* resp = (const __bf16*)((const unsigned char*)kp->ep_res + (size_t)cur.lane * (size_t)kp->lane_res);
+      const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (unsigned char*)kp->ep_res + (size_t)cur.lane * (size_t)kp->lane_res, 0, res ? out_bytes : 0u, 0x00020000);
       auto load_res = [&](u32x4 (&r)[2][2], int mi) __attribute__((always_inline)) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) r[ni][k] = res ? *(const u32x4*)(resp + eo[mi] + ni * 32 + 16 * k) : (u32x4){0u, 0u, 0u, 0u};
+          for (int k = 0; k < 2; ++k)  // (no residual: a zero-length descriptor, the loads return zeros)
+            r[ni][k] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, eo[mi] + (uint32_t)(ni * 64 + 32 * k), 0, 0);
       };
       u32x4 rv[2][2];
       load_res(rv, 0);
@@ -420,83 +463,125 @@ __global__ __launch_bounds__(256, 2) void contract_taps3_kernel(const ContractPa
       asm volatile("" : "+s"(SB));
       const float lowb = kp->ep_relu ? 0.f : -__builtin_inff();  // ReLU as a lower bound: one instruction stream for both
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the constants are in LDS
-      auto combine = [&](auto bias_tag) __attribute__((always_inline)) {
+      BTX_T3_MARK(tr_st[1]);  // addresses, residual loads issued, constants in LDS, waves met
+      // Phase A — fold the delta accumulators into the mean ones, in place: (mean + bias) + s_out * (delta + bias delta).
+      // Needs nothing but the sign words; afterwards 64 of the 128 accumulator registers are free, which is what lets
+      // phase B run without spills.
+      auto fold = [&](auto bias_tag) __attribute__((always_inline)) {
         constexpr bool BIAS = decltype(bias_tag)::value;
+        if constexpr (KIND == 1 || BIAS) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int cl = ni * 32 + 8 * q + 4 * h;
-            f32x4 bm, bd;
-            if constexpr (BIAS) { bm = *(const f32x4*)(ba_lds + cl); bd = *(const f32x4*)(ba_lds + BN + cl); }
-            const f32x4 sc = *(const f32x4*)(ba_lds + 2 * BN + cl);
-            const f32x4 sh = *(const f32x4*)(ba_lds + 3 * BN + cl);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int rr = 0; rr < 4; ++rr) {
-                float val = accm[mi][ni][4 * q + rr];
-                if constexpr (BIAS) val += bm[rr];
-                if constexpr (KIND == 1) {
-                  float dl = accd[mi][ni][4 * q + rr];
-                  if constexpr (BIAS) dl += bd[rr];
-                  const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1));
-                  val += u2f(__builtin_amdgcn_bitop3_b32(f2u(dl), wsh[mi][ni] << sft, SB, 0x78));
-                }
-                accm[mi][ni][4 * q + rr] = __builtin_fmaf(val, sc[rr], sh[rr]);
+            for (int q = 0; q < 4; ++q) {
+              f32x4 bm, bd;
+              if constexpr (BIAS) {
+                const int cl = ni * 32 + 8 * q + 4 * h;
+                bm = *(const f32x4*)(ba_lds + cl); bd = *(const f32x4*)(ba_lds + BN + cl);
               }
-            // one (ni, q) group at a time: left alone the scheduler issues all 32 constant reads up front (128 registers
-            // beside the 128 accumulators) and the allocator spills — into the K loop too
-            __builtin_amdgcn_sched_barrier(0);
-          }
-      };
-      if (has_bias) combine(std::true_type{}); else combine(std::false_type{});
-      // pair the half-waves' 4-channel runs into 8-channel runs, add the residual, ReLU, round, store
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        u32x4 rcur[2][2];
+              for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int k = 0; k < 2; ++k) rcur[ni][k] = rv[ni][k];
-        if (mi + 1 < MI) load_res(rv, mi + 1);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            float v[8];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const auto r = __builtin_amdgcn_permlane32_swap(f2u(accm[mi][ni][4 * (2 * k) + rr]),
-                                                              f2u(accm[mi][ni][4 * (2 * k + 1) + rr]), false, false);
-              v[rr] = u2f(r[0]);
-              v[4 + rr] = u2f(r[1]);
+                for (int rr = 0; rr < 4; ++rr) {
+                  float val = accm[mi][ni][4 * q + rr];
+                  if constexpr (BIAS) val += bm[rr];
+                  if constexpr (KIND == 1) {
+                    float dl = accd[mi][ni][4 * q + rr];
+                    if constexpr (BIAS) dl += bd[rr];
+                    const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1));
+                    val += u2f(__builtin_amdgcn_bitop3_b32(f2u(dl), wsh[mi][ni] << sft, SB, 0x78));
+                  }
+                  accm[mi][ni][4 * q + rr] = val;
+                }
+              if constexpr (BIAS) __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // (one instantiation only — the host does not take this kernel for layers with a bias: with both forms behind a
+      // run-time branch the compiler hoists their 64 common `sign word << shift` values above it and spills them)
+      fold(std::false_type{});
+      BTX_T3_MARK(tr_st[2]);
+      // Phase B — one (pixel mi, 32-channel half ni, 16-channel pair k) group at a time, registers -> store: scale/shift
+      // on the lane's two 4-channel runs, the half-waves' runs paired into one 8-channel run per lane
+      // (v_permlane32_swap), residual, ReLU, round, one 16-byte store.  The constants of the next group are requested
+      // before this group's arithmetic.
+      {
+        struct Cst { f32x4 sc[2], sh[2]; };
+        auto load_cst = [&](Cst& c, int ni, int k) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[2 * j] += u2f(rcur[ni][k][j] << 16); v[2 * j + 1] += u2f(rcur[ni][k][j] & 0xffff0000u); }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], lowb);
-            const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
-            const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(x0, bf16x4));
-            const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(x1, bf16x4));
-            if (gok[mi] && !(kp->pt_tune & 1))  // pt_tune bit 0 (tuning builds): no stores — what the stores cost
-              *(u32x4*)(outp + eo[mi] + ni * 32 + 16 * k) = (u32x4){p0[0], p0[1], p1[0], p1[1]};
+          for (int hf = 0; hf < 2; ++hf) {
+            const int cl = ni * 32 + 8 * (2 * k + hf) + 4 * h;
+            c.sc[hf] = *(const f32x4*)(ba_lds + 2 * BN + cl);
+            c.sh[hf] = *(const f32x4*)(ba_lds + 3 * BN + cl);
           }
+        };
+        Cst cst[2];
+        load_cst(cst[0], 0, 0);
+        u32x4 rnx[2][2];
+        static_for<0, 8>([&](auto g_tag) __attribute__((always_inline)) {
+          constexpr int g = decltype(g_tag)::value;
+          constexpr int mi = g >> 2, ni = (g >> 1) & 1, k = g & 1;
+          if constexpr (g + 1 < 8) load_cst(cst[(g + 1) & 1], ((g + 1) >> 1) & 1, (g + 1) & 1);
+          if constexpr (g == 0 && MI > 1) load_res(rnx, 1);  // pixel 1's residual rows land while pixel 0 is stored
+          const Cst& c = cst[g & 1];
+          float t[2][4];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+              t[hf][rr] = __builtin_fmaf(accm[mi][ni][4 * (2 * k + hf) + rr], c.sc[hf][rr], c.sh[hf][rr]);
+          float v[8];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const auto r = __builtin_amdgcn_permlane32_swap(f2u(t[0][rr]), f2u(t[1][rr]), false, false);
+            v[rr] = u2f(r[0]);
+            v[4 + rr] = u2f(r[1]);
+          }
+          const u32x4 rw = (mi == 0) ? rv[ni][k] : rnx[ni][k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[2 * j] += u2f(rw[j] << 16); v[2 * j + 1] += u2f(rw[j] & 0xffff0000u); }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], lowb);
+          const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+          const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(x0, bf16x4));
+          const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(x1, bf16x4));
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4){p0[0], p0[1], p1[0], p1[1]}, out_rsrc,
+                                                 eo[mi] + (uint32_t)(ni * 64 + 32 * k), 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
     }
+    BTX_T3_MARK(tr_st[3]);  // pairing, residual, stores issued
+#ifdef BTX_PT_TRACE
+    ++tr_n;
+#endif
     if (!has_next) break;
     // ============ next tile: its first block's data is in the rings, its first fragments in the registers ==============
-    ++ig_cur;
+    ig_cur = ig_next;
     cur = nxt;
     w_sbase = n_sbase; w_doff = n_doff;
     rl = rl_n;
-    if (ig_cur + 1 < ig_end) plan_next();
     after_store = !(p.pt_tune & 2);  // pt_tune bit 1 (tuning builds): the plain wait immediate behind a store side
     // every wave is through with the constants before the next tile's first stage rewrites that sign slot
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     load_a(fa, 0, 0);  // the new tile's first fragments (its block 0 sits on patch slot 0: ncb is even)
     load_w(wm, wslot, 0);
+    BTX_T3_MARK(tr_st[4]);  // next tile planned, waves met, first fragments requested
   }
+#ifdef BTX_PT_TRACE
+  if (p.trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t tr_t3 = (uint32_t)__builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      uint32_t* tr = (uint32_t*)p.trace + (size_t)(blockIdx.x * NW + wave) * 8;
+      if (p.pt_tune & 128) { tr[0] = tr_st[0]; tr[1] = tr_st[1]; tr[2] = tr_st[2]; tr[3] = tr_st[3]; tr[4] = tr_st[4]; tr[5] = tr_n; }
+      else { tr[0] = tr_pro; tr[1] = tr_k; tr[2] = (uint32_t)__builtin_amdgcn_s_memrealtime() - tr_r0; tr[3] = 0;
+             tr[4] = tr_st[0] + tr_st[1] + tr_st[2] + tr_st[3] + tr_st[4]; tr[5] = tr_t3 - tr_t0; }
+      tr[6] = tr_t0; tr[7] = tr_n;
+    }
+  }
+#endif
 }
 
 }  // namespace btx

@@ -57,7 +57,8 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) > 2 * 512 * 4608 * 2
     g.H = g.W = 56
     g.C = g.N = 64
-    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) == 2 * 64 * 576 * 2
+    # (+ 4 KiB, 256-byte aligned: the image-group queues of the persistent form of the tap-unrolled 3x3 kernel)
+    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) == 2 * 64 * 576 * 2 + 4096
 
 
 def test_argument_errors_of_the_sampling_and_format_entry_points():

@@ -180,6 +180,12 @@ def trace(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64, war
     if not len(t):
         return
     names = ["prologue", "A->B issue+mma", "B->C vmcnt|100MHz ticks", "C->D barrier", "epilogue", "total"]
+    if os.environ.get("BTX_PERSIST"):  # contract_taps3_kernel: sums over the tiles a workgroup walks (column 7: tiles)
+        names = ["prologue", "K loops (sum)", "100MHz ticks", "-", "store sides (sum)", "total"]
+        if int(os.environ.get("BTX_TAPS_TUNE", "0")) & 128:
+            names = ["ss: in-flight landed", "ss: addresses+constants+barrier", "ss: combine", "ss: pair+residual+stores", "ss: next tile+barrier", "tiles"]
+    elif int(os.environ.get("BTX_TAPS_TUNE", "0")) & 128:  # prologue sub-stamps, cumulative from the kernel's first instruction
+        names = ["patch DMAs issued", "sign keys derived", "role index math", "sign words written", "patch landed+barrier", "first fragments (K loop starts)"]
     if t[:, 2].astype(np.float64).mean() > 0 and t[:, 3].astype(np.float64).mean() == 0:
         print("  shader clock while the blocks ran: %.3f GHz (s_memtime / s_memrealtime)" % (
             t[:, 5].astype(np.float64).mean() / t[:, 2].astype(np.float64).mean() * 0.1))
