@@ -184,6 +184,18 @@ __device__ __forceinline__ ContractParams lane_view(const ContractParams& q, int
   return p;
 }
 
+// Launch parameters of a kernel SECTION: a lane view (above) of the ~180-dword argument struct, read through a pointer to
+// the kernel-argument segment that the compiler cannot connect to the pointer of another section.  A kernel that takes
+// the struct by value loads every field any part of it uses at entry and keeps it to its last use: the tap-unrolled
+// Flipout kernel spilt 140 SGPRs into VGPR lanes, ~40 % of the VALU instructions of its prologue and store side were
+// v_readlane / v_writelane.  With one view for prologue + K loop and one for the store side: 94, prologue 10.9k -> 8.2k cycles.
+#define BTX_SECTION_PARAMS(name, logical_var)                                                                         \
+  const __attribute__((address_space(4))) ContractParams* name##_karg =                                               \
+      (const __attribute__((address_space(4))) ContractParams*)__builtin_amdgcn_kernarg_segment_ptr();                \
+  asm volatile("" : "+s"(name##_karg));                                                                               \
+  int logical_var = xcd_logical();                                                                                    \
+  const ContractParams name = lane_view(*(const ContractParams*)name##_karg, logical_var)
+
 // ---- the (sample index, sign keys) a launch actually uses --------------------------------------------------------
 // BtxRng.sample_idx_dev lets a captured hipGraph be replayed for successive MC samples: the index — and the Flipout
 // sign keys derived from it — are then resolved on the device at run time instead of being baked into the arguments.

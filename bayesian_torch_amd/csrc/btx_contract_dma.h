@@ -89,9 +89,8 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 #undef BTX_VM
 
 template <int PREC, int KIND, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const ContractParams pk) {
-  int logical = xcd_logical();
-  const ContractParams p = lane_view(pk, logical);
+__global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const ContractParams) {
+  BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   using LD = DmaLds<NW>;
   constexpr int TP = LD::TP, WD = LD::WD, DA_STAGE = LD::A_STAGE, DS_STAGE = LD::S_STAGE, DA_OFF = LD::A_OFF,
                 DS_OFF = LD::S_OFF, DW_OFF = LD::W_OFF;
@@ -364,17 +363,18 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
 
   // =================== epilogue (btx_epilogue.h) ============================================================
   {
+    BTX_SECTION_PARAMS(pe, logical2);
     const uint32_t m0 = (uint32_t)mtile * (uint32_t)TP;
-    const int nvalid = min(TP, p.M - (int)m0);
+    const int nvalid = min(TP, pe.M - (int)m0);
 #ifdef BTX_PT_TRACE
     tr_t2 = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
 #ifdef BTX_EP_TRACE
     uint32_t ep_t[2] = {0, 0};
-    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid, ep_t);
+    staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid, ep_t);
     tr_ab = ep_t[0] - tr_t2; tr_bc = ep_t[1] - ep_t[0];
 #else
-    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
 #endif
   }
 #ifdef BTX_PT_TRACE

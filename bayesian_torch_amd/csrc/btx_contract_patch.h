@@ -45,9 +45,8 @@ namespace btx {
 // accumulators — the unified 512-entry register file of a single wave per SIMD; every weight fragment read from LDS
 // then feeds twice as many MFMAs).
 template <int PREC, int KIND, int NW, int MI>
-__global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_kernel(const ContractParams pk) {
-  int logical = xcd_logical();
-  const ContractParams p = lane_view(pk, logical);
+__global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_kernel(const ContractParams) {
+  BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   const RngLive rl = rng_live<KIND>(p);
   constexpr int NT = 64 * NW;
   constexpr int WPX = 32 * MI;                      // pixels per wave
@@ -321,16 +320,17 @@ __global__ __launch_bounds__(64 * NW, (MI == 4) ? 1 : 2) void contract_patch_ker
   // =================== epilogue (btx_epilogue.h) ============================================================
   {
     // valid pixels of the tile are a prefix of its flattened (image, row, col) order, contiguous in the output
-    const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
-    const int nvalid = nimg * nrow * p.Wo;
-    const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
-if constexpr (MI == 2) {
-      staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    BTX_SECTION_PARAMS(pe, logical2);
+    const int nimg = min(pe.pt_G, pe.NB - img0), nrow = min(pe.pt_R, pe.Ho - row0);
+    const int nvalid = nimg * nrow * pe.Wo;
+    const uint32_t m0 = (uint32_t)(img0 * pe.Ho + row0) * (uint32_t)pe.Wo;
+    if constexpr (MI == 2) {
+      staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
     } else {
 #pragma unroll
       for (int hf = 0; hf < MI / 2; ++hf) {
         __builtin_amdgcn_sched_barrier(0);  // one half of the 256 accumulators at a time
-        staged_epilogue<KIND, NW>(p, rl, reinterpret_cast<const f32x16(&)[2][2]>(accm[2 * hf]),
+        staged_epilogue<KIND, NW>(pe, rl, reinterpret_cast<const f32x16(&)[2][2]>(accm[2 * hf]),
                                   reinterpret_cast<const f32x16(&)[2][2]>(accd[2 * hf]), smem, tid, wave, lane, ntile,
                                   group, split, m0, nvalid, nullptr, wave * (MI / 2) + hf, hf == 0);
       }

@@ -25,9 +25,8 @@ namespace btx {
 // bytes), pt_astage (patch bytes rounded to 1 KiB), st_sbytes (bytes of the sign-word array), pt_nw, pt_lds.
 // Geometry as the C-ABI hands it over with BTX_FLAG_ROWFUSE: p.Cg = KW*C elements per kernel row, pad 0, groups 1.
 template <int PREC, int KIND, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void contract_stem_kernel(const ContractParams pk) {
-  int logical = xcd_logical();
-  const ContractParams p = lane_view(pk, logical);
+__global__ __launch_bounds__(64 * NW, 2) void contract_stem_kernel(const ContractParams) {
+  BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   constexpr int NT = 64 * NW;
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
@@ -172,8 +171,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_stem_kernel(const Contrac
 
   // =================== epilogue (btx_epilogue.h) ============================================================
   {
-    const uint32_t m0 = (uint32_t)(img * p.Ho + row0) * (uint32_t)p.Wo;
-    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, 0, 0, m0, nvalid);
+    BTX_SECTION_PARAMS(pe, logical2);
+    const uint32_t m0 = (uint32_t)(img * pe.Ho + row0) * (uint32_t)pe.Wo;
+    staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, 0, 0, m0, nvalid);
   }
 }
 

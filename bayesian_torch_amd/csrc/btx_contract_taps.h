@@ -78,15 +78,7 @@ constexpr int tp_pieces(int t) {
 // before its first stage, group 0 one after its last): one group's MFMA half sits beside the other's load half.
 template <int PREC, int KIND, int KH, int KW, int KG>
 __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const ContractParams) {
-  // The launch parameters (~180 dwords) are read through a pointer to the kernel-argument segment, once per SECTION of
-  // the kernel (prologue + K loop here, the store side at the end through a pointer the compiler cannot connect to this
-  // one): taken by value, every field any section uses is loaded at entry and stays live to its last use — 140 SGPRs
-  // spilt into VGPR lanes, and ~40 % of the prologue's and store side's VALU instructions were v_readlane/v_writelane.
-  using KArg = const __attribute__((address_space(4))) ContractParams*;
-  KArg karg = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(karg));
-  int logical = xcd_logical();
-  const ContractParams p = lane_view(*(const ContractParams*)karg, logical);
+  BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   constexpr int NW = 4, NT = 256, MI = 2, T = KH * KW;
   static_assert(T >= 5 && T <= 32, "tap-unrolled kernel: 5..32 taps");
   constexpr int MAXNI = TP_MAXNI;
@@ -424,10 +416,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
 
   // =================== epilogue (btx_epilogue.h) ============================================================
   {
-    KArg karg2 = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(karg2));
-    int logical2 = xcd_logical();
-    const ContractParams pe = lane_view(*(const ContractParams*)karg2, logical2);  // the store side's own reads
+    BTX_SECTION_PARAMS(pe, logical2);  // the store side's own reads
     const int nimg = min(pe.pt_G, pe.NB - img0), nrow = min(pe.pt_R, pe.Ho - row0);
     const int nvalid = nimg * nrow * pe.Wo;
     const uint32_t m0 = (uint32_t)(img0 * pe.Ho + row0) * (uint32_t)pe.Wo;

@@ -45,9 +45,8 @@ constexpr int t2_p0(int s) { return (s == 1 || s == 6 || s == 8) ? 3 : 0; }     
 constexpr int t2_fseq(int s) { return s < 2 ? 2 : (s == 4 ? 3 : (s < 7 ? 4 : 5)); }  // plane it belongs to (4, 5: next block)
 
 template <int PREC, int KIND>
-__global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractParams pk) {
-  int logical = xcd_logical();
-  const ContractParams p = lane_view(pk, logical);
+__global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractParams) {
+  BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   constexpr int NW = 4, NT = 256, MI = 2, T = T2_T, MAXNI = T2_MAXNI, WD = T2_WD;
   constexpr int WOPS = (KIND == 1) ? 2 : 1;  // weight DMA instructions per wave per stage
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
@@ -304,10 +303,11 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
 
   // =================== epilogue (btx_epilogue.h) ============================================================
   {
-    const int nimg = min(p.pt_G, p.NB - img0), nrow = min(p.pt_R, p.Ho - row0);
-    const int nvalid = nimg * nrow * p.Wo;
-    const uint32_t m0 = (uint32_t)(img0 * p.Ho + row0) * (uint32_t)p.Wo;
-    staged_epilogue<KIND, NW>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    BTX_SECTION_PARAMS(pe, logical2);
+    const int nimg = min(pe.pt_G, pe.NB - img0), nrow = min(pe.pt_R, pe.Ho - row0);
+    const int nvalid = nimg * nrow * pe.Wo;
+    const uint32_t m0 = (uint32_t)(img0 * pe.Ho + row0) * (uint32_t)pe.Wo;
+    staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
   }
 }
 
