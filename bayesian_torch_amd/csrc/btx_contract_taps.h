@@ -276,6 +276,17 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     int q[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) q[mi] = q0[mi] + toffv;
+    if constexpr (BTX_PT_ABL & 2) {  // measurement builds: no fragment reads
+#pragma unroll
+      for (int kk = 0; kk < NG / 2; ++kk) {
+#pragma unroll
+        for (int mi = 0; mi < MIA; ++mi) f.a[kk][mi] = (u32x4){(uint32_t)q[mi], 5u, 1u, 4u};
+        f.wm[kk][0] = f.wm[kk][1] = (u32x4){7u, 7u, 1u, (uint32_t)wsl};
+      }
+#pragma unroll
+      for (int mi = 0; mi < MIA; ++mi) f.sw[mi] = (uint32_t)q[mi];
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < NG / 2; ++kk) {
       const int row = 2 * kk + h;
@@ -326,14 +337,16 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
         asm volatile("" : "+v"(q0[0]), "+v"(q0[1]));
         // 1. W(s+3)
         constexpr int t3 = (t + 3) % T, c3 = (t + 3) / T;
-        if constexpr (c3 == 0) {
-          issue_w((uint32_t)t3, (uint32_t)(cb0 + cbi), (wslot + 3) & 3);
-        } else {
-          if (!last) issue_w((uint32_t)t3, (uint32_t)(cb0 + cbi + 1), (wslot + 3) & 3);
+        if constexpr (!(BTX_PT_ABL & 4)) {
+          if constexpr (c3 == 0) {
+            issue_w((uint32_t)t3, (uint32_t)(cb0 + cbi), (wslot + 3) & 3);
+          } else {
+            if (!last) issue_w((uint32_t)t3, (uint32_t)(cb0 + cbi + 1), (wslot + 3) & 3);
+          }
         }
         // 2. this stage's share of the next block's patch (+ its sign words at the first stage)
         constexpr int KP = tp_pieces<T>(t);
-        if constexpr (t < PST) {
+        if constexpr (t < PST && !(BTX_PT_ABL & 4)) {
           if (!last) {
             const uint32_t cboff = (uint32_t)((cb0 + cbi + 1) * BK * ESZ);
 #pragma unroll

@@ -1,0 +1,145 @@
+// Micro-benchmark: the instruction mix of one K-stage of the Flipout tap kernel (fragment reads from LDS, s_in masks on
+// the activation fragments, mean + delta MFMAs, one barrier) at different register-tile shapes, run long enough for the
+// power management to settle.  What it answers: at the clock the chip sustains under each mix, how many TFLOP/s does
+//   A  2x2 MFMA tiles per wave (128 accumulators in VGPRs), 4-wave blocks, 2 blocks per CU      — contract_taps_kernel
+//   B  4x2 tiles (256 accumulators in AGPRs), 4-wave blocks, 1 block per CU (1 wave per SIMD, 512 registers)
+//   C  2x4 tiles (256 accumulators in AGPRs), same occupancy                                   — halves the masks per MFMA
+//   D  A without the masks, E  A without masks and with half the fragment reads (upper bounds of what removing them buys)
+// deliver?  No global memory traffic in the loop: weights and activations stay in LDS.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip && tools/ubench/mfma_mix
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+template <bool AG>
+__device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& a) {
+  if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+  else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+
+// MI x NI tiles of 32 pixels x 32 channels per wave; MASK: s_in masks; RD: fragment reads per stage (1 = all, 2 = every 2nd stage)
+template <int MI, int NI, bool AG, bool MASK, int RD, int BPC>
+__global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned* clk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  for (int i = tid; i < 65536 / 4; i += 256) ((unsigned*)lds)[i] = 0x3c003c00u + ((i * 2654435761u) & 0x007f007fu);
+  __syncthreads();
+  f32x16 accm[MI][NI], accd[MI][NI];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < NI; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
+  if constexpr (AG) {
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < NI; ++b) { asm volatile("" : "+a"(accm[a][b])); asm volatile("" : "+a"(accd[a][b])); }
+  }
+  const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime(), r0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+  struct Frag { u32x4 A[2][MI], WM[2][NI], WD[2][NI]; unsigned sw[MI]; };
+  auto load = [&](Frag& f, int s) __attribute__((always_inline)) {
+    const unsigned char* ab = lds + ((s * 4096) & 16383);
+    const unsigned char* wb = lds + 32768 + ((s * 8192) & 16383);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) f.A[kk][mi] = *(const u32x4*)(ab + ((mi * 32 + l31) & 63) * 64 + (((2 * kk + h) ^ ((l31 >> 2) & 3)) * 16));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        f.WM[kk][ni] = *(const u32x4*)(wb + ((2 * kk + h) * 64 + ((ni * 32 + l31) & 63)) * 16);
+        f.WD[kk][ni] = *(const u32x4*)(wb + 4096 + ((2 * kk + h) * 64 + ((ni * 32 + l31) & 63)) * 16);
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) f.sw[mi] = *(const unsigned*)(lds + 49152 + ((s * 256 + mi * 32 + l31) & 1023) * 4);
+  };
+  // stage s multiplies `cur` while the fragments of stage s+1 are read into `nxt` (as the kernel does)
+  auto stage = [&](Frag& cur, Frag& nxt, int s) __attribute__((always_inline)) {
+    if (RD == 1 || (s & 2) == 0) load(nxt, s + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mma<AG>(accm[mi][ni], cur.WM[kk][ni], cur.A[kk][mi]);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if constexpr (MASK) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const unsigned swr = cur.sw[mi] << (4 * (2 * kk + h));
+#pragma unroll
+          for (int d = 0; d < 4; ++d) cur.A[kk][mi][d] ^= ((swr << d) & 0x80008000u);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mma<AG>(accd[mi][ni], cur.WD[kk][ni], cur.A[kk][mi]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  Frag fa, fb;
+  load(fa, 0); load(fb, 1);
+  for (int s = 0; s < stages; s += 2) {
+    stage(fa, fb, s);
+    stage(fb, fa, s + 1);
+  }
+  const unsigned t1 = (unsigned)__builtin_amdgcn_s_memtime(), r1 = (unsigned)__builtin_amdgcn_s_memrealtime();
+  float v = 0.f;
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < NI; ++b) {
+      if constexpr (AG) { asm volatile("" : "+a"(accm[a][b])); asm volatile("" : "+a"(accd[a][b])); }
+      v += accm[a][b][0] + accd[a][b][5];
+    }
+  if (v == 12345.678f) sink[0] = v;
+  if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+template <int MI, int NI, bool AG, bool MASK, int RD, int BPC>
+void run(const char* name, float* sink, unsigned* clk) {
+  auto fn = k<MI, NI, AG, MASK, RD, BPC>;
+  const int lds_bytes = BPC == 2 ? 81920 : 163840;  // pins the blocks per CU
+  hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  const int grid = 256 * BPC;
+  const int stages = 100000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 6; ++w) fn<<<grid, 256, lds_bytes>>>(stages, sink, clk);  // ~0.1 s each: power management settles
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int reps = 6;
+  for (int w = 0; w < reps; ++w) fn<<<grid, 256, lds_bytes>>>(stages, sink, clk);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  unsigned c[2];
+  hipMemcpy(c, clk, 8, hipMemcpyDeviceToHost);
+  const double flop = (double)reps * grid * 4 * stages * (2.0 * MI * NI * 2) * 32768.0;
+  const double ghz = (double)c[0] / (double)c[1] * 0.1;
+  const double cyc_stage = (double)c[0] / stages;
+  printf("%-58s %7.1f TFLOP/s  clock %.3f GHz  %6.0f cycles/stage (MFMA pipe needs %d: %.0f %% busy)\n", name, flop / (ms * 1e-3) / 1e12, ghz,
+         cyc_stage, 2 * MI * NI * 2 * 32 * BPC, 100.0 * (2 * MI * NI * 2 * 32 * BPC) / cyc_stage);
+}
+
+int main() {
+  float* sink; unsigned* clk;
+  hipMalloc(&sink, 16); hipMalloc(&clk, 16);
+  for (int round = 0; round < 2; ++round) {
+    run<2, 2, false, true, 1, 2>("A  2x2 tiles, VGPR acc, 2 blocks/CU, masks", sink, clk);
+    run<4, 2, true, true, 1, 1>("B  4x2 tiles, AGPR acc, 1 block/CU, masks", sink, clk);
+    run<2, 4, true, true, 1, 1>("C  2x4 tiles, AGPR acc, 1 block/CU, masks", sink, clk);
+    run<2, 2, false, false, 1, 2>("D  A without masks", sink, clk);
+    run<2, 2, false, false, 2, 2>("E  A without masks, half the fragment reads", sink, clk);
+    run<4, 2, true, false, 1, 1>("F  B without masks", sink, clk);
+  }
+  return 0;
+}
