@@ -1263,9 +1263,9 @@ int btx_sample_weights_lanes(const BtxSampleItem* items, int n_items, const BtxR
           return BTX_E_UNSUPPORTED;
         it.Cp = s.geom->C; it.KWp = s.geom->KW; it.src_KW = s.src_KW; it.src_C = s.src_C;
       }
-      uint32_t nb = (it.nquads + 1023u) / 1024u;  // ~4 quads per thread
+      uint32_t nb = lanes > 1 ? (it.nquads + 255u) / 256u : (it.nquads + 1023u) / 1024u;  // ~4 (quad, lane) pairs per thread
       if (nb < 1) nb = 1;
-      if (nb > 1024u) nb = 1024u;
+      if (nb > (lanes > 1 ? 4096u : 1024u)) nb = lanes > 1 ? 4096u : 1024u;
       blocks += nb;
     }
     b.total_blocks = blocks;

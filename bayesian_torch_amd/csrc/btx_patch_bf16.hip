@@ -13,7 +13,7 @@ int launch_stem_pool_bf16(int kind, const ContractParams& p, int nwg, hipStream_
   return launch_stem_pool_impl(kind, p, nwg, st);
 }
 int launch_presample_batch_bf16(const PresampleBatch& b, hipStream_t st) {
-  hipLaunchKernelGGL((presample_batch_kernel<1>), dim3(b.total_blocks * (uint32_t)(b.lanes > 1 ? b.lanes : 1)), dim3(256), 0, st, b);
+  hipLaunchKernelGGL((presample_batch_kernel<1>), dim3(b.total_blocks), dim3(256), 0, st, b);
   return (int)hipGetLastError();
 }
 }  // namespace btx

@@ -9,7 +9,7 @@ int launch_contract_stem_f32(int kind, const ContractParams& p, int nwg, hipStre
   return launch_contract_stem_impl<0>(kind, p, nwg, st);
 }
 int launch_presample_batch_f32(const PresampleBatch& b, hipStream_t st) {
-  hipLaunchKernelGGL((presample_batch_kernel<0>), dim3(b.total_blocks * (uint32_t)(b.lanes > 1 ? b.lanes : 1)), dim3(256), 0, st, b);
+  hipLaunchKernelGGL((presample_batch_kernel<0>), dim3(b.total_blocks), dim3(256), 0, st, b);
   return (int)hipGetLastError();
 }
 }  // namespace btx

@@ -15,16 +15,21 @@ namespace btx {
 // Same element indices, same _hw sampling functions and the same rounding as the in-kernel sampler: the values are
 // bit-identical to what the other variants compute.
 // one quad (4 consecutive k of one output channel) of the tile image; `t` enumerates (padded channel, quad)
+// MC sample lanes (lanes > 1): the quad's mu / sigma are fetched ONCE and every lane's noise is drawn on top — lane l
+// samples for index sample + l (sample_ptr[l]) into its own tiles `lane_stride` bytes behind the previous lane's (Flipout:
+// the delta tiles, the mean tiles exist once; Reparameterization: the W tiles).  Values per lane are those of a one-lane
+// call with that index.
 template <int PREC>
 __device__ __forceinline__ void presample_quad(int kind, const float* __restrict__ mu, const float* __restrict__ rho,
                                                unsigned char* __restrict__ wt, uint32_t delta_off, int Ng, int K,
                                                int ntiles, uint32_t t, uint32_t seed_lo, uint32_t seed_hi,
                                                uint32_t sample, uint32_t layer, int Cp = 0, int KWp = 0, int src_KW = 0,
                                                int src_C = 0, const float* __restrict__ eps_w = nullptr,
-                                               bool write_mu = true, float* __restrict__ sig = nullptr) {
+                                               bool write_mu = true, float* __restrict__ sig = nullptr, int lanes = 1,
+                                               uint32_t lane_stride = 0, const uint32_t* __restrict__ sample_ptr = nullptr) {
   // sig (btx_sample_weights_lanes): sigma = softplus(rho) of every weight in tile order, f32.  write_mu: this call
   // computes sigma from rho and stores it beside the mean tiles; !write_mu (BTX_SAMPLE_SKIP_MU): mu is not needed and
-  // sigma is READ from there — per MC sample the pre-pass is one load, Philox + Box-Muller, one multiply, one store.
+  // sigma is READ from there — per MC sample the pre-pass is Philox + Box-Muller, one multiply, one store.
   constexpr int G = (PREC == 1) ? 8 : 4;
   // t enumerates the OUTPUT image linearly — (tile, k-granule, channel, quad of the granule), quad fastest — so a wave
   // writes 512 (bf16) / 1024 (f32) contiguous bytes; its reads are 32-byte (bf16) / 16-byte runs, one per channel
@@ -35,24 +40,20 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
   const uint32_t quad = kg0 * QPG + qh;
   const int group = (int)tile / ntiles, ntile = (int)tile - group * ntiles;
   const int col = ntile * BN + (int)ch;
-  float wm[4] = {0.f, 0.f, 0.f, 0.f}, wd[4] = {0.f, 0.f, 0.f, 0.f};
   const uint32_t kg_ = (4u * quad) / G;
-  const uint32_t o_ = (((uint32_t)tile * ((uint32_t)K / G) + kg_) * 64u + (uint32_t)ch) * 16u;
-  const uint32_t so_ = (PREC == 1) ? (o_ + (quad & 1u) * 8u) * 2u : o_;  // byte offset of this quad's f32 sigmas
-  float sg4[4] = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t o = (((uint32_t)tile * ((uint32_t)K / G) + kg_) * 64u + (uint32_t)ch) * 16u;
+  const uint32_t so_ = (PREC == 1) ? (o + (quad & 1u) * 8u) * 2u : o;  // byte offset of this quad's f32 sigmas
+  const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
+  const bool live = col < Ng;  // (channels that pad the last n-tile hold zeros)
   const bool cached = (sig != nullptr) && !write_mu && (kind == 1);
-  if (col < Ng && cached) {
-    const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
+  float mu4[4] = {0.f, 0.f, 0.f, 0.f}, sg4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live && cached) {
     const f32x4 s4 = *(const f32x4*)((const unsigned char*)sig + so_);
-    float eps[4];
-    btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) wd[e] = s4[e] * eps[e];
-  } else if (col < Ng) {
-    const uint32_t e0 = (uint32_t)(group * Ng + col) * (uint32_t)K + 4u * quad;
-    f32x4 mu4, rho4;
+    sg4[0] = s4[0]; sg4[1] = s4[1]; sg4[2] = s4[2]; sg4[3] = s4[3];
+  } else if (live) {
+    f32x4 m4, rho4;
     if (Cp == 0) {
-      mu4 = *(const f32x4*)(mu + e0);
+      m4 = *(const f32x4*)(mu + e0);
       rho4 = *(const f32x4*)(rho + e0);
     } else {
       // padded layout [n][rows][KWp][Cp] sampled straight from the caller's unpadded [n][rows][src_KW][src_C] weights:
@@ -64,34 +65,36 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool ok = kw < (uint32_t)src_KW && c0 + e < (uint32_t)src_C;
-        mu4[e] = ok ? mu[sbase + c0 + e] : 0.f;
+        m4[e] = ok ? mu[sbase + c0 + e] : 0.f;
         rho4[e] = ok ? rho[sbase + c0 + e] : -1e30f;
       }
     }
-    float eps[4];
-    if (eps_w) {  // BtxNoise.eps_w (parity mode): same [N][K] layout as mu
-      const f32x4 e4 = *(const f32x4*)(eps_w + e0);
-      eps[0] = e4[0]; eps[1] = e4[1]; eps[2] = e4[2]; eps[3] = e4[3];
-    } else {
-      btx_normal4_hw(e0 >> 2, sample, layer, 0u, seed_lo, seed_hi, eps);
-    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float sg = btx_softplus_hw(rho4[e]);
-      sg4[e] = sg;
-      if (kind == 0) wm[e] = __builtin_fmaf(sg, eps[e], mu4[e]);
-      else { wm[e] = mu4[e]; wd[e] = sg * eps[e]; }
-    }
+    for (int e = 0; e < 4; ++e) { mu4[e] = m4[e]; sg4[e] = btx_softplus_hw(rho4[e]); }
   }
   if (sig != nullptr && write_mu && kind == 1) *(f32x4*)((unsigned char*)sig + so_) = (f32x4){sg4[0], sg4[1], sg4[2], sg4[3]};
-  const uint32_t o = o_;
-  if constexpr (PREC == 1) {
-    const uint32_t oo = o + (quad & 1u) * 8u;
-    if (write_mu) *(u32x2*)(wt + oo) = pack_quad_bf16(wm);
-    if (kind == 1) *(u32x2*)(wt + delta_off + oo) = pack_quad_bf16(wd);
-  } else {
-    if (write_mu) *(u32x4*)(wt + o) = (u32x4){f2u(wm[0]), f2u(wm[1]), f2u(wm[2]), f2u(wm[3])};
-    if (kind == 1) *(u32x4*)(wt + delta_off + o) = (u32x4){f2u(wd[0]), f2u(wd[1]), f2u(wd[2]), f2u(wd[3])};
+  const uint32_t oo = (PREC == 1) ? o + (quad & 1u) * 8u : o;
+  if (kind == 1 && write_mu) {
+    if constexpr (PREC == 1) *(u32x2*)(wt + oo) = pack_quad_bf16(mu4);
+    else *(u32x4*)(wt + oo) = (u32x4){f2u(mu4[0]), f2u(mu4[1]), f2u(mu4[2]), f2u(mu4[3])};
+  }
+  for (int l = 0; l < lanes; ++l) {
+    float eps[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      if (eps_w) {  // BtxNoise.eps_w (parity mode, one lane): same [N][K] layout as mu
+        const f32x4 e4 = *(const f32x4*)(eps_w + e0);
+        eps[0] = e4[0]; eps[1] = e4[1]; eps[2] = e4[2]; eps[3] = e4[3];
+      } else {
+        const uint32_t smp = sample_ptr ? __builtin_amdgcn_readfirstlane(sample_ptr[l]) : sample + (uint32_t)l;
+        btx_normal4_hw(e0 >> 2, smp, layer, 0u, seed_lo, seed_hi, eps);
+      }
+    }
+    float w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (kind == 0) ? __builtin_fmaf(sg4[e], eps[e], mu4[e]) : sg4[e] * eps[e];
+    unsigned char* dst = wt + (kind == 1 ? delta_off : 0u) + (uint32_t)l * lane_stride + oo;
+    if constexpr (PREC == 1) *(u32x2*)dst = pack_quad_bf16(w);
+    else *(u32x4*)dst = (u32x4){f2u(w[0]), f2u(w[1]), f2u(w[2]), f2u(w[3])};
   }
 }
 
@@ -124,35 +127,28 @@ struct PresampleBatch {
   int n;
   uint32_t seed_lo, seed_hi, sample, total_blocks;
   const uint32_t* sample_ptr;
-  // MC sample lanes: the grid is `lanes` copies of the item grid; lane l samples for index sample + l (sample_ptr[l]) into
-  // the lane's tiles — Flipout: delta tiles at delta_off * (1 + l), the shared mu tiles written by lane 0 (never when
-  // skip_mu: they are current); Reparameterization: W tiles at delta_off * l
+  // MC sample lanes: every thread draws the noise of all lanes for its quad (mu / sigma fetched once); lane l samples for
+  // index sample + l (sample_ptr[l]) into its own tiles — Flipout: delta tiles at delta_off * (1 + l), the mean tiles
+  // exist once (not rewritten when skip_mu: they are current); Reparameterization: W tiles at delta_off * l
   int lanes, skip_mu;
 };
 template <int PREC>
 __global__ __launch_bounds__(256) void presample_batch_kernel(const PresampleBatch b) {
-  const uint32_t lane = blockIdx.x / b.total_blocks, blk = blockIdx.x - lane * b.total_blocks;
+  const uint32_t blk = blockIdx.x;
   int i = 0;
   for (int j = 1; j < b.n; ++j)
     if (blk >= b.it[j].first_block) i = j;
   const PresampleItem& it = b.it[i];
-  const uint32_t sample = b.sample_ptr ? __builtin_amdgcn_readfirstlane(b.sample_ptr[lane]) : b.sample + lane;
   const uint32_t nblk = (i + 1 < b.n ? b.it[i + 1].first_block : b.total_blocks) - it.first_block;
-  unsigned char* wt = it.wt;
-  uint32_t doff = it.delta_off;
-  bool write_mu = true;
-  float* sig = nullptr;
-  if (it.kind == 1) {
-    doff = it.delta_off * (1u + lane);
-    // the sigma cache sits behind the lanes' delta tiles.  Without skip_mu lane 0 writes it (and the mean tiles) while
-    // the other lanes, which may run before lane 0 has, take sigma from rho themselves.
-    sig = (float*)(it.wt + (size_t)it.delta_off * (size_t)(1 + b.lanes));
-    write_mu = (lane == 0) && !b.skip_mu;
-    if (!b.skip_mu && lane != 0) sig = nullptr;
-  } else wt += (size_t)it.delta_off * lane;
+  const int lanes = b.lanes > 1 ? b.lanes : 1;
+  // Flipout: [mu tiles | delta tiles of lane 0 | lane 1 | ... | sigma cache (f32, tile order)]; the cache is written
+  // together with the mean tiles and read instead of (mu, rho) when the caller vouches the parameters are unchanged
+  float* sig = (it.kind == 1) ? (float*)(it.wt + (size_t)it.delta_off * (size_t)(1 + lanes)) : nullptr;
+  const bool write_mu = !b.skip_mu;
   for (uint32_t t = (blk - it.first_block) * 256u + threadIdx.x; t < it.nquads; t += nblk * 256u)
-    presample_quad<PREC>(it.kind, it.mu, it.rho, wt, doff, it.Ng, it.K, it.ntiles, t, b.seed_lo, b.seed_hi,
-                         sample, it.layer, it.Cp, it.KWp, it.src_KW, it.src_C, nullptr, write_mu, sig);
+    presample_quad<PREC>(it.kind, it.mu, it.rho, it.wt, it.delta_off, it.Ng, it.K, it.ntiles, t, b.seed_lo, b.seed_hi,
+                         b.sample, it.layer, it.Cp, it.KWp, it.src_KW, it.src_C, nullptr, write_mu, sig, lanes,
+                         it.delta_off, b.sample_ptr);
 }
 
 template <int PREC>

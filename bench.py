@@ -277,53 +277,67 @@ def time_sampling(model, lanes, reps=10):
     return e0.elapsed_time(e1) / (2 * reps) * 1e3
 
 
-def measure_traffic(timeout_s=150):
-    """HBM bytes of the worst stride-1 3x3 launch (ResNet18 layer4: 512->512 on 7x7, batch 64: weights dominate),
-    INCLUDING its sampling pre-pass and split-K reduce, from rocprofv3 PMC counters collected now (two passes:
-    FETCH_SIZE, WRITE_SIZE; gfx950 correction FETCH x2 per MI355X_MICROARCH.md §HBM).  None when rocprofv3 is missing
-    or fails (the committed profiles/ then hold the last collected numbers)."""
+def measure_traffic(lanes=8, timeout_s=240):
+    """HBM bytes per LAUNCH of the stride-1 3x3 convolutions of ResNet18 layer1 / layer3 / layer4 (batch 64) the way the
+    timed loop runs them — `lanes` MC samples per contraction launch, their weights sampled by one pre-pass launch with
+    the mean tiles cached (tools/gpu_diag.py lanes) — from rocprofv3 PMC counters collected now (two passes per shape:
+    FETCH_SIZE, WRITE_SIZE; gfx950 correction FETCH x2, MI355X_MICROARCH.md section HBM).  The headline numbers are those of
+    layer4 (weights dominate: the worst ratio).  None when rocprofv3 is missing or fails (profiles/pmc_traffic.json then
+    holds the last collected numbers)."""
     import glob
     import shutil
     import sqlite3
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
-    shape = "512,512,7,1,3"
-    vals = {}
+    shapes = [("layer4", 512, 7), ("layer3", 256, 14), ("layer1", 64, 56)]
+    out = {}
     tmp = tempfile.mkdtemp(prefix="btx_pmc_")
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable,
-                   os.path.join(ROOT, "tools", "gpu_diag.py"), "one", "--prec", "bf16", "--iters", "4", "--shape", shape]
-            subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=timeout_s / 2, check=True)
-            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
-            con = sqlite3.connect(dbs[0])
-            cur = con.cursor()
-            tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
-            tab = lambda p: [t for t in tabs if t.startswith(p)][0]  # noqa: E731
-            ev, disp, sym = tab("rocpd_pmc_event"), tab("rocpd_kernel_dispatch"), tab("rocpd_info_kernel_symbol")
-            cols = [c[1] for c in cur.execute("pragma table_info('%s')" % disp)]
-            rows = cur.execute(
-                "select s.kernel_name, avg(q.v) from (select d.kernel_id as kid, sum(e.value) as v from '%s' e join '%s' d "
-                "on e.event_id = d.%s group by d.id) q join '%s' s on s.id = q.kid group by s.kernel_name" % (
-                    ev, disp, "event_id" if "event_id" in cols else "id", sym)).fetchall()
-            vals[ctr] = {kn: v for kn, v in rows if "btx" in kn or "presample" in kn or "splitk" in kn}
+        for name, ch, hw in shapes:
+            vals = {}
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, name + ctr)
+                cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable,
+                       os.path.join(ROOT, "tools", "gpu_diag.py"), "lanes", "--prec", "bf16", "--iters", "3",
+                       "--lanes", str(lanes), "--shape", "%d,%d,%d,1,3" % (ch, ch, hw)]
+                subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout_s / 6, check=True)
+                dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+                con = sqlite3.connect(dbs[0])
+                cur = con.cursor()
+                tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+                tab = lambda p: [t for t in tabs if t.startswith(p)][0]  # noqa: E731
+                ev, disp, sym = tab("rocpd_pmc_event"), tab("rocpd_kernel_dispatch"), tab("rocpd_info_kernel_symbol")
+                cols = [c[1] for c in cur.execute("pragma table_info('%s')" % disp)]
+                # per dispatch: counter summed over its instances; per kernel: the MINIMUM over dispatches = the steady
+                # state (the first sampling call also writes the mean tiles and the sigma cache)
+                rows = cur.execute(
+                    "select s.kernel_name, min(q.v) from (select d.kernel_id as kid, sum(e.value) as v from '%s' e join '%s' d "
+                    "on e.event_id = d.%s group by d.id) q join '%s' s on s.id = q.kid group by s.kernel_name" % (
+                        ev, disp, "event_id" if "event_id" in cols else "id", sym)).fetchall()
+                vals[ctr] = {kn: v for kn, v in rows if "btx" in kn or "presample" in kn or "splitk" in kn}
+            per = {}
+            for kn in set(vals.get("FETCH_SIZE", {})) | set(vals.get("WRITE_SIZE", {})):
+                short = "contraction" if "taps" in kn else ("sampling" if "presample" in kn else ("splitk" if "splitk" in kn else kn[:40]))
+                per[short] = per.get(short, 0.0) + 2.0 * 1024.0 * vals["FETCH_SIZE"].get(kn, 0.0) + 1024.0 * vals["WRITE_SIZE"].get(kn, 0.0)
+            if not per:
+                return None
+            # algorithmic: every lane's input and output once (bf16) + (mu, rho) once per launch (f32)
+            algo = lanes * 64 * hw * hw * ch * 2 * 2 + 8 * ch * ch * 9
+            out[name] = {"launch": "flipout 3x3 s1 cin%d cout%d %dx%d, batch 64 x %d lanes" % (ch, ch, hw, hw, lanes),
+                         "hbm_bytes": sum(per.values()), "by_kernel": per, "algorithmic_bytes": algo,
+                         "ratio": sum(per.values()) / algo}
     except Exception:  # noqa
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    per = {}
-    for kn in set(vals.get("FETCH_SIZE", {})) | set(vals.get("WRITE_SIZE", {})):
-        short = "taps" if "taps" in kn else ("presample" if "presample" in kn else ("splitk" if "splitk" in kn else kn[:40]))
-        per[short] = per.get(short, 0.0) + 2.0 * 1024.0 * vals["FETCH_SIZE"].get(kn, 0.0) + 1024.0 * vals["WRITE_SIZE"].get(kn, 0.0)
-    if not per:
-        return None
-    algo = 64 * 7 * 7 * 512 * 2 * 2 + 8 * 512 * 512 * 9  # x + out (bf16) + (mu, rho) f32
-    return {"launch": "flipout 3x3 s1 cin512 cout512 M3136 (ResNet18 layer4)", "hbm_bytes": sum(per.values()),
-            "by_kernel": per, "algorithmic_bytes": algo, "ratio": sum(per.values()) / algo,
-            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE"}
+    l4 = out["layer4"]
+    return {"launch": l4["launch"] + " (ResNet18 layer4) incl. its weight-sampling launch", "hbm_bytes": l4["hbm_bytes"],
+            "by_kernel": l4["by_kernel"], "algorithmic_bytes": l4["algorithmic_bytes"], "ratio": l4["ratio"],
+            "layers": out, "mc_samples_per_launch": lanes,
+            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of tools/gpu_diag.py lanes, steady-state "
+                   "dispatch; bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -573,15 +587,43 @@ def run_train_step(dev, steps=5):
         loss = step()
     torch.cuda.synchronize(dev)
     ms = 1e3 * (time.perf_counter() - t0) / steps
+    # parity figure: the same step (same parameters, same MC sample index => same BTX-RNG noise) in f32 parity mode —
+    # loss and the weight gradients of the first convolution, a layer3 convolution and the classifier
+    def grads(m, xin):
+        for p_ in m.parameters():
+            p_.grad = None
+        bt.set_sample_index(m, 11)
+        out = m(xin)
+        loss_ = torch.nn.functional.cross_entropy(out.float(), y) + bt.get_kl_loss(m) / 64
+        loss_.backward()
+        picks = [m.conv1, m.layer3[0].conv1, m.fc]
+        return float(loss_), [l_._w()[0].grad.detach().float().clone() for l_ in picks], [l_._w()[1].grad.detach().float().clone() for l_ in picks]
+    parity = None
+    try:
+        l16, gm16, gr16 = grads(model, x)
+        bt.set_precision("f32")
+        ref = build_model("Flipout", dev, torch.float32, fuse=False).train()
+        l32, gm32, gr32 = grads(ref, x.float())
+        rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+        parity = {"reference": "the same step in f32 parity mode (f32 activations, v_mfma_f32_32x32x2_f32), same sample index",
+                  "loss_rel_err": abs(l16 - l32) / abs(l32),
+                  "dmu_rel_l2": {n: rel(a, b) for n, a, b in zip(("conv1", "layer3.0.conv1", "fc"), gm16, gm32)},
+                  "drho_rel_l2": {n: rel(a, b) for n, a, b in zip(("conv1", "layer3.0.conv1", "fc"), gr16, gr32)}}
+        del ref
+    except Exception as e:  # noqa
+        parity = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        bt.set_precision("bf16")
     # forward 464.4 + data gradient 434.2 (no dx for the stem) + weight gradient 464.4 GFLOP (Flipout: two contractions
     # each; the stem counted with its own 7x7x3 taps, not the padded row-fused geometry)
     gflop = 464.4 + (464.4 - 30.2) + 464.4
     return {"workload": "training step (README.md:114-125): dnn_to_bnn(ResNet18) Flipout bs64, bf16 activations, forward + "
                         "CE + KL/B + backward through libbtx (f32-MFMA weight gradients), eager launches",
-            "ms_per_step": ms, "achieved_tflops": gflop / ms, "loss_finite": bool(torch.isfinite(loss))}
+            "ms_per_step": ms, "achieved_tflops": gflop / ms, "loss_finite": bool(torch.isfinite(loss)),
+            "parity_vs_f32_mode": parity}
 
 
-def summarise_extra(name, r, prec):
+def summarise_extra(name, r, prec, table=False):
     peak = MFMA_PEAK_TFLOPS[prec]
     out = {"workload": name, "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "MC-samples/s", "dtype": prec,
            "kl": r["kl"], "lanes": r["lanes"], "lane_mode": r.get("lane_mode"), "ms_per_step_runs": r.get("ms_per_step_runs")}
@@ -592,6 +634,17 @@ def summarise_extra(name, r, prec):
         out.update({"gflop_per_step": r["gflop_per_step"], "achieved_e2e_tflops": r["achieved_e2e_tflops"],
                     "frac_e2e": r["achieved_e2e_tflops"] / peak, "dominant_kernel_tflops": r["dominant_tflops"],
                     "dominant_kernel_frac": r["dominant_tflops"] / peak, "kernel_us_per_step": r["kernel_us_per_step"]})
+        if table:  # launches of a forward grouped by shape: count, time per launch, share of its own bound
+            rows = {}
+            for pl in r["per_launch"]:
+                g = rows.setdefault(pl["launch"], {"launch": pl["launch"], "count": 0, "us": 0.0, "gflop": pl["gflop"],
+                                                   "bound": pl["bound"], "frac": 0.0, "lanes": pl.get("lanes")})
+                g["count"] += 1
+                g["us"] += pl["us"]
+                g["frac"] += pl.get("frac_incl_sampling", pl["frac"])
+            out["per_launch"] = [dict(g, us=round(g["us"] / g["count"], 2), frac=round(g["frac"] / g["count"], 3),
+                                      share_of_kernel_time=round(g["us"] / sum(q["us"] for q in rows.values()), 3))
+                                 for g in rows.values()]
     return out
 
 
@@ -725,7 +778,7 @@ def main():
         if "per_launch" in head:
             traffic = None
             if world == 1 and not args.no_traffic and args.arch == "resnet18" and args.prec == "bf16":
-                traffic = measure_traffic()
+                traffic = measure_traffic(lanes=head["launch_lanes"])
             tsrc = "measured in this run"
             if traffic is None:
                 tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -790,7 +843,17 @@ def main():
                     "cfg4 shard in f32 parity mode (v_mfma_f32_32x32x2_f32, f32 activations)", r, "f32")
                 extra["cfg2"] = run_mlp_config(dev)
                 r = run_resnet_config("resnet50", "Flipout", "bf16", 128, True, 6, 2, args.lanes, dev, parity=True, prewarm=3)
-                extra["cfg5"] = summarise_extra("cfg5 shard: dnn_to_bnn(ResNet50) Flipout + MOPED(0.5) bs128 bf16", r, "bf16")
+                extra["cfg5"] = summarise_extra("cfg5 shard: dnn_to_bnn(ResNet50) Flipout + MOPED(0.5) bs128 bf16", r, "bf16",
+                                                table=True)
+                # the strong-scaling shape of cfg4 (32 samples over 8 GPUs): 4 MC samples on this rank, one replay — the
+                # fixed cost per rank (graph launch, packed-vector fold) is visible against the 24-sample region above
+                r = run_resnet_config("resnet18", "Flipout", "bf16", 64, False, 4, 3, 4, dev, per_launch=False, prewarm=3,
+                                      scaling="strong", total=4)
+                extra["cfg4_strong_shape_4_per_rank"] = {
+                    "workload": "cfg4 strong-scaling shape: 4 MC samples on this rank (32 over 8 GPUs), one hipGraph replay of 4 lanes",
+                    "ms_per_step": r["ms_per_step"], "ms_per_region": r["ms_per_step"] * 4, "value": r["value"],
+                    "unit": "MC-samples/s", "ms_per_step_runs": r.get("ms_per_step_runs"),
+                    "vs_weak_region": r["value"] / head["value"]}
                 extra["train_step"] = run_train_step(dev)
             except Exception as e:  # noqa — the headline must survive a failing extra
                 extra["error"] = "%s: %s" % (type(e).__name__, e)

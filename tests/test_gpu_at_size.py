@@ -17,6 +17,7 @@ import numpy as np
 import pytest
 import torch
 
+BENCH_LANES = 8  # bench.py --lanes default
 pytestmark = pytest.mark.gpu
 warnings.filterwarnings("ignore")
 
@@ -128,14 +129,16 @@ def test_resnet50_moped_bs128_every_layer(prec, tol):
                                                     ("resnet50", "Flipout", True, 128, 1e-2)])
 def test_benched_configuration_end_to_end(arch, typ, moped, bs, tol):
     """bench.py's configuration — bf16, eval-BN/ReLU/residual folded into the epilogues (fuse_resnet), one weight
-    sampling launch per sample, hipGraph replay with 3 MC samples in flight — against the UNFUSED f32-parity-mode op
-    chain of the same parameters evaluated eagerly with the same sample indices (same BTX-RNG noise)."""
+    sampling launch for all lanes, hipGraph replay with BENCH_LANES MC samples as lanes of one launch per layer (bench.py's
+    default) — against the UNFUSED f32-parity-mode op chain of the same parameters evaluated eagerly with the same sample
+    indices (same BTX-RNG noise).  Two replays: the second one reads the cached mean tiles (BTX_SAMPLE_SKIP_MU)."""
     import bayesian_torch_amd as bt
     from bayesian_torch_amd import mc
     from bayesian_torch_amd.models.fuse import fuse_resnet
     dev = _dev()
     bt.manual_seed(2024)
-    samples = [11, 12, 13]
+    samples = list(range(11, 11 + 2 * BENCH_LANES))
+    checked = [0, 1, BENCH_LANES - 1, BENCH_LANES, 2 * BENCH_LANES - 1]  # lanes of both replays (the f32 reference is eager: a few)
     try:
         bt.set_precision("f32")
         ref_m = _build(arch, typ, moped, dev, False)
@@ -143,18 +146,23 @@ def test_benched_configuration_end_to_end(arch, typ, moped, bs, tol):
         x = torch.randn(bs, 3, 224, 224, device=dev)
         refs = []
         with torch.no_grad():
-            for s in samples:
-                bt.set_sample_index(ref_m, s)
+            for k in checked:
+                bt.set_sample_index(ref_m, samples[k])
                 refs.append(ref_m(x).float().clone())
         del ref_m
         bt.set_precision("bf16")
         m = _build(arch, typ, moped, dev, True)
         fuse_resnet(m)
-        g = mc.GraphedMC(m, x.to(torch.bfloat16), kl=0.0, lanes=3, keep_logits=True)
-        g.run_many(samples)
-        torch.cuda.synchronize()
-        errs = [float((g.lane_logits[k].float() - refs[k]).norm() / refs[k].norm()) for k in range(3)]
+        g = mc.GraphedMC(m, x.to(torch.bfloat16), kl=0.0, lanes=BENCH_LANES, keep_logits=True)
+        errs = []
+        for rep in range(2):
+            g.run_many(samples[rep * BENCH_LANES:(rep + 1) * BENCH_LANES])
+            torch.cuda.synchronize()
+            for i, k in enumerate(checked):
+                if k // BENCH_LANES == rep:
+                    errs.append(float((g.lane_logits[k % BENCH_LANES].float() - refs[i]).norm() / refs[i].norm()))
         g.close()
+        assert len(errs) == len(checked)
         assert not torch.equal(refs[0], refs[1])
         print("%s %s%s bs%d: logits rel-L2 of the graphed bf16 configuration vs the unfused f32 chain: %s" % (
             arch, typ, "+MOPED" if moped else "", bs, ", ".join("%.3g" % e for e in errs)))

@@ -119,6 +119,34 @@ def one(prec, iters, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def lanes_run(prec, iters, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64, lanes=8):
+    """one layer shape the way the bench's MC loop runs it: `lanes` MC samples per launch (their own activations), the
+    weights sampled for all lanes by one pre-pass launch with the mean tiles cached after the first call (skip_mu) —
+    `iters` x (sampling launch + contraction launch): the target of the rocprofv3 --pmc traffic runs of bench.py"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L, rng as R
+    dev = torch.device("cuda:0")
+    act = torch.bfloat16 if prec == "bf16" else torch.float32
+    torch.manual_seed(0)
+    bt.manual_seed(1)
+    layer = getattr(L, "Conv2d" + typ)(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(dev)
+    layer.precision = prec
+    bt.assign_layer_ids(layer)
+    x = torch.randn(lanes * bs, cin, hw, hw, device=dev).to(act).contiguous(memory_format=torch.channels_last)
+    cache = {}
+    with torch.no_grad():
+        sd = bt.set_sample_lanes(layer, list(range(lanes)), batch=bs)
+        layer._forward_hip(x)  # records the input shape the pre-pass needs
+        R._presample(layer, 0, cache=cache)
+        layer._forward_hip(x)
+        torch.cuda.synchronize()
+        for i in range(iters):
+            bt.set_sample_lanes(layer, [100 + i * lanes + l for l in range(lanes)], batch=bs, sample_dev=sd)
+            R._presample(layer, 100 + i * lanes, cache=cache, skip_mu=True)
+            layer._forward_hip(x)
+    torch.cuda.synchronize()
+
+
 def gtime(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64, reps=20):
     """GPU time of one layer call (all its kernels) with the host out of the picture: `reps` calls captured in a
     hipGraph, replayed and timed with events"""
@@ -209,11 +237,15 @@ if __name__ == "__main__":
     ap.add_argument("--shape", default="64,64,56,1,3")
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--warm", type=int, default=3)
+    ap.add_argument("--lanes", type=int, default=8)
     ap.add_argument("--throughput-plan", action="store_true")
     a = ap.parse_args()
     if a.throughput_plan:
         from bayesian_torch_amd import functional as _BF
         _BF._CONCURRENT = True
+    if "lanes" in a.what:
+        c = [int(v) for v in a.shape.split(",")]
+        lanes_run(a.prec.split(",")[0], a.iters, *c, bs=a.bs, lanes=a.lanes)
     if "one" in a.what or "timeone" in a.what:
         c = [int(v) for v in a.shape.split(",")]
         us = one(a.prec.split(",")[0], a.iters, *c, bs=a.bs)

@@ -1,44 +1,169 @@
 #!/usr/bin/env python3
-"""Regenerates profiles/ from the last GPU session's gpurun_out/ (steps: prof, pmc, gtimes, ptrace of tools/gpu_session.sh)."""
+"""One command per file under profiles/ (round 3 on).  Run the collecting steps on a GPU box, e.g.
+
+    gpurun --timeout 2400 -- 'python tools/refresh_profiles.py bench trace pmc'     # writes gpurun_out/profiles/*
+    python tools/refresh_profiles.py install                                        # here: gpurun_out/profiles/* -> profiles/
+
+steps (each writes the files named in its docstring, with the command that produced them in the header):
+  bench       profiles/r03_bench_line.json (+ _summary.txt)            python bench.py (the driver's default invocation)
+  trace       profiles/r03_bench_kernel_trace_stats.txt, _lanes1.txt   rocprofv3 --kernel-trace of the bench command
+  pmc         profiles/r03_pmc_taps_lanes.txt                          SQ counters of contract_taps_kernel, many-tiles regime
+  phase       profiles/r03_phase_timers.txt, r03_phase_timers_sustained.txt   block phase timers (trace build)
+  ablation    profiles/r03_kloop_ablation.txt                          what the K loop pays for (ablation builds)
+  ubench      profiles/r03_mfma_mix_ubench.txt                         tools/ubench/mfma_mix.hip
+  persistent  profiles/r03_persistent_kbench.txt                       persistent kernel A/B (tuning build)
+  tall        profiles/r03_tall_tiles_ab.txt                           tall-strip tiles A/B
+The measurement builds (build_variants/libbtx_{tune,trace,abl*}.so) are made by tools/build_variants.sh when missing.
+"""
+import glob
 import json
 import os
-import re
+import shutil
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.chdir(ROOT)
+OUT = os.path.join(ROOT, "gpurun_out", "profiles")
+ENV = dict(os.environ, TMPDIR="/tmp")
+SHAPES = ["64,64,56,1,3", "128,128,28,1,3", "256,256,14,1,3", "512,512,7,1,3"]
 
 
-def run(cmd):
-    return subprocess.run(cmd, shell=True, capture_output=True, text=True).stdout
+def sh(cmd, env=None, timeout=1500, cwd=ROOT):
+    r = subprocess.run(cmd, shell=True, capture_output=True, text=True, env=dict(ENV, **(env or {})), timeout=timeout, cwd=cwd)
+    return "\n".join(l for l in (r.stdout + r.stderr).splitlines() if "amdgpu.ids" not in l) + "\n"
 
 
-hdr = ("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (1 MI355X, ROCm 7.2; 12 pre-warm +\n"
-       "# 2 warm-up + 5 timed graph replays + 5 eager re-issues with per-launch events + capture warm-ups; tools/trace_report.py)\n")
-open("profiles/r01_bench_kernel_trace_stats.txt", "w").write(hdr + run("python tools/trace_report.py gpurun_out/prof/bench_results.db"))
-hdr = ("# rocprofv3 --pmc <set> --kernel-trace -- python tools/gpu_diag.py one --prec bf16 --iters 6   (ResNet18 layer1: 3x3 conv 64->64,\n"
-       "# 56x56, batch 64, Flipout, bf16: the most frequent launch of the bench step; one --pmc pass per counter set; tools/pmc_report.py)\n"
-       "# counters slow the kernel down (the plain kernel trace has it at ~47 us)\n")
-pm = run("python tools/pmc_report.py 'gpurun_out/pmc*/pmc_results.db' --kernel patch")
-open("profiles/r01_pmc_layer1_conv3x3_flipout_bf16.txt", "w").write(hdr + pm + run("python tools/pmc_report.py 'gpurun_out/pmc1/pmc_results.db' --kernel presample"))
-hdr = ("# GPU time of ONE layer call (sampling pre-pass + contraction + split-K reduce + the input packing of the stem),\n"
-       "# 20 calls captured in a hipGraph and replayed (tools/gpu_diag.py gtime): no host launch overhead in the number.\n"
-       "# shape = cin,cout,hw,stride,k ; Flipout, bf16 activations + bf16 MFMA, batch 64; TFLOP/s = 2*2*M*N*K / time\n")
-open("profiles/r01_per_layer_resnet18_bs64.txt", "w").write(hdr + open("gpurun_out/gtimes.log").read())
-if os.path.exists("gpurun_out/ptrace.log"):
-    hdr = ("# per-wave phase timers (s_memtime, ~2.4 GHz ticks; -DBTX_PT_TRACE build, tools/gpu_diag.py trace): mean/min/max over all waves\n"
-           "# of one launch.  A->B = DMA issue + fragment reads + MFMA issue, B->C = timer read + vmcnt wait, C->D = barrier wait (summed over\n"
-           "# the K stages of the block).  shape = cin,cout,hw,stride,k ; Flipout bf16 batch 64\n")
-    tr = "".join(l for l in open("gpurun_out/ptrace.log") if " wave " not in l and "kernel span" not in l and "column 7" not in l)
-    open("profiles/r01_phase_timers.txt", "w").write(hdr + tr)
-f = float(re.search(r"FETCH_SIZE\s+([0-9.e+]+)", pm).group(1))
-w = float(re.search(r"WRITE_SIZE\s+([0-9.e+]+)", pm).group(1))
-j = {"hbm_bytes_per_launch": (2 * f + w) * 1024.0,
-     "launch": "contract_patch_kernel<bf16,Flipout,4 waves> on ResNet18 layer1 3x3 conv, bs 64 (the most frequent launch of the bench step)",
-     "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
-     "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md HBM "
-             "section); separate --pmc passes, rocprofv3",
-     "algorithmic_bytes_per_launch": 51675136}
-j["ratio"] = j["hbm_bytes_per_launch"] / j["algorithmic_bytes_per_launch"]
-json.dump(j, open("profiles/pmc_traffic.json", "w"), indent=1)
-print(open("profiles/pmc_traffic.json").read())
+def write(name, header, body):
+    os.makedirs(OUT, exist_ok=True)
+    open(os.path.join(OUT, name), "w").write("".join("# " + l + "\n" for l in header.strip().splitlines()) + body)
+    print("wrote", os.path.join("gpurun_out/profiles", name))
+
+
+def variant(name, flags):
+    so = os.path.join(ROOT, "build_variants", "libbtx_%s.so" % name)
+    if not os.path.exists(so):
+        print(sh("bash tools/build_variants.sh %s '%s'" % (name, flags), timeout=3000))
+    return so
+
+
+def step_bench():
+    out = sh("python bench.py", timeout=2400)
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    os.makedirs(OUT, exist_ok=True)
+    json.dump(d, open(os.path.join(OUT, "r03_bench_line.json"), "w"), indent=1)
+    r = d["roofline"]
+    body = "value %.1f %s  ms/step %.4f  regions %s\n" % (d["value"], d["unit"], d["ms_per_step"], ["%.3f" % v for v in d["ms_per_step_runs"]])
+    body += "roofline.frac %.4f (contraction only %.4f)  e2e %.4f  sampling %.1f us per %d-lane launch\n" % (
+        r["frac"], r["frac_contraction_only"], r["frac_e2e"], r["sampling_us_per_launch"], r["mc_samples_per_launch"])
+    body += "traffic (%s): %s\n" % (r["traffic_source"], json.dumps({k: round(v["ratio"], 2) for k, v in (r["traffic_detail"] or {}).get("layers", {}).items()}))
+    body += "parity: logits rel-L2 %s  KL rel err %s\n" % (d.get("logits_rel_l2_vs_unfused_f32"), d.get("kl_rel_err"))
+    for row in r["per_launch"]:
+        body += "  %-46s %8.1f us  %7.1f TFLOP/s  %5.2f TB/s  %s %.3f\n" % (row["launch"], row["us"], row["tflops"], row["tbs"], row["bound"], row["frac_incl_sampling"])
+    for k, v in d.get("extra", {}).items():
+        body += "%s: %s\n" % (k, json.dumps(v)[:600])
+    body += "cpu_baseline: %s\n" % json.dumps(d.get("cpu_baseline"))[:400]
+    write("r03_bench_summary.txt", "python bench.py   (1 MI355X; the JSON line is profiles/r03_bench_line.json)", body)
+
+
+def step_trace():
+    for tag, extra in (("stats", ""), ("lanes1", " --lanes 1")):
+        d = os.path.join(ROOT, "gpurun_out", "r3_kt_" + tag)
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = "python %s/bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline --no-traffic%s" % (ROOT, extra)
+        sh("rocprofv3 --kernel-trace --stats -d %s -o kt -- %s" % (d, cmd), cwd="/tmp", timeout=1200)
+        db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+        body = sh("python tools/trace_report.py %s" % db[0]) if db else "(no trace written)\n"
+        write("r03_bench_kernel_trace_%s.txt" % tag,
+              "cd /tmp && rocprofv3 --kernel-trace --stats -- %s   (1 MI355X; tools/trace_report.py on the result)\n"
+              "%s" % (cmd.replace(ROOT + "/", ""), "lanes 1: one MC sample per launch — the dominant kernel's average here is a single-sample launch"
+                      if extra else "the bench's default: 8 MC samples per launch (lanes), per-launch replays included"), body)
+
+
+def step_pmc():
+    sets = ["SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES",
+            "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_MFMA",
+            "GRBM_GUI_ACTIVE"]
+    body = ""
+    for shp in SHAPES[:2]:
+        for i, s in enumerate(sets):
+            d = os.path.join(ROOT, "gpurun_out", "r3_pmc%d_%s" % (i, shp.replace(",", "_")))
+            shutil.rmtree(d, ignore_errors=True)
+            sh("rocprofv3 --pmc %s --kernel-trace -d %s -o pmc -- python %s/tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 "
+               "--bs 256 --shape %s" % (s, d, ROOT, shp), cwd="/tmp", timeout=400)
+        body += "== %s\n" % shp + sh("python tools/pmc_report.py 'gpurun_out/r3_pmc*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
+    write("r03_pmc_taps_lanes.txt",
+          "rocprofv3 --pmc <set> --kernel-trace -- python tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 --bs 256 --shape <s>\n"
+          "(one pass per counter set; batch 256 = the tiles of 4 MC sample lanes; contract_taps_kernel; tools/pmc_report.py)", body)
+
+
+def step_phase():
+    lib = variant("trace", "-DBTX_PT_TRACE -DBTX_TUNING")
+    body = ""
+    for shp in SHAPES[:2]:
+        for v in ("X=0", "BTX_NO_TALL=1", "BTX_TAPS_TUNE=128 BTX_NO_TALL=1"):
+            body += "== %s %s\n" % (shp, v) + "".join(
+                l + "\n" for l in sh("env %s python tools/gpu_diag.py trace --prec bf16 --shape %s" % (v, shp), env={"BTX_LIB": lib}).splitlines()
+                if " wave " not in l and "column 7" not in l)
+    write("r03_phase_timers.txt", "BTX_LIB=build_variants/libbtx_trace.so python tools/gpu_diag.py trace --prec bf16 --shape <s>  (batch 64, one launch;\n"
+          "X=0: tall-strip tiles where the plan takes them, BTX_NO_TALL=1: plain tiles, BTX_TAPS_TUNE=128: prologue sub-stamps)", body)
+    body = ""
+    for shp in SHAPES[:2]:
+        for v in ("BTX_PERSIST=1", "X=0"):
+            body += "== %s %s (600 warm launches)\n" % (shp, v) + "".join(
+                l + "\n" for l in sh("env %s BTX_NO_TALL=1 python tools/gpu_diag.py trace --throughput-plan --bs 256 --warm 600 --prec bf16 --shape %s" % (v, shp),
+                                     env={"BTX_LIB": lib}).splitlines() if " wave " not in l and "column 7" not in l)
+    write("r03_phase_timers_sustained.txt", "BTX_LIB=build_variants/libbtx_trace.so [BTX_PERSIST=1] BTX_NO_TALL=1 python tools/gpu_diag.py trace --throughput-plan --bs 256\n"
+          "--warm 600 --prec bf16 --shape <s>: block phase timers and the shader clock (s_memtime / s_memrealtime) under sustained load,\n"
+          "persistent kernel (contract_taps3_kernel) against contract_taps_kernel", body)
+
+
+def kbench(lib, envs, shapes, bs=256, env=None):
+    return sh("python tools/kbench.py --throughput-plan --env %s --bs %d --rounds 3 --reps 10 --shapes %s" % (" ".join(envs), bs, " ".join(shapes)),
+              env=dict({"BTX_LIB": lib}, **(env or {})), timeout=900)
+
+
+def step_ablation():
+    body = ""
+    for name, flags in (("tune", "-DBTX_TUNING"), ("abl4", "-DBTX_TUNING -DBTX_PT_ABL=4"), ("abl16", "-DBTX_TUNING -DBTX_PT_ABL=16"),
+                        ("abl2", "-DBTX_TUNING -DBTX_PT_ABL=2"), ("abl22", "-DBTX_TUNING -DBTX_PT_ABL=22")):
+        body += "## %s\n" % name + kbench(variant(name, flags), ["-"], [SHAPES[0], SHAPES[1], SHAPES[3]], env={"BTX_NO_TALL": "1"})
+    write("r03_kloop_ablation.txt", "BTX_NO_TALL=1 BTX_LIB=build_variants/libbtx_<v>.so python tools/kbench.py --throughput-plan --env - --bs 256 ...\n"
+          "builds with -DBTX_PT_ABL=<bits>: 4 no weight/patch DMA in the K loop, 16 no s_in masks, 2 no LDS fragment reads, 22 all three\n"
+          "(results wrong by construction; time only)", body)
+
+
+def step_ubench():
+    sh("/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip", timeout=900)
+    write("r03_mfma_mix_ubench.txt", "hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip && tools/ubench/mfma_mix", sh("tools/ubench/mfma_mix", timeout=600))
+
+
+def step_persistent():
+    lib = variant("tune", "-DBTX_TUNING")
+    write("r03_persistent_kbench.txt", "BTX_NO_TALL=1 BTX_LIB=build_variants/libbtx_tune.so python tools/kbench.py --throughput-plan --env BTX_PERSIST=1 - --bs 256 ...\n"
+          "(contract_taps3_kernel against contract_taps_kernel; '== variant0: True' = bit-identical results)",
+          sh("python tools/kbench.py --throughput-plan --env BTX_PERSIST=1 - --bs 256 --rounds 3 --reps 10 --shapes %s" % " ".join(SHAPES),
+             env={"BTX_LIB": lib, "BTX_NO_TALL": "1"}, timeout=900))
+
+
+def step_tall():
+    lib = variant("tune", "-DBTX_TUNING")
+    body = ""
+    for bs in (64, 256, 512):
+        body += "## batch %d\n" % bs + kbench(lib, ["-", "BTX_NO_TALL=1"], SHAPES, bs=bs)
+    write("r03_tall_tiles_ab.txt", "BTX_LIB=build_variants/libbtx_tune.so python tools/kbench.py --throughput-plan --env - BTX_NO_TALL=1 --bs <b> ...\n"
+          "(tall-strip tiles where the plan takes them against plain tiles)", body)
+
+
+def step_install():
+    n = 0
+    for f in sorted(glob.glob(os.path.join(OUT, "*"))):
+        shutil.copy(f, os.path.join(ROOT, "profiles", os.path.basename(f)))
+        n += 1
+    print("installed %d file(s) into profiles/" % n)
+
+
+if __name__ == "__main__":
+    steps = sys.argv[1:] or ["install"]
+    for s in steps:
+        globals()["step_" + s]()
