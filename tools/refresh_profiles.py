@@ -115,7 +115,9 @@ def step_phase():
                                      env={"BTX_LIB": lib}).splitlines() if " wave " not in l and "column 7" not in l)
     write("r03_phase_timers_sustained.txt", "BTX_LIB=build_variants/libbtx_trace.so [BTX_PERSIST=1] BTX_NO_TALL=1 python tools/gpu_diag.py trace --throughput-plan --bs 256\n"
           "--warm 600 --prec bf16 --shape <s>: block phase timers and the shader clock (s_memtime / s_memrealtime) under sustained load,\n"
-          "persistent kernel (contract_taps3_kernel) against contract_taps_kernel", body)
+          "persistent kernel (contract_taps3_kernel) against contract_taps_kernel.  Reading: per tile the persistent kernel needs fewer\n"
+          "cycles (56x56: (K loops + store sides) / 7 tiles ~ 29k against ~35k for a one-tile block) but runs at a lower clock under the\n"
+          "higher duty (1.9 against 2.2 GHz): the launch takes the same time (r03_persistent_kbench.txt, r03_persistent_ab.txt)", body)
 
 
 def kbench(lib, envs, shapes, bs=256, env=None):
@@ -130,12 +132,21 @@ def step_ablation():
         body += "## %s\n" % name + kbench(variant(name, flags), ["-"], [SHAPES[0], SHAPES[1], SHAPES[3]], env={"BTX_NO_TALL": "1"})
     write("r03_kloop_ablation.txt", "BTX_NO_TALL=1 BTX_LIB=build_variants/libbtx_<v>.so python tools/kbench.py --throughput-plan --env - --bs 256 ...\n"
           "builds with -DBTX_PT_ABL=<bits>: 4 no weight/patch DMA in the K loop, 16 no s_in masks, 2 no LDS fragment reads, 22 all three\n"
-          "(results wrong by construction; time only)", body)
+          "(results wrong by construction; time only).  Reading (128->128, 28x28): no DMA -19 %, no masks -7 %, no fragment reads -27 %,\n"
+          "none of the three: the floor set by MFMA issue, barriers, prologue and store side (118 GFLOP at ~2.1 GHz = 54 us of matrix time)", body)
 
 
 def step_ubench():
     sh("/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip", timeout=900)
-    write("r03_mfma_mix_ubench.txt", "hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip && tools/ubench/mfma_mix", sh("tools/ubench/mfma_mix", timeout=600))
+    write("r03_mfma_mix_ubench.txt", "hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip && tools/ubench/mfma_mix\n"
+          "The instruction mix of one K-stage of the Flipout tap kernel (LDS fragment reads, s_in masks, mean + delta MFMAs, a barrier; NO\n"
+          "global traffic) per register-tile shape, 12 x 50 ms launches per line, two rounds; TFLOP/s from HIP events (the cycles/stage\n"
+          "column is block 0's s_memtime delta: only meaningful for the 1-block/CU lines).\n"
+          "Reading: A, the mix of contract_taps_kernel, sustains ~1.75 PFLOP/s (0.70 of the nominal bf16 peak) at 2.03 GHz — what the K loop\n"
+          "could deliver if weight/patch DMA, real patch addressing and tile prologue/store side were free (the kernel: 0.85-1.05).  The\n"
+          "512-register 1-wave/SIMD shapes with AGPR accumulators: 4x2 tiles 0.93x, 2x4 tiles 1.03x of A (a single wave per SIMD exposes\n"
+          "the mask VALU and LDS latency a second wave hides).  Masks cost 10 % (D vs A), half the fragment reads another 8 % (E vs D).",
+          sh("tools/ubench/mfma_mix", timeout=600))
 
 
 def step_persistent():
