@@ -275,8 +275,9 @@ int btx_sample_weights(const BtxSampleItem* items_host, int n_items, const BtxRn
 /* The same for `lanes` MC samples at once (sample indices rng->sample_idx + l, or rng->sample_idx_dev[l]); `out` of each
  * item holds btx_sampled_w_bytes_lanes(...) bytes.  The mean tiles of a Flipout layer do not depend on the sample: the
  * buffer keeps ONE set for all lanes, and with BTX_SAMPLE_SKIP_MU in `sflags` the call leaves them untouched — for
- * callers that know mu has not changed since the call that last wrote them into this buffer (an MC loop over frozen
- * parameters): per sample the pre-pass then reads rho and writes sigma*eps, nothing else. */
+ * callers that know mu AND rho have not changed since the call that last wrote them into this buffer (an MC loop over
+ * frozen parameters): the buffer also keeps sigma = softplus(rho) (f32, tile order) from that call, and per MC step the
+ * pre-pass reads it once and writes sigma*eps for every lane, nothing else. */
 #define BTX_SAMPLE_SKIP_MU 1u
 size_t btx_sampled_w_bytes_lanes(const BtxGeom* g, int kind, int prec, int lanes);
 int btx_sample_weights_lanes(const BtxSampleItem* items_host, int n_items, const BtxRng* rng /* layer_id unused */,

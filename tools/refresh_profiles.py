@@ -80,6 +80,21 @@ def step_trace():
                       if extra else "the bench's default: 8 MC samples per launch (lanes), per-launch replays included"), body)
 
 
+def derived(rep):
+    """MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); issued FLOP = SQ_INSTS_MFMA x 32768;
+    LDS bank-conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"""
+    import re
+    v = {k: float(x) for k, x in re.findall(r"^\s+([A-Z_]+)\s+([0-9.e+]+)\s*$", rep, re.M)}
+    try:
+        return ("derived: MFMA busy %.1f %% of the SIMD-cycles of the launch; issued %.1f GFLOP; LDS bank-conflict cycles %.1f %% of "
+                "SQ_LDS_IDX_ACTIVE; shader clock %.2f GHz (GRBM_GUI_ACTIVE / 8 / kernel time)\n" % (
+                    100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0), v["SQ_INSTS_MFMA"] * 32768 / 1e9,
+                    100.0 * v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"],
+                    v["GRBM_GUI_ACTIVE"] / 8.0 / (float(re.findall(r"avg ([0-9.]+) us", rep)[-1]) * 1e3)))
+    except Exception as e:  # noqa
+        return "derived: (%s)\n" % e
+
+
 def step_pmc():
     sets = ["SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES",
             "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_MFMA",
@@ -91,7 +106,8 @@ def step_pmc():
             shutil.rmtree(d, ignore_errors=True)
             sh("rocprofv3 --pmc %s --kernel-trace -d %s -o pmc -- python %s/tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 "
                "--bs 256 --shape %s" % (s, d, ROOT, shp), cwd="/tmp", timeout=400)
-        body += "== %s\n" % shp + sh("python tools/pmc_report.py 'gpurun_out/r3_pmc*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
+        rep = sh("python tools/pmc_report.py 'gpurun_out/r3_pmc*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
+        body += "== %s\n" % shp + derived(rep) + rep
     write("r03_pmc_taps_lanes.txt",
           "rocprofv3 --pmc <set> --kernel-trace -- python tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 --bs 256 --shape <s>\n"
           "(one pass per counter set; batch 256 = the tiles of 4 MC sample lanes; contract_taps_kernel; tools/pmc_report.py)", body)
