@@ -259,13 +259,21 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   }
   const int row_step = p.dh * p.pt_Wp;  // patch-pixel offset of tap (kh, kw) = kh*row_step + kw*dw (wave-uniform)
 
+  // bf16, one K-group: the accumulators are started by the first stage's MFMAs (zero C operand, stage_mma<..., ZERO>) instead
+  // of 128 v_mov in the prologue; what that stage does not touch (a dead second pixel tile, a block without K work) is
+  // cleared explicitly
+  constexpr bool ZI = (PREC == 1 && KG == 1);
   f32x16 accm[MI][2], accd[MI][2];
+  auto clear_acc = [&](int a0) __attribute__((always_inline)) {
 #pragma unroll
-  for (int a = 0; a < MI; ++a)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
+        for (int r = 0; r < 16; ++r)
+          if (a >= a0) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
+  };
+  if (!ZI || ncb <= 0) clear_acc(0);
 
   using Frag = StageFragT<MI>;
   auto load_frag = [&](Frag& f, int aslot, int toffv, int wsl, auto mia_tag) __attribute__((always_inline)) {
@@ -324,8 +332,9 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
 #endif
     // One channel block = T unrolled stages.  PAR = parity of the block = its patch / sign slot; the fragment register
     // sets alternate per stage (KG == 1), T may be odd, hence two instantiations.  `last` (wave-uniform): no next block.
-    auto block = [&](auto par_tag, int cbi, bool last) __attribute__((always_inline)) {
+    auto block = [&](auto par_tag, auto first_tag, int cbi, bool last) __attribute__((always_inline)) {
       constexpr int PAR = decltype(par_tag)::value;
+      constexpr bool FIRST = decltype(first_tag)::value;  // first block of the tile: its first stage starts the accumulators
       static_for<0, T>([&](auto t_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value;
         constexpr int sp = (PAR * T + t) & 1;
@@ -367,7 +376,8 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
           constexpr int t1 = (t + 1) % T, c1 = (t + 1) / T;
           load_frag(nxt, PAR ^ c1, (t1 / KW) * row_step + (t1 % KW) * p.dw, (wslot + 1) & 3, mia_tag);
           // 4. multiply
-          stage_mma<PREC, KIND, MI, MIA>(cur, df, accm, accd, l31, h);
+          if constexpr (FIRST && t == 0) stage_mma<PREC, KIND, MI, MIA, true>(cur, df, accm, accd, l31, h);
+          else stage_mma<PREC, KIND, MI, MIA>(cur, df, accm, accd, l31, h);
           // 5. W(s+2) — and, from stage T-3 on, every piece of the next patch — landed; meet the other waves
 #ifdef BTX_PT_TRACE
           {  // split the stage end: issue+MFMA | LDS reads back | VMEM wait | barrier
@@ -409,12 +419,25 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
       });
     };
     if (KG == 2 && kg == 1) asm volatile("s_barrier" ::: "memory");
-    int cbi = 0;
-    for (; cbi + 2 <= ncb; cbi += 2) {
-      block(std::integral_constant<int, 0>{}, cbi, false);
-      block(std::integral_constant<int, 1>{}, cbi + 1, cbi + 2 == ncb);
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if constexpr (ZI) {
+      if constexpr (MIA < MI) clear_acc(MIA);
+      block(P0{}, std::true_type{}, 0, ncb == 1);
+      int cbi = 1;
+      for (; cbi + 2 <= ncb; cbi += 2) {
+        block(P1{}, std::false_type{}, cbi, false);
+        block(P0{}, std::false_type{}, cbi + 1, cbi + 2 == ncb);
+      }
+      if (cbi < ncb) block(P1{}, std::false_type{}, cbi, true);
+    } else {
+      int cbi = 0;
+      for (; cbi + 2 <= ncb; cbi += 2) {
+        block(P0{}, std::false_type{}, cbi, false);
+        block(P1{}, std::false_type{}, cbi + 1, cbi + 2 == ncb);
+      }
+      if (cbi < ncb) block(P0{}, std::false_type{}, cbi, true);
     }
-    if (cbi < ncb) block(std::integral_constant<int, 0>{}, cbi, true);
     if (KG == 2 && kg == 0) asm volatile("s_barrier" ::: "memory");
 #ifdef BTX_PT_TRACE
     tr_s[0] = tr_ab; tr_s[1] = tr_lg; tr_s[2] = tr_bc; tr_s[3] = tr_cd;

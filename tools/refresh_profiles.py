@@ -13,6 +13,7 @@ steps (each writes the files named in its docstring, with the command that produ
   ubench      profiles/r03_mfma_mix_ubench.txt                         tools/ubench/mfma_mix.hip
   persistent  profiles/r03_persistent_kbench.txt                       persistent kernel A/B (tuning build)
   tall        profiles/r03_tall_tiles_ab.txt                           tall-strip tiles A/B
+  power       profiles/r03_power_probe.txt                             socket power / clock under sustained launches
 The measurement builds (build_variants/libbtx_{tune,trace,abl*}.so) are made by tools/build_variants.sh when missing.
 """
 import glob
@@ -180,6 +181,46 @@ def step_tall():
         body += "## batch %d\n" % bs + kbench(lib, ["-", "BTX_NO_TALL=1"], SHAPES, bs=bs)
     write("r03_tall_tiles_ab.txt", "BTX_LIB=build_variants/libbtx_tune.so python tools/kbench.py --throughput-plan --env - BTX_NO_TALL=1 --bs <b> ...\n"
           "(tall-strip tiles where the plan takes them against plain tiles)", body)
+
+
+def step_power():
+    """profiles/r03_power_probe.txt: socket power and sclk (rocm-smi, every ~0.3 s) while 60 000 back-to-back launches of one
+    layer run — contract_taps_kernel against the persistent kernel; needs the tuning build"""
+    import threading
+    import time
+    lib = variant("tune", "-DBTX_TUNING")
+    body = sh("rocm-smi --showmaxpower | grep -i max")
+    for shp in SHAPES[:2]:
+        for tag, env in (("contract_taps_kernel", {}), ("persistent (BTX_PERSIST=1)", {"BTX_PERSIST": "1"})):
+            samples, done = [], []
+
+            def poll():
+                while not done:
+                    o = sh("rocm-smi --showpower --showclocks", timeout=20)
+                    try:
+                        w = float([l for l in o.splitlines() if "Socket Graphics" in l][0].split(":")[-1])
+                        c = float([l for l in o.splitlines() if "sclk" in l][0].split("(")[1].split("Mhz")[0])
+                        samples.append((w, c))
+                    except Exception:  # noqa
+                        pass
+                    time.sleep(0.3)
+            th = threading.Thread(target=poll)
+            th.start()
+            out = sh("python tools/gpu_diag.py timeone --throughput-plan --prec bf16 --bs 256 --iters 60000 --shape %s" % shp,
+                     env=dict({"BTX_LIB": lib, "BTX_NO_TALL": "1"}, **env), timeout=400)
+            done.append(1)
+            th.join()
+            busy = [(w, c) for w, c in samples if w > 500]
+            body += "%s  %-28s %s" % (shp, tag, [l for l in out.splitlines() if "us / launch" in l][-1].split(":")[-1])
+            if busy:
+                body += "   busy samples %d: mean power %.0f W (max %.0f), mean sclk %.0f MHz\n" % (
+                    len(busy), sum(w for w, _ in busy) / len(busy), max(w for w, _ in busy), sum(c for _, c in busy) / len(busy))
+            else:
+                body += "   (no busy samples)\n"
+    write("r03_power_probe.txt", "BTX_LIB=build_variants/libbtx_tune.so BTX_NO_TALL=1 [BTX_PERSIST=1] python tools/gpu_diag.py timeone --throughput-plan\n"
+          "--prec bf16 --bs 256 --iters 60000 --shape <s>, with `rocm-smi --showpower --showclocks` polled meanwhile (1 MI355X).\n"
+          "Reading: both kernels run within 4-13 % of the 1400 W package limit and below the 2.4 GHz peak clock; the persistent kernel\n"
+          "(higher matrix-pipe duty per cycle) is held at a lower clock.  tools/ubench/mfma_mix draws 1260-1340 W at 2.3-2.4 GHz.", body)
 
 
 def step_install():

@@ -21,8 +21,9 @@ __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& a)
 }
 
 // MI x NI tiles of 32 pixels x 32 channels per wave; MASK: s_in masks; RD: fragment reads per stage (1 = all, 2 = every 2nd stage)
-template <int MI, int NI, bool AG, bool MASK, int RD, int BPC>
-__global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned* clk) {
+template <int MI, int NI, bool AG, bool MASK, int RD, int BPC, int DMA = 0>
+__global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned* clk, const unsigned char* wbuf = nullptr,
+                                              const unsigned char* xbuf = nullptr, unsigned xbytes = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   for (int i = tid; i < 65536 / 4; i += 256) ((unsigned*)lds)[i] = 0x3c003c00u + ((i * 2654435761u) & 0x007f007fu);
@@ -43,8 +44,8 @@ __global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned*
   const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime(), r0 = (unsigned)__builtin_amdgcn_s_memrealtime();
   struct Frag { u32x4 A[2][MI], WM[2][NI], WD[2][NI]; unsigned sw[MI]; };
   auto load = [&](Frag& f, int s) __attribute__((always_inline)) {
-    const unsigned char* ab = lds + ((s * 4096) & 16383);
-    const unsigned char* wb = lds + 32768 + ((s * 8192) & 16383);
+    const unsigned char* ab = lds + ((s * 4096) & 8191);
+    const unsigned char* wb = lds + 12288;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -56,10 +57,31 @@ __global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned*
       }
     }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) f.sw[mi] = *(const unsigned*)(lds + 49152 + ((s * 256 + mi * 32 + l31) & 1023) * 4);
+    for (int mi = 0; mi < MI; ++mi) f.sw[mi] = *(const unsigned*)(lds + 24576 + ((s * 256 + mi * 32 + l31) & 1023) * 4);
+  };
+  // DMA stream of the kernel: every wave fetches 2 x 1 KiB of the stage's weight tiles (mean + delta row of an 8-KiB stage,
+  // 147 KiB per lane of tiles: L2-resident) into a 4-slot ring three stages ahead; DMA == 2: plus 1 KiB per wave of
+  // activations streamed from a buffer far larger than the caches
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wbuf, 0, 147456u * 8u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbuf, 0, xbytes, 0x00020000);
+  unsigned xoff = (unsigned)((blockIdx.x * 4u + wave) * 1048576u) % (xbytes ? xbytes : 1u);
+  auto dma = [&](int s) __attribute__((always_inline)) {
+    if constexpr (DMA >= 1) {
+      const unsigned so = (unsigned)((s % 18) * 8192 + (blockIdx.x & 7) * 147456) + wave * 1024u;
+      unsigned char* ld = lds + 28672 + (s & 3) * 8192 + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)ld, 16, lane * 16u, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(ld + 4096), 16, lane * 16u, so + 4096u, 0, 0);
+    }
+    if constexpr (DMA >= 2) {
+      unsigned char* ld = lds + 61440 + (s & 1) * 4096 + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)ld, 16, lane * 16u, xoff, 0, 0);
+      xoff += 1024u; if (xoff + 1024u > xbytes) xoff = 0;
+    }
   };
   // stage s multiplies `cur` while the fragments of stage s+1 are read into `nxt` (as the kernel does)
   auto stage = [&](Frag& cur, Frag& nxt, int s) __attribute__((always_inline)) {
+    dma(s + 3);
     if (RD == 1 || (s & 2) == 0) load(nxt, s + 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -82,6 +104,8 @@ __global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned*
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) mma<AG>(accd[mi][ni], cur.WD[kk][ni], cur.A[kk][mi]);
     }
+    if constexpr (DMA == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // what was issued two stages ago has landed
+    if constexpr (DMA == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   Frag fa, fb;
@@ -103,20 +127,23 @@ __global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned*
   if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
-template <int MI, int NI, bool AG, bool MASK, int RD, int BPC>
+static unsigned char* g_wbuf = nullptr;
+static unsigned char* g_xbuf = nullptr;
+static const unsigned g_xbytes = 1u << 30;
+template <int MI, int NI, bool AG, bool MASK, int RD, int BPC, int DMA = 0>
 void run(const char* name, float* sink, unsigned* clk) {
-  auto fn = k<MI, NI, AG, MASK, RD, BPC>;
-  const int lds_bytes = BPC == 2 ? 81920 : 163840;  // pins the blocks per CU
+  auto fn = k<MI, NI, AG, MASK, RD, BPC, DMA>;
+  const int lds_bytes = BPC == 2 ? 81920 : 163840;  // pins the blocks per CU (DMA rings: 64 KiB .. 108 KiB > the 80 KiB of a block when BPC == 2: folded below)
   hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   const int grid = 256 * BPC;
   const int stages = 100000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 6; ++w) fn<<<grid, 256, lds_bytes>>>(stages, sink, clk);  // ~0.1 s each: power management settles
+  for (int w = 0; w < 6; ++w) fn<<<grid, 256, lds_bytes>>>(stages, sink, clk, g_wbuf, g_xbuf, g_xbytes);  // ~0.1 s each: power management settles
   hipDeviceSynchronize();
   hipEventRecord(e0);
   const int reps = 6;
-  for (int w = 0; w < reps; ++w) fn<<<grid, 256, lds_bytes>>>(stages, sink, clk);
+  for (int w = 0; w < reps; ++w) fn<<<grid, 256, lds_bytes>>>(stages, sink, clk, g_wbuf, g_xbuf, g_xbytes);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -133,6 +160,8 @@ void run(const char* name, float* sink, unsigned* clk) {
 int main() {
   float* sink; unsigned* clk;
   hipMalloc(&sink, 16); hipMalloc(&clk, 16);
+  hipMalloc(&g_wbuf, 147456 * 8); hipMemset(g_wbuf, 0x3c, 147456 * 8);
+  hipMalloc(&g_xbuf, g_xbytes); hipMemset(g_xbuf, 0x3c, g_xbytes);
   for (int round = 0; round < 2; ++round) {
     run<2, 2, false, true, 1, 2>("A  2x2 tiles, VGPR acc, 2 blocks/CU, masks", sink, clk);
     run<4, 2, true, true, 1, 1>("B  4x2 tiles, AGPR acc, 1 block/CU, masks", sink, clk);
@@ -140,6 +169,9 @@ int main() {
     run<2, 2, false, false, 1, 2>("D  A without masks", sink, clk);
     run<2, 2, false, false, 2, 2>("E  A without masks, half the fragment reads", sink, clk);
     run<4, 2, true, false, 1, 1>("F  B without masks", sink, clk);
+    run<2, 2, false, true, 1, 2, 1>("G  A + weight-tile DMA (8 KiB per block-stage from L2)", sink, clk);
+    run<2, 2, false, true, 1, 2, 2>("H  G + 4 KiB per block-stage of activations from HBM", sink, clk);
+    run<4, 2, true, true, 1, 1, 1>("I  B + weight-tile DMA (8 KiB per 512-pixel block-stage)", sink, clk);
   }
   return 0;
 }
