@@ -1192,16 +1192,17 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     long long blocks = (total / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    for (int l = 0; l < lanes && !rc; ++l) {
-      const float* part = (const float*)((const unsigned char*)ws + (long long)l * p.lane_partial);
-      unsigned char* o = (unsigned char*)out + (long long)l * p.lane_out;
-      const unsigned char* r = p.ep_res ? (const unsigned char*)p.ep_res + (long long)l * p.lane_res : nullptr;
+    {  // one launch for all MC sample lanes (blockIdx.y)
+      const float* part = (const float*)ws;
+      const unsigned char* r = (const unsigned char*)p.ep_res;
       if (out_bf16)
-        hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, part, (__bf16*)o, total,
-                           pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const __bf16*)r, p.ep_relu);
+        hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((int)blocks, lanes), dim3(256), 0, st, part, (__bf16*)out, total,
+                           pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const __bf16*)r, p.ep_relu, p.lane_partial, p.lane_out,
+                           p.lane_res);
       else
-        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, st, part, (float*)o, total,
-                           pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const float*)r, p.ep_relu);
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((int)blocks, lanes), dim3(256), 0, st, part, (float*)out, total,
+                           pl.ksplits, g->N, p.ep_scale, p.ep_shift, (const float*)r, p.ep_relu, p.lane_partial, p.lane_out,
+                           p.lane_res);
       rc = (int)hipGetLastError();
     }
   }

@@ -765,7 +765,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                            long long total, int ksplits, int N,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           const ACT* __restrict__ res, int relu) {
+                                                           const ACT* __restrict__ res, int relu,
+                                                           long long lane_partial, long long lane_out, long long lane_res) {
+  // MC sample lanes: blockIdx.y = lane; byte strides between the lanes' partial sums / outputs / residuals
+  partial = (const float*)((const unsigned char*)partial + (long long)blockIdx.y * lane_partial);
+  out = (ACT*)((unsigned char*)out + (long long)blockIdx.y * lane_out);
+  if (res) res = (const ACT*)((const unsigned char*)res + (long long)blockIdx.y * lane_res);
   const long long stride = (long long)gridDim.x * blockDim.x * 4;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += stride) {
     const int nv = (int)((total - i) < 4 ? (total - i) : 4);
