@@ -162,7 +162,10 @@ def step_ubench():
           "Reading: A, the mix of contract_taps_kernel, sustains ~1.75 PFLOP/s (0.70 of the nominal bf16 peak) at 2.03 GHz — what the K loop\n"
           "could deliver if weight/patch DMA, real patch addressing and tile prologue/store side were free (the kernel: 0.85-1.05).  The\n"
           "512-register 1-wave/SIMD shapes with AGPR accumulators: 4x2 tiles 0.93x, 2x4 tiles 1.03x of A (a single wave per SIMD exposes\n"
-          "the mask VALU and LDS latency a second wave hides).  Masks cost 10 % (D vs A), half the fragment reads another 8 % (E vs D).",
+          "the mask VALU and LDS latency a second wave hides).  Masks cost 10 % (D vs A), half the fragment reads another 8 % (E vs D).\n"
+          "G/H/I add the kernel's DMA streams: weight tiles from L2 (8 KiB per block-stage) cost 4-5 %; streaming another 4 KiB per\n"
+          "block-stage from HBM (about twice the kernel's own activation traffic) costs 14 % and pulls the clock from 1.97 to 1.65 GHz:\n"
+          "at the package power limit HBM bytes are paid for in clock, whether or not their latency is hidden.",
           sh("tools/ubench/mfma_mix", timeout=600))
 
 
@@ -189,7 +192,7 @@ def step_power():
     import threading
     import time
     lib = variant("tune", "-DBTX_TUNING")
-    body = sh("rocm-smi --showmaxpower | grep -i max")
+    body = sh("rocm-smi --showmaxpower 2>/dev/null | grep -i 'max graphics'")
     for shp in SHAPES[:2]:
         for tag, env in (("contract_taps_kernel", {}), ("persistent (BTX_PERSIST=1)", {"BTX_PERSIST": "1"})):
             samples, done = [], []
@@ -219,8 +222,9 @@ def step_power():
                 body += "   (no busy samples)\n"
     write("r03_power_probe.txt", "BTX_LIB=build_variants/libbtx_tune.so BTX_NO_TALL=1 [BTX_PERSIST=1] python tools/gpu_diag.py timeone --throughput-plan\n"
           "--prec bf16 --bs 256 --iters 60000 --shape <s>, with `rocm-smi --showpower --showclocks` polled meanwhile (1 MI355X).\n"
-          "Reading: both kernels run within 4-13 % of the 1400 W package limit and below the 2.4 GHz peak clock; the persistent kernel\n"
-          "(higher matrix-pipe duty per cycle) is held at a lower clock.  tools/ubench/mfma_mix draws 1260-1340 W at 2.3-2.4 GHz.", body)
+          "Reading: both kernels run at 92-99 % of the 1400 W package limit with the clock throttled to 1.86-2.03 GHz (peak 2.4 GHz;\n"
+          "boxes of the pool differ by a few percent): the operating point is set by power, and a kernel that keeps the matrix pipe\n"
+          "busier per cycle (the persistent one) gets fewer cycles per second.  tools/ubench/mfma_mix draws 1260-1340 W at 2.3-2.4 GHz.", body)
 
 
 def step_install():

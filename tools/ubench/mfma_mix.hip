@@ -5,7 +5,9 @@
 //   B  4x2 tiles (256 accumulators in AGPRs), 4-wave blocks, 1 block per CU (1 wave per SIMD, 512 registers)
 //   C  2x4 tiles (256 accumulators in AGPRs), same occupancy                                   — halves the masks per MFMA
 //   D  A without the masks, E  A without masks and with half the fragment reads (upper bounds of what removing them buys)
-// deliver?  No global memory traffic in the loop: weights and activations stay in LDS.
+//   G  A + the kernel's weight-tile DMA (8 KiB per block-stage out of an L2-resident buffer, 4-slot LDS ring)
+//   H  G + 4 KiB per block-stage of activations streamed from a 1-GiB buffer (HBM),  I  B + the weight-tile DMA
+// deliver?  A-F: no global memory traffic in the loop (weights and activations stay in LDS).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip && tools/ubench/mfma_mix
 #include <hip/hip_runtime.h>
 #include <stdio.h>
