@@ -28,7 +28,9 @@
 #include "btx_mma.h"
 #include "btx_contract_taps.h"
 #include "btx_contract_taps2.h"
-#include "btx_contract_taps3.h"
+#if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
+#include "btx_contract_taps3.h"  // persistent form: measurement builds only
+#endif
 
 namespace btx {
 
@@ -380,6 +382,7 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
 #undef BTX_LAUNCH_T2
     return (int)hipGetLastError();
   }
+#if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
   if constexpr (PREC == 1) {
     if (p.pt_taps == 33 && p.pt_persist > 0) {  // persistent form (btx_contract_taps3.h): the grid is pt_persist workgroups
 #define BTX_LAUNCH_T3(KIND)                                                                                       \
@@ -398,6 +401,7 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
       return (int)hipGetLastError();
     }
   }
+#endif
   if (p.pt_taps == 33) {  // 3x3, 4-wave K-groups: the tap-unrolled kernel (btx_contract_taps.h)
 #define BTX_LAUNCH_TP(KIND, KG)                                                                                    \
   do {                                                                                                            \
