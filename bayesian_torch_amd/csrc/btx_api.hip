@@ -1139,11 +1139,10 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     // Persistent form of the tap-unrolled kernel (btx_contract_taps3.h): about two workgroups per CU, each walking one
     // tile position through the images of all lanes; the K loop runs across tile boundaries and the store side works
     // from the fragment registers.  bf16 in and out, 3x3, plain tiles, one K split, an even number of channel blocks,
-    // whole 64-channel n-tiles, 32-aligned s_out words, hashed signs.  MEASUREMENT ONLY (BTX_PERSIST=1 in tuning builds;
-    // the shipped library never takes it): bit-identical results, but hipcc cannot hold the Flipout K loop plus the
-    // cross-tile state in 256 VGPRs — one or two spill reloads per K-stage, each a vmcnt(0) that drains the DMA ring
-    // (profiles/r03_persistent_ab.txt: 359 vs 135 us on the 56x56 layer at batch 256).  The Reparameterization
-    // instantiation allocates cleanly (222 VGPRs, no scratch).
+    // whole 64-channel n-tiles, 32-aligned s_out words, hashed signs, no bias.  MEASUREMENT ONLY (BTX_PERSIST=1 in tuning
+    // builds; the shipped library does not even contain the kernel): bit-identical results, 241 VGPRs and no scratch, a
+    // 56x56 tile in 29k instead of 35k cycles — and the same launch time, because the chip, at its package power limit,
+    // answers the higher matrix-pipe duty with a lower clock (profiles/r03_persistent_ab.txt, r03_power_probe.txt).
     {
       const int bk = NG * 8;
       const int ncb = pl.Cg / bk;

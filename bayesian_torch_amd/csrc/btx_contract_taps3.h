@@ -6,9 +6,9 @@
 // K loop 24 k, store side 8 k cycles):
 //
 //   * a workgroup is persistent: the grid is about two workgroups per CU; a workgroup owns ONE (row tile, n-tile, group)
-//     position and walks it through a range of images (of all MC sample lanes).  Its next tile is therefore the same
-//     patch one image further on: every per-thread offset of the tile advances by one scalar, and nothing has to be
-//     decoded between tiles.  The K loop does not stop at a tile boundary: the last channel block of a tile fetches —
+//     position and walks it through image groups (of all MC sample lanes) drawn from the position's queue, one atomic
+//     per tile, a tile ahead.  Its next tile is therefore the same patch some images further on: every per-thread offset
+//     of the tile advances by one scalar, and nothing has to be decoded between tiles.  The K loop does not stop at a tile boundary: the last channel block of a tile fetches —
 //     stage by stage, with the static DMA schedule of any other block — the first patch, sign words and weight tiles of
 //     the NEXT tile.  No prologue after the first tile.
 //   * the store side needs no LDS (the rings hold the next tile's data by then): bias, Flipout combine, eval-BN affine in
@@ -19,8 +19,12 @@
 //
 // Eligibility (btx_api.hip): 3x3 stride 1, plain (whole-row) tiles whose image count divides the batch, bf16 activations
 // and output, one K split, an even number of channel blocks (a tile then always starts on patch slot 0), whole
-// 64-channel n-tiles with 32-aligned s_out words, generated noise.
-// Everything else runs contract_taps_kernel.
+// 64-channel n-tiles with 32-aligned s_out words, generated noise, no bias.
+// Compiled in measurement builds only (-DBTX_TUNING / -DBTX_PT_TRACE, BTX_PERSIST=1 selects it): it needs 29k instead of
+// 35k cycles per 56x56 tile and takes the same time per launch — the chip runs it at a lower clock (DESIGN.md section 5,
+// round 3; profiles/r03_persistent_ab.txt, r03_phase_timers_sustained.txt, r03_power_probe.txt).  What it took to make hipcc
+// allocate it (241 VGPRs, no scratch) is in the comments below: parameters through an address_space(4) kernarg pointer,
+// tile scalars pinned to SGPRs, ONE instantiation of the store side.
 #pragma once
 #include "btx_contract_taps.h"
 
