@@ -169,6 +169,26 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   };
   if (ncb > 0) issue_w(0u, (uint32_t)cb0, 0);
 
+  // ---- sign role: thread t owns the words of patch pixels t and t+256 (element offset of channel 0 of the group).  The
+  // same map — patch pixel -> input pixel, or "outside" — is what the patch loader below needs for ITS pixels: it is
+  // evaluated once per patch pixel here and handed over through LDS (the second sign slot, free until the first block's
+  // stage 0) instead of six more times per thread (6 x ~100 instructions in front of the last patch DMA of the prologue).
+  uint32_t sg_off[2];
+  bool sg_ok[2];
+  uint32_t* const pix_tab = (uint32_t*)(smem + PT_S_OFF + s_stage);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = tid + NT * j;
+    sg_ok[j] = q < p.pt_PP;
+    bool inside;
+    const uint32_t ipix = patch_src(sg_ok[j] ? q : 0, inside);
+    sg_off[j] = ipix * (uint32_t)p.C + (uint32_t)(group * p.Cg);  // outside pixels hold zeros: any word will do
+    if (q * 4 < s_stage) pix_tab[q] = (sg_ok[j] && inside) ? sg_off[j] : 0xffffffffu;
+    if (p.sign_in)  // explicit signs (parity mode) are read from memory: only pixels inside the input exist
+      sg_ok[j] = sg_ok[j] && inside;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
   // ---- patch loader: DMA instruction j of wave w moves patch pixels 16*(w + 4j) + (lane>>2), granule slot lane&3
   const int g_lane = (lane & 3) ^ ((lane >> 4) & 3);
   uint32_t pp_boff[MAXNI];
@@ -178,9 +198,8 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     const int q = 16 * (wave + NW * j) + (lane >> 2);
     uint32_t bo = DMA_OOB;
     if (j < p.pt_NI && q < p.pt_PP) {
-      bool ok;
-      const uint32_t ipix = patch_src(q, ok);
-      if (ok) bo = (ipix * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) * (uint32_t)ESZ;
+      const uint32_t e = pix_tab[q];
+      if (e != 0xffffffffu) bo = (e + (uint32_t)(G * g_lane)) * (uint32_t)ESZ;
     }
     pp_boff[j] = bo;
     if (j < p.pt_NI && 16 * (wave + NW * j) < p.pt_PP) {
@@ -210,19 +229,6 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   }
 
   BTX_TR_P(1);  // sign keys derived (sample word arrived)
-  // ---- sign role: thread t owns the words of patch pixels t and t+256 (element offset of channel 0 of the group)
-  uint32_t sg_off[2];
-  bool sg_ok[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = tid + NT * j;
-    sg_ok[j] = q < p.pt_PP;
-    bool inside;
-    const uint32_t ipix = patch_src(sg_ok[j] ? q : 0, inside);
-    sg_off[j] = ipix * (uint32_t)p.C + (uint32_t)(group * p.Cg);  // outside pixels hold zeros: any word will do
-    if (p.sign_in)  // explicit signs (parity mode) are read from memory: only pixels inside the input exist
-      sg_ok[j] = sg_ok[j] && inside;
-  }
   auto write_signs = [&](int slot, int cb) __attribute__((always_inline)) {
     if constexpr (KIND == 1) {
       unsigned char* ss = smem + PT_S_OFF + slot * s_stage;
