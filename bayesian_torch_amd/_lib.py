@@ -61,7 +61,7 @@ class KlItem(ctypes.Structure):
 
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss", "btx_kl_model_workspace_bytes",
            "btx_kl_gauss_model", "btx_kl_gauss_model_bwd", "btx_contract_wgrad",
-           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_fwd_lanes", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign",
+           "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_fwd_lanes", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign", "btx_rho_grad",
            "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
 
 
@@ -113,6 +113,8 @@ def lib():
     L.btx_out_shape.argtypes = [ctypes.POINTER(Geom), u32] + [ctypes.POINTER(ctypes.c_int32)] * 3
     L.btx_fill_eps.restype = i32
     L.btx_fill_eps.argtypes = [vp, sz, ctypes.POINTER(Rng), u32, vp]
+    L.btx_rho_grad.restype = i32
+    L.btx_rho_grad.argtypes = [vp, vp, vp, sz, ctypes.POINTER(Rng), u32, vp]
     L.btx_fill_sign.restype = i32
     L.btx_fill_sign.argtypes = [vp, sz, ctypes.POINTER(Rng), u32, vp]
     L.btx_mc_packed_floats.restype = sz

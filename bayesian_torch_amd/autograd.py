@@ -89,10 +89,14 @@ class ContractFn(torch.autograd.Function):
             stem_wgrad = plan is not None and not op.transposed
             need_signs = flip and ((padded and (ctx.needs_input_grad[2] or not stem_wgrad)) or
                                    (op.transposed and rho_b is not None))  # transposed layers: db_delta by torch
-            nz = layer.materialize_noise(s, tuple(x.shape), tuple(dy.shape), x.dtype, signs=need_signs)
-            eps = nz["eps_w"]
-            dsig = torch.sigmoid(rho.detach())
             w_shape = tuple(rho.shape)
+            fused_w = False  # dmu / drho formed by btx_rho_grad on the kernel's own buffers (plain layouts)
+            # the noise TENSORS (eps, signs) are only materialised where something still needs them: the data gradient (it
+            # contracts with the transposed / flipped sigma*eps), padded / transposed layouts, bias gradients
+            plain_w = not op.transposed and not padded
+            need_nz = (ctx.needs_input_grad[2] or not plain_w or need_signs or
+                       (rho_b is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6])))
+            nz = layer.materialize_noise(s, tuple(x.shape), tuple(dy.shape), x.dtype, signs=need_signs) if need_nz else {}
             dx = dmu = drho = dmu_b = drho_b = None
             kind = _lib.KIND_FLIPOUT if flip else _lib.KIND_REPARAM
             want_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
@@ -104,6 +108,20 @@ class ContractFn(torch.autograd.Function):
                     # 49 taps x 3 channels of a 64-wide tile; the forward's hashed signs instead of sign tensors)
                     dW, dWd, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
                                                     bias=want_b, rowfuse=plan)
+                elif not op.transposed and not padded:
+                    # plain layouts: the kernel's GEMM-major buffers ARE the gradients (strided logical views, as the
+                    # parameters themselves are stored), and drho = dW_delta * eps * sigmoid(rho) is one launch with eps
+                    # regenerated in the kernel (btx_rho_grad) instead of fill_eps + unpack + sigmoid + two products
+                    dWf, dWdf, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
+                                                      bias=want_b, raw=True)
+                    if want_w:
+                        rho_f = BF.gemm_major_view(rho, op).reshape(-1)
+                        src = dWdf if flip else dWf
+                        drho_f = BF.rho_grad_hip(src, rho_f, _rng.seed(), s, layer._btx_layer_id, _lib.STREAM_EPS_W,
+                                                 out=src if flip else None)
+                        dmu = BF.gemm_major_logical_view(dWf, w_shape, op)
+                        drho = BF.gemm_major_logical_view(drho_f, w_shape, op)
+                    fused_w = True
                 elif not op.transposed:
                     dW, dWd, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
                                                     signs=signs, bias=want_b)
@@ -121,9 +139,9 @@ class ContractFn(torch.autograd.Function):
                         red = tuple(i for i in range(dy.dim()) if i != 1)
                         db = dy.float().sum(red)
                         dbd = (dy.float() * nz["sign_out"].reshape(dy.shape).float()).sum(red) if flip else None
-                if want_w:
+                if want_w and not fused_w:
                     dmu = dW
-                    drho = (dWd if flip else dW) * eps * dsig
+                    drho = (dWd if flip else dW) * nz["eps_w"] * torch.sigmoid(rho.detach())
                 if want_b:
                     dmu_b = db
                     drho_b = (dbd if flip else db) * nz["eps_b"] * torch.sigmoid(rho_b.detach())

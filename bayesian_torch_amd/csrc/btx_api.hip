@@ -173,6 +173,22 @@ __global__ __launch_bounds__(256) void fill_eps_kernel(float* __restrict__ out, 
   }
 }
 
+// drho = dw * eps * sigmoid(rho): the elementwise follow-up of the weight gradient, eps regenerated (never materialised)
+__global__ __launch_bounds__(256) void rho_grad_kernel(const float* __restrict__ dw, const float* __restrict__ rho,
+                                                       float* __restrict__ drho, size_t n, uint32_t k0, uint32_t k1,
+                                                       uint32_t sample, uint32_t layer, uint32_t stream) {
+  const size_t nblk = (n + 3) >> 2;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nblk; b += (size_t)gridDim.x * 256) {
+    float z[4];
+    btx_normal4((uint32_t)b, sample, layer, stream, k0, k1, z);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t i = (b << 2) + e;
+      if (i < n) drho[i] = dw[i] * z[e] * (1.0f / (1.0f + expf(-rho[i])));
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_sign_kernel(int8_t* __restrict__ out, size_t n, uint32_t ka, uint32_t kb) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const uint32_t w = btx_sign_word((uint32_t)(i >> 5), ka, kb);
@@ -1282,6 +1298,18 @@ int btx_fill_eps(float* out, size_t n, const BtxRng* rng, uint32_t rng_stream, v
   size_t blocks = ((n + 3) / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(fill_eps_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, n,
+                     (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx, rng->layer_id, rng_stream);
+  return (int)hipGetLastError();
+}
+
+int btx_rho_grad(const float* dw, const float* rho, float* drho, size_t n, const BtxRng* rng, uint32_t rng_stream,
+                 void* stream) {
+  if (!dw || !rho || !drho || !rng) return BTX_E_NULL;
+  if (n == 0) return 0;
+  if (n > 0xfffffffcULL) return BTX_E_UNSUPPORTED;  // BTX-RNG v1 block index is 32 bits
+  size_t blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rho_grad_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dw, rho, drho, n,
                      (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx, rng->layer_id, rng_stream);
   return (int)hipGetLastError();
 }

@@ -412,7 +412,7 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
 
 
 def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, swap=False, bias=False, rowfuse=None,
-              _flags=0):
+              _flags=0, raw=False):
     """btx_contract_wgrad: (dW_mu, dW_delta | None, db_mu | None, db_delta | None) in the layer's LOGICAL weight layout
     (f32).  `op` is a plain (non-transposed) contraction; `signs` = (sign_in, sign_out) logical +/-1 tensors for layers
     whose forward ran on padded layouts, else the forward's hashed signs are regenerated.  `rowfuse` = the layer's
@@ -467,6 +467,8 @@ def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, 
     _lib.check(L.btx_contract_wgrad(kind, ctypes.byref(g), xp.data_ptr(), dyp.data_ptr(), dwm.data_ptr(), ptr(dwd), ptr(dbm),
                                     ptr(dbd), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None, act,
                                     (_lib.FLAG_SWAP_SIGNS if swap else 0) | _flags, torch.cuda.current_stream(dev).cuda_stream))
+    if raw:  # the flat GEMM-major buffers as the kernel wrote them (autograd: strided logical views, no unpack copies)
+        return dwm, dwd, dbm, dbd
     un = lambda t: unpack_gemm_major(t, w_shape, op) if t is not None else None  # noqa: E731
     return un(dwm), un(dwd), dbm, dbd
 
@@ -615,6 +617,18 @@ def fill_eps_hip(n, device, seed, sample_idx, layer_id, rng_stream):
     r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
     _lib.check(L.btx_fill_eps(out.data_ptr(), out.numel(), ctypes.byref(r), rng_stream,
                               torch.cuda.current_stream(out.device).cuda_stream))
+    return out
+
+
+def rho_grad_hip(dw_flat, rho_flat, seed, sample_idx, layer_id, rng_stream, out=None):
+    """btx_rho_grad: drho = dw * eps * sigmoid(rho) over flat f32 tensors in the same (GEMM-major) element order, eps
+    regenerated inside the kernel.  `out` may be dw_flat itself."""
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty_like(dw_flat)
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    _lib.check(L.btx_rho_grad(dw_flat.data_ptr(), rho_flat.data_ptr(), out.data_ptr(), dw_flat.numel(), ctypes.byref(r),
+                              rng_stream, torch.cuda.current_stream(dw_flat.device).cuda_stream))
     return out
 
 

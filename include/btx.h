@@ -283,6 +283,14 @@ size_t btx_sampled_w_bytes_lanes(const BtxGeom* g, int kind, int prec, int lanes
 int btx_sample_weights_lanes(const BtxSampleItem* items_host, int n_items, const BtxRng* rng /* layer_id unused */,
                              int prec, void* stream, int lanes, uint32_t sflags);
 
+/* Training, the step behind btx_contract_wgrad: drho[i] = dw[i] * eps(i) * sigmoid(rho[i]) over the n elements of a weight
+ * tensor in the order of mu_w (what autograd derives for `sigma = log1p(exp(rho)); delta = sigma * eps` of
+ * conv_flipout.py:372-375 / conv_variational.py:358-366 / linear_flipout.py:150-153).  dw = dw_delta of a Flipout layer,
+ * dw_mu of a Reparameterization layer (dmu is dw_mu itself).  eps is regenerated from rng (stream BTX_STREAM_EPS_W, or
+ * _EPS_B for the bias vectors): the values btx_fill_eps would write, never materialised.  drho may alias dw. */
+int btx_rho_grad(const float* dw, const float* rho, float* drho, size_t n, const BtxRng* rng, uint32_t rng_stream,
+                 void* stream);
+
 /* §8(f): the data format in front of the path.  Small-C stems (BTX_FLAG_ROWFUSE) take channels-last [NB][Hp][Wp][cp]
  * activations with the conv padding materialised and the channels zero-padded to cp (4 or 8), in the MFMA dtype.
  * btx_rowfuse_pack writes that tensor in ONE pass from the caller's logical [N,C,H,W] activations of any layout:

@@ -278,3 +278,21 @@ def test_unbatched_inputs_on_the_padded_layouts():
             a = layer._forward_hip(x, sample_idx=5)
             b = layer._forward_hip(x.unsqueeze(0), sample_idx=5)
         assert a.dim() == 3 and torch.equal(a, b[0])
+
+
+def test_rho_grad_kernel_matches_the_elementwise_formula():
+    """btx_rho_grad: drho = dw * eps * sigmoid(rho) with eps regenerated in the kernel == the same product formed from
+    btx_fill_eps values by torch (in place and out of place, a length that is not a multiple of 4)"""
+    from bayesian_torch_amd import functional as BF, _lib
+    dev = _dev()
+    torch.manual_seed(0)
+    n = 4099
+    dw = torch.randn(n, device=dev)
+    rho = torch.randn(n, device=dev) * 3
+    eps = BF.fill_eps_hip(n, dev, 1234, 7, 5, _lib.STREAM_EPS_W)
+    want = dw * eps * torch.sigmoid(rho)
+    got = BF.rho_grad_hip(dw, rho, 1234, 7, 5, _lib.STREAM_EPS_W)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+    inplace = dw.clone()
+    BF.rho_grad_hip(inplace, rho, 1234, 7, 5, _lib.STREAM_EPS_W, out=inplace)
+    assert torch.equal(inplace, got)
