@@ -1082,6 +1082,8 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   p.M = pl.M; p.K = pl.K;
   p.mtiles = pl.mtiles; p.ntiles = pl.ntiles; p.groups = g->groups; p.ksplits = pl.ksplits; p.kper = pl.kper;
   p.transposed = (flags & BTX_FLAG_TRANSPOSED) ? 1 : 0;
+  p.pointwise = (!p.transposed && g->KD == 1 && g->KH == 1 && g->KW == 1 && g->sd == 1 && g->sh == 1 && g->sw == 1 &&
+                 g->pd == 0 && g->ph == 0 && g->pw == 0) ? 1 : 0;
   p.out_bf16 = out_bf16;
   if (ep) { p.ep_scale = ep->scale; p.ep_shift = ep->shift; p.ep_res = ep->residual; p.ep_relu = ep->relu; }
   if (rowfuse) {  // K = KH*(KW*C) unchanged; the pixel stride p.C stays C

@@ -105,6 +105,7 @@ struct ContractParams {
   int M, K;
   int mtiles, ntiles, groups, ksplits, kper;
   int transposed;
+  int pointwise;   // 1x1x1 filter, stride 1, no padding, not transposed: output pixel m reads input pixel m (a plain GEMM)
   uint32_t seed_lo, seed_hi, sample, layer;
   const uint32_t* sample_ptr;  // non-NULL: the MC sample index is read from device memory when the kernel runs
   uint32_t kin_a, kin_b, kout_a, kout_b;
