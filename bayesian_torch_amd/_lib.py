@@ -8,11 +8,12 @@ _LIB = None
 
 KIND_REPARAM, KIND_FLIPOUT = 0, 1
 ACT_F32, ACT_BF16 = 0, 1
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_CODE = {"f32": 0, "bf16": 1, "bf16x3": 2}
 FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER, FLAG_SWAP_SIGNS, FLAG_CONCURRENT = 1, 2, 4, 8, 16, 32, 64, 128
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_LANES_SHIFT = 16
 SAMPLE_SKIP_MU = 1
 
@@ -62,7 +63,7 @@ class KlItem(ctypes.Structure):
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss", "btx_kl_model_workspace_bytes",
            "btx_kl_gauss_model", "btx_kl_gauss_model_bwd", "btx_contract_wgrad",
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_fwd_lanes", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign", "btx_rho_grad",
-           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
+           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_mc_accumulate_lanes", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
 
 
 def lib_path():
@@ -136,6 +137,8 @@ def lib():
     L.btx_avgpool_global_cl.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.btx_mc_accumulate.restype = i32
     L.btx_mc_accumulate.argtypes = [vp, i32, i32, i32, f32, vp, vp]
+    L.btx_mc_accumulate_lanes.restype = i32
+    L.btx_mc_accumulate_lanes.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     if L.btx_abi_version() != ABI_VERSION:
         raise BtxError("libbtx.so ABI %d != expected %d" % (L.btx_abi_version(), ABI_VERSION))
     _LIB = L

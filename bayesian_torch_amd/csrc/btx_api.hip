@@ -201,51 +201,56 @@ __global__ __launch_bounds__(256) void fill_sign_kernel(int8_t* __restrict__ out
 // -> mean(dim=0)  examples/main_bayesian_imagenet_dnn2bnn.py:483-499 ; predictive_entropy / mutual_information
 // utils/util.py:41-60.  One workgroup per batch row; the row is owned by that workgroup so no atomics.
 // ========================================================================================================
+// lanes > 1 (btx_mc_accumulate_lanes): the logits of `lanes` MC samples back to back ([lanes][bs][C]); the workgroup that
+// owns a batch row folds its lanes in order — the same additions, in the same order, as `lanes` single-sample launches
 template <typename ACT>
 __global__ __launch_bounds__(256) void mc_accumulate_kernel(const ACT* __restrict__ logits, int bs, int C, float kl,
-                                                            float* __restrict__ packed) {
+                                                            float* __restrict__ packed, int lanes) {
   const int row = blockIdx.x;
-  const ACT* lr = logits + (size_t)row * C;
   __shared__ float red[4];
   __shared__ float bc;
-  float mx = -INFINITY;
-  for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, (float)lr[c]);
+  for (int ln = 0; ln < lanes; ++ln) {
+    const ACT* lr = logits + ((size_t)ln * bs + row) * C;
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, (float)lr[c]);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  mx = bc;
-  float se = 0.f;
-  for (int c = threadIdx.x; c < C; c += 256) se += expf((float)lr[c] - mx);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    mx = bc;
+    float se = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) se += expf((float)lr[c] - mx);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) se += __shfl_down(se, off, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
-  __syncthreads();
-  if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
-  __syncthreads();
-  const float inv = 1.0f / bc;
-  float ent = 0.f;
-  float* sp = packed + (size_t)row * C;
-  float* sp2 = packed + (size_t)bs * C + (size_t)row * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float pr = expf((float)lr[c] - mx) * inv;
-    sp[c] += pr;
-    sp2[c] += pr * pr;
-    ent -= pr * logf(pr + 1e-15f);  // utils/util.py:44 epsilon
-  }
+    for (int off = 32; off > 0; off >>= 1) se += __shfl_down(se, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const float inv = 1.0f / bc;
+    float ent = 0.f;
+    float* sp = packed + (size_t)row * C;
+    float* sp2 = packed + (size_t)bs * C + (size_t)row * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float pr = expf((float)lr[c] - mx) * inv;
+      sp[c] += pr;
+      sp2[c] += pr * pr;
+      ent -= pr * logf(pr + 1e-15f);  // utils/util.py:44 epsilon
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) ent += __shfl_down(ent, off, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ent;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    packed[(size_t)2 * bs * C + row] += red[0] + red[1] + red[2] + red[3];
-    if (row == 0) {
-      packed[(size_t)2 * bs * C + bs] += kl;
-      packed[(size_t)2 * bs * C + bs + 1] += 1.0f;
+    for (int off = 32; off > 0; off >>= 1) ent += __shfl_down(ent, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ent;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      packed[(size_t)2 * bs * C + row] += red[0] + red[1] + red[2] + red[3];
+      if (row == 0) {
+        packed[(size_t)2 * bs * C + bs] += kl;
+        packed[(size_t)2 * bs * C + bs + 1] += 1.0f;
+      }
     }
   }
 }
@@ -541,7 +546,7 @@ static inline bool throughput_plan(uint32_t flags) { return (flags & BTX_FLAG_CO
 static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* pl) {
   int rc = btx_out_shape(g, flags, &pl->Do, &pl->Ho, &pl->Wo);
   if (rc) return rc;
-  if (prec != BTX_PREC_F32 && prec != BTX_PREC_BF16) return BTX_E_DTYPE;
+  if (prec != BTX_PREC_F32 && prec != BTX_PREC_BF16 && prec != BTX_PREC_BF16X3) return BTX_E_DTYPE;
   pl->Cg = g->C / g->groups;
   pl->Ng = g->N / g->groups;
   const long long M = (long long)g->NB * pl->Do * pl->Ho * pl->Wo;
@@ -1144,7 +1149,8 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     p.st_sbytes = stp.sbytes; p.pt_lds = stp.lds; p.pt_PP = stp.patch_bytes;
     p.fd_rtiles = make_fastdiv((uint32_t)stp.rtiles);
     rc = (prec == BTX_PREC_BF16) ? launch_contract_stem_bf16(kind, p, pl.nwg * lanes, st)
-                                 : launch_contract_stem_f32(kind, p, pl.nwg * lanes, st);
+         : (prec == BTX_PREC_BF16X3) ? launch_contract_stem_x3(kind, p, pl.nwg * lanes, st)
+                                     : launch_contract_stem_f32(kind, p, pl.nwg * lanes, st);
   } else if (patch) {
     p.pt_G = pt.G; p.pt_R = pt.R; p.pt_Rp = pt.Rp; p.pt_Wp = pt.Wp; p.pt_PP = pt.PP; p.pt_NI = pt.NI;
     p.fd_ptWp = make_fastdiv((uint32_t)pt.Wp); p.fd_ptRp = make_fastdiv((uint32_t)pt.Rp); p.fd_ptR = make_fastdiv((uint32_t)pt.R);
@@ -1192,13 +1198,16 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
       }
     }
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg * lanes, st)
-                                 : launch_contract_patch_f32(kind, p, pl.nwg * lanes, st);
+         : (prec == BTX_PREC_BF16X3) ? launch_contract_patch_x3(kind, p, pl.nwg * lanes, st)
+                                     : launch_contract_patch_f32(kind, p, pl.nwg * lanes, st);
   } else if (dma)
     rc = (prec == BTX_PREC_BF16) ? launch_contract_dma_bf16(kind, p, pl.nwg * lanes, st)
-                                 : launch_contract_dma_f32(kind, p, pl.nwg * lanes, st);
+         : (prec == BTX_PREC_BF16X3) ? launch_contract_dma_x3(kind, p, pl.nwg * lanes, st)
+                                     : launch_contract_dma_f32(kind, p, pl.nwg * lanes, st);
   else {
     // the register-staged fast kernel samples in registers and hashes its own s_in: explicit eps_w / sign_in need either
     // the LDS-DMA family above (pre-pass sampling, packed sign words) or the gather kernel
+    // (BTX_PREC_BF16X3 has no register-staged form: such shapes run on the exact-f32 kernel, which is at least as accurate)
     const bool gen2 = gen || (noise && (noise->eps_w || noise->sign_in));
     rc = (prec == BTX_PREC_BF16) ? launch_contract_bf16(kind, act_dtype == BTX_ACT_BF16, gen2, p, pl.nwg * lanes, st)
                                  : launch_contract_f32(kind, act_dtype == BTX_ACT_BF16, gen2, p, pl.nwg * lanes, st);
@@ -1248,7 +1257,7 @@ int btx_sample_weights_lanes(const BtxSampleItem* items, int n_items, const BtxR
   const uint64_t seed = rng->seed;
   const uint32_t sample_idx = rng->sample_idx;
   if (n_items <= 0) return n_items == 0 ? 0 : BTX_E_SHAPE;
-  if (prec != BTX_PREC_F32 && prec != BTX_PREC_BF16) return BTX_E_DTYPE;
+  if (prec != BTX_PREC_F32 && prec != BTX_PREC_BF16 && prec != BTX_PREC_BF16X3) return BTX_E_DTYPE;
   for (int base = 0; base < n_items; base += PRESAMPLE_MAX_ITEMS) {
     PresampleBatch b;
     memset(&b, 0, sizeof(b));
@@ -1288,7 +1297,8 @@ int btx_sample_weights_lanes(const BtxSampleItem* items, int n_items, const BtxR
     }
     b.total_blocks = blocks;
     int rc = (prec == BTX_PREC_BF16) ? launch_presample_batch_bf16(b, (hipStream_t)stream)
-                                     : launch_presample_batch_f32(b, (hipStream_t)stream);
+             : (prec == BTX_PREC_BF16X3) ? launch_presample_batch_x3(b, (hipStream_t)stream)
+                                         : launch_presample_batch_f32(b, (hipStream_t)stream);
     if (rc) return rc;
   }
   return 0;
@@ -1388,14 +1398,20 @@ int btx_avgpool_global_cl(const void* x, void* out, int dtype, int NB, int HW, i
 }
 
 int btx_mc_accumulate(const void* logits, int bs, int C, int act_dtype, float kl, float* packed, void* stream) {
+  return btx_mc_accumulate_lanes(logits, 1, bs, C, act_dtype, kl, packed, stream);
+}
+
+int btx_mc_accumulate_lanes(const void* logits, int lanes, int bs, int C, int act_dtype, float kl, float* packed,
+                            void* stream) {
   if (!logits || !packed) return BTX_E_NULL;
-  if (bs <= 0 || C <= 0) return BTX_E_SHAPE;
+  if (bs <= 0 || C <= 0 || lanes <= 0) return BTX_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (act_dtype == BTX_ACT_F32)
-    hipLaunchKernelGGL(mc_accumulate_kernel<float>, dim3(bs), dim3(256), 0, st, (const float*)logits, bs, C, kl, packed);
+    hipLaunchKernelGGL(mc_accumulate_kernel<float>, dim3(bs), dim3(256), 0, st, (const float*)logits, bs, C, kl, packed,
+                       lanes);
   else if (act_dtype == BTX_ACT_BF16)
     hipLaunchKernelGGL(mc_accumulate_kernel<__bf16>, dim3(bs), dim3(256), 0, st, (const __bf16*)logits, bs, C, kl,
-                       packed);
+                       packed, lanes);
   else
     return BTX_E_DTYPE;
   return (int)hipGetLastError();

@@ -815,6 +815,11 @@ struct PresampleBatch;
 int launch_presample_batch_f32(const PresampleBatch& b, hipStream_t st);
 int launch_presample_batch_bf16(const PresampleBatch& b, hipStream_t st);
 int launch_contract_patch_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
+// split-bf16 (BTX_PREC_BF16X3, btx_x3.hip)
+int launch_contract_patch_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_stem_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_dma_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_presample_batch_x3(const PresampleBatch& b, hipStream_t st);
 
 template <int PREC>
 static int launch_contract_impl(int kind, int act_bf16, bool gen, const ContractParams& p, int nwg, hipStream_t st) {

@@ -19,6 +19,16 @@ namespace btx {
 // samples for index sample + l (sample_ptr[l]) into its own tiles `lane_stride` bytes behind the previous lane's (Flipout:
 // the delta tiles, the mean tiles exist once; Reparameterization: the W tiles).  Values per lane are those of a one-lane
 // call with that index.
+// split-bf16 tiles (PREC == 2, btx_mma.h): the quad's granule holds [4 bf16 hi | 4 bf16 lo], hi = rn(w), lo = rn(w - hi)
+__device__ __forceinline__ u32x4 pack_quad_split(const float* w) {
+  const f32x4 v = {w[0], w[1], w[2], w[3]};
+  const u32x2 hb = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+  const f32x4 r = {w[0] - u2f(hb[0] << 16), w[1] - u2f(hb[0] & 0xffff0000u), w[2] - u2f(hb[1] << 16),
+                   w[3] - u2f(hb[1] & 0xffff0000u)};
+  const u32x2 lb = __builtin_bit_cast(u32x2, __builtin_convertvector(r, bf16x4));
+  return (u32x4){hb[0], hb[1], lb[0], lb[1]};
+}
+
 template <int PREC>
 __device__ __forceinline__ void presample_quad(int kind, const float* __restrict__ mu, const float* __restrict__ rho,
                                                unsigned char* __restrict__ wt, uint32_t delta_off, int Ng, int K,
@@ -76,6 +86,7 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
   const uint32_t oo = (PREC == 1) ? o + (quad & 1u) * 8u : o;
   if (kind == 1 && write_mu) {
     if constexpr (PREC == 1) *(u32x2*)(wt + oo) = pack_quad_bf16(mu4);
+    else if constexpr (PREC == 2) *(u32x4*)(wt + oo) = pack_quad_split(mu4);
     else *(u32x4*)(wt + oo) = (u32x4){f2u(mu4[0]), f2u(mu4[1]), f2u(mu4[2]), f2u(mu4[3])};
   }
   for (int l = 0; l < lanes; ++l) {
@@ -94,6 +105,7 @@ __device__ __forceinline__ void presample_quad(int kind, const float* __restrict
     for (int e = 0; e < 4; ++e) w[e] = (kind == 0) ? __builtin_fmaf(sg4[e], eps[e], mu4[e]) : sg4[e] * eps[e];
     unsigned char* dst = wt + (kind == 1 ? delta_off : 0u) + (uint32_t)l * lane_stride + oo;
     if constexpr (PREC == 1) *(u32x2*)dst = pack_quad_bf16(w);
+    else if constexpr (PREC == 2) *(u32x4*)dst = pack_quad_split(w);
     else *(u32x4*)dst = (u32x4){f2u(w[0]), f2u(w[1]), f2u(w[2]), f2u(w[3])};
   }
 }

@@ -14,15 +14,18 @@ import torch.nn.functional as F
 from . import _lib
 from . import rng as _rng
 
-_PRECISION = os.environ.get("BTX_PRECISION", "f32")  # "f32" (parity mode) | "bf16" (throughput mode)
+_PRECISION = os.environ.get("BTX_PRECISION", "f32")  # "f32" (parity mode) | "bf16x3" | "bf16" (throughput mode)
+PRECISIONS = ("f32", "bf16", "bf16x3")
 
 
 def set_precision(prec):
     """Contraction precision of the HIP path: "f32" = v_mfma_f32_32x32x2_f32 (exact f32 fma chain, parity to
-    ~1e-6 rel), "bf16" = v_mfma_f32_32x32x16_bf16 with f32 accumulation (rel-L2 ~3e-3, stated in DESIGN.md)."""
+    ~1e-6 rel), "bf16" = v_mfma_f32_32x32x16_bf16 with f32 accumulation (rel-L2 ~3e-3, stated in DESIGN.md),
+    "bf16x3" = split-bf16: f32 activations, operands as hi + lo bf16, three bf16 MFMAs per product (rel-L2 ~1e-6 per
+    layer: inside north_star's 1e-4 at a third of the bf16 matrix rate)."""
     global _PRECISION
-    if prec not in ("f32", "bf16"):
-        raise ValueError("precision must be 'f32' or 'bf16'")
+    if prec not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % (PRECISIONS,))
     _PRECISION = prec
 
 
@@ -242,7 +245,7 @@ def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None, lanes
     L = _lib.lib()
     if not items:
         return []
-    prec_c = _lib.PREC_BF16 if prec == "bf16" else _lib.PREC_F32
+    prec_c = _lib.PREC_CODE[prec]
     arr = (_lib.SampleItem * len(items))()
     geoms, outs = [], []
     for i, (kind, op, mu_p, rho_p, layer_id, *src) in enumerate(items):
@@ -285,7 +288,7 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     else:
         raise _lib.BtxError("activations must be float32 or bfloat16, got %s" % x.dtype)
     prec = prec or _PRECISION
-    prec_c = _lib.PREC_BF16 if prec == "bf16" else _lib.PREC_F32
+    prec_c = _lib.PREC_CODE[prec]
     xp, nb, spatial, restore = _to_channels_last(x, op)
     out_sp = op.out_spatial(spatial)
     if min(out_sp) <= 0:
@@ -303,6 +306,27 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
         elif nb != rows * lanes:
             raise _lib.BtxError("lanes=%d x lane_batch=%d does not match the input batch %d" % (lanes, lane_batch, x.shape[0]))
         nb = rows  # the geometry of ONE lane
+        # btx_contract_fwd_lanes wants 16-byte lane strides.  A layer whose per-lane tensors are not (a 10-class head at an
+        # odd batch: 10 * bs * 4 bytes) runs its lanes as single-sample launches planned like lanes (BTX_FLAG_CONCURRENT):
+        # the same values, one launch per lane instead of one
+        esz_o = (out_dtype or x.dtype).itemsize
+        out_lane = nb * out_sp[0] * out_sp[1] * out_sp[2] * op.out_channels * esz_o
+        x_lane = 0 if x_shared else (xp.numel() // lanes) * xp.element_size()
+        pooled = epilogue is not None and epilogue.get("pool")
+        if ((x_lane | out_lane) & 15) and not pooled:
+            outs = []
+            xl = x.reshape((lanes, -1) + tuple(x.shape[1:])) if not x_shared else None
+            res = epilogue.get("residual") if epilogue is not None else None
+            for l in range(lanes):
+                ep_l = epilogue
+                if res is not None:
+                    ep_l = dict(epilogue, residual=res.reshape((lanes, -1) + tuple(res.shape[1:]))[l])
+                with concurrent_plan():
+                    outs.append(contract_hip(kind, x if x_shared else xl[l], mu_p, rho_p, mu_b, rho_b, op, seed,
+                                             int(sample_idx) + l, layer_id, prec=prec, extra_flags=extra_flags,
+                                             out_dtype=out_dtype, epilogue=ep_l,
+                                             sample_dev=sample_dev[l:l + 1] if sample_dev is not None else None))
+            return torch.cat(outs, 0)
     flags = (_lib.FLAG_TRANSPOSED if op.transposed else 0) | extra_flags | (_lib.FLAG_CONCURRENT if _CONCURRENT else 0)
     if lanes > 1:
         flags |= lanes << _lib.FLAG_LANES_SHIFT
@@ -566,7 +590,7 @@ def contract_pool_ok(op, nb, spatial, act_dtype, prec, extra_flags=0):
     g.od, g.oh, g.ow = op.output_padding
     g.groups = op.groups
     act = _lib.ACT_BF16 if act_dtype == torch.bfloat16 else _lib.ACT_F32
-    prec_c = _lib.PREC_BF16 if prec == "bf16" else _lib.PREC_F32
+    prec_c = _lib.PREC_CODE[prec]
     return bool(L.btx_contract_pool_shape(ctypes.byref(g), act, prec_c, extra_flags, None, None))
 
 

@@ -314,7 +314,7 @@ class _VariationalNd(BaseVariationalLayer_):
             mu_f, rho_f = BF.rowfuse_weights(mu_p, rho_p, plan) if pre is None else (mu_p, rho_p)
             # the padded copy is made in the MFMA dtype (the rounding a staging kernel would apply anyway); the
             # output keeps the caller's activation dtype
-            xin = BF.rowfuse_input(x, plan, torch.bfloat16 if prec == "bf16" else torch.float32)
+            xin = self._rowfuse_packed(x, plan, torch.bfloat16 if prec == "bf16" else torch.float32)
             fo = plan["op"].out_spatial((1, plan["Hp"], plan["Wp"]))
             if epilogue is not None and epilogue.get("residual") is not None and fo[2] != plan["Wo"]:
                 raise _lib.BtxError("residual epilogue is not available for this row-fused stem geometry")
@@ -341,6 +341,29 @@ class _VariationalNd(BaseVariationalLayer_):
                                self._btx_layer_id, prec=self.precision, noise=noise, epilogue=epilogue, sampled_w=pre,
                                sample_dev=getattr(self, "_btx_sample_dev", None),
                                extra_flags=_lib.FLAG_GATHER if gather else 0, lanes=lanes, lane_batch=lane_batch)
+
+    def _rowfuse_packed(self, x, plan, dtype):
+        """the row-fused stem's input in its kernel layout (btx_rowfuse_pack).  mc.GraphedMC(static_input=True) vouches
+        that the batch does not change between the MC samples it replays: the pack then happens once, at capture time,
+        instead of once per replay (GraphedMC.set_input() re-packs)."""
+        if not self.__dict__.get("_btx_static_x"):
+            return BF.rowfuse_input(x, plan, dtype)
+        key = (x.data_ptr(), tuple(x.shape), x.dtype, dtype)
+        st = self.__dict__.get("_btx_static_pack")
+        if st is None or st[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.BtxError("static_input: the stem input must be packed before the capture starts")
+            st = (key, BF.rowfuse_input(x, plan, dtype))
+            self.__dict__["_btx_static_pack"] = st
+        return st[1]
+
+    def _static_repack(self, x):
+        """mc.GraphedMC.set_input(): refill the packed copy the captured launches read (same buffer, new contents)"""
+        st = self.__dict__.get("_btx_static_pack")
+        if st is None or st[0][0] != x.data_ptr():
+            return
+        plan = self._rowfuse_plan(x)
+        st[1].copy_(BF.rowfuse_input(x, plan, st[1].dtype))
 
     def pool_fusable(self, x):
         """True when forward_fused(..., pool=True) can fold nn.MaxPool2d(3, 2, 1) into this layer's launch: a row-fused
@@ -540,6 +563,13 @@ class _VariationalLSTM(BaseVariationalLayer_):
             return_kl = False
         nb, steps, _ = X.size()
         hs = self.out_features
+        for lin in (self.ih, self.hh):
+            # every time step must draw fresh noise: eager forwards get it from the layers' advancing sample counter; a
+            # device-resident sample index (mc.GraphedMC) or MC sample lanes pin one index for the whole forward, which
+            # would reuse one (seed, sample, layer) draw for every step
+            if X.is_cuda and steps > 1 and (lin.__dict__.get("_btx_lanes", 1) > 1 or getattr(lin, "_btx_sample_dev", None) is not None):
+                raise _lib.BtxError("LSTM layers need a fresh MC sample index per time step: run them with eager forwards "
+                                    "(mc.mc_forward(lanes=1)), not under mc.GraphedMC / MC sample lanes")
         if hidden_states is None:
             h_t = torch.zeros(nb, hs, device=X.device, dtype=X.dtype)
             c_t = torch.zeros(nb, hs, device=X.device, dtype=X.dtype)

@@ -49,6 +49,23 @@ def accumulate(packed, logits, kl=0.0):
     return packed
 
 
+def accumulate_lanes(packed, logits, lanes, kl=0.0):
+    """packed += statistics of `lanes` MC samples whose logits sit back to back along the batch axis ([lanes*bs, C]) —
+    on the GPU one launch (btx_mc_accumulate_lanes: a workgroup owns a batch row and folds its lanes in order, so the
+    result equals `lanes` accumulate() calls bit for bit)."""
+    lanes = int(lanes)
+    bs = logits.shape[0] // lanes
+    if lanes == 1 or not logits.is_cuda or logits.dtype not in (torch.float32, torch.bfloat16):
+        for k in range(lanes):
+            accumulate(packed, logits[k * bs:(k + 1) * bs], kl)
+        return packed
+    lg = logits.contiguous()
+    act = _lib.ACT_F32 if lg.dtype == torch.float32 else _lib.ACT_BF16
+    _lib.check(_lib.lib().btx_mc_accumulate_lanes(lg.data_ptr(), lanes, bs, lg.shape[1], act, float(kl), packed.data_ptr(),
+                                                  torch.cuda.current_stream(lg.device).cuda_stream))
+    return packed
+
+
 def unpack(packed, bs, num_classes):
     """-> dict(mean_prob [bs,C], var_prob [bs,C], predictive_entropy [bs], mutual_information [bs], kl, samples)."""
     C = num_classes
@@ -79,21 +96,34 @@ def mc_forward(model, x, num_samples, sample_offset=0, with_kl=False, group=None
     mine = list(range(rank, num_samples, world))
     lanes = max(1, int(lanes)) if x.is_cuda else 1
     bs = x.shape[0]
+    from . import functional as BF
     for g0 in range(0, len(mine), lanes):
         grp = [sample_offset + s for s in mine[g0:g0 + lanes]]
         if len(grp) > 1:
             _rng.set_sample_lanes(model, grp, batch=bs, presample=True)
-        else:
+            logits = model(x)
+        elif x.is_cuda:
             if lanes > 1:
                 _rng.set_sample_lanes(model, None)
-            _rng.set_sample_index(model, grp[0], presample=x.is_cuda)
-        logits = model(x)
+            # a ragged last group of ONE sample is planned like a lane (BTX_FLAG_CONCURRENT: the K split of the throughput
+            # plan), so a sample's f32 summation order does not depend on how the samples were grouped over launches / ranks
+            with BF.concurrent_plan(lanes > 1 or BF._CONCURRENT):
+                _rng.set_sample_index(model, grp[0], presample=True)
+                logits = model(x)
+        else:
+            # CPU tensors take the ATen route, whose noise comes from torch's generator (the reference's draw order): key
+            # that generator on (seed, sample index) for the duration of the forward, so that sample s is the same draw on
+            # whichever rank evaluates it — the property the GPU path has by construction (BTX-RNG v1); the caller's
+            # generator state is left untouched
+            _rng.set_sample_index(model, grp[0])
+            with torch.random.fork_rng(devices=[]):
+                torch.manual_seed(_rng.cpu_sample_seed(grp[0]))
+                logits = model(x)
         if isinstance(logits, tuple):
             logits = logits[0]
         if packed is None:
             packed = torch.zeros(packed_numel(bs, logits.shape[1]), dtype=torch.float32, device=logits.device)
-        for k in range(len(grp)):
-            accumulate(packed, logits[k * bs:(k + 1) * bs], kl)
+        accumulate_lanes(packed, logits, len(grp), kl)
     if lanes > 1:
         _rng.set_sample_lanes(model, None)
     if packed is None:  # this rank got no sample: it still takes part in the collective
@@ -146,21 +176,28 @@ class GraphedMC:
         for s in my_samples: g.run(s)
         stats = unpack(g.packed, *g.logits_shape)
 
-    The parameters must not be re-allocated while the graph is alive (in-place updates are seen by the replays)."""
+    The parameters must not be re-allocated while the graph is alive.  In-place parameter updates are seen by the replays
+    of a one-sample graph and of lane_mode "streams"; lane_mode "launch" (the default for lanes > 1) caches the Flipout mean
+    tiles and sigma between replays: call refresh_weights() after an update.  The input is read from `self.x` on every
+    replay unless static_input=True (then call set_input() to change it)."""
 
-    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1, keep_logits=False, concurrent_hint=None, lane_mode="launch"):
+    def __init__(self, model, x, kl=0.0, warmup=2, lanes=1, keep_logits=False, concurrent_hint=None, lane_mode="launch",
+                 static_input=False):
         """lanes > 1: one replay evaluates `lanes` MC samples (independent noise: the same results as one at a time); use
         run_many().  lane_mode "launch" (default): the samples are lanes of ONE launch per layer (rng.set_sample_lanes:
         4x the workgroups per launch fill the 256 CUs where one sample of a 7x7 / 14x14 layer cannot, and one
         workgroup's prologue / store overlaps another's MFMA loop); the mean tiles of the Flipout layers are written
         once (refresh_weights() after a parameter update), a replay samples sigma*eps only.  "streams": each sample on
-        its own stream inside the graph, one launch per (layer, sample) — the round-2 form, kept for A/B."""
+        its own stream inside the graph, one launch per (layer, sample) — the round-2 form, kept for A/B.
+        static_input (lane_mode "launch"): the input batch is the same for every replay, so a row-fused stem packs it into
+        its kernel layout ONCE, outside the graph, instead of once per replay (set_input() re-packs)."""
         if not x.is_cuda:
             raise ValueError("GraphedMC needs CUDA (ROCm) tensors")
         if lane_mode not in ("launch", "streams"):
             raise ValueError("lane_mode must be 'launch' or 'streams'")
         self.model, self.x, self.kl, self.lanes = model, x, float(kl), int(lanes)
         self.lane_mode = lane_mode
+        self.static_input = bool(static_input) and self.lanes > 1 and lane_mode == "launch"
         if self.lanes > 1 and lane_mode == "launch":
             self._init_launch_lanes(warmup, keep_logits)
             return
@@ -220,7 +257,7 @@ class GraphedMC:
         self._tiles = {}  # tile buffers of this graph (rng._presample cache): the mean tiles live here between replays
         self.packed, self._streams = None, []
         self.bs = x.shape[0]
-        _rng.set_sample_lanes(model, list(range(self.lanes)), batch=self.bs, sample_dev=self.sample_dev)
+        self._set_lane_state(True)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():
@@ -232,6 +269,23 @@ class GraphedMC:
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._launch_lanes(skip_mu=True)
         self.packed.zero_()
+        # the replays need nothing from the Python-side lane state: a plain `model(x)` between replays is a plain forward
+        self._set_lane_state(False)
+
+    def _set_lane_state(self, on):
+        """(re)apply / clear this graph's lane state on the layers WITHOUT touching the sample words: what makes
+        rng.presample() address this graph's tile buffers (its cache key holds the lane count and the layers' ids)"""
+        for m in self._layers:
+            d = m.__dict__
+            if on:
+                d["_btx_lanes"], d["_btx_lane_batch"], d["_btx_sample_dev"] = self.lanes, self.bs, self.sample_dev
+                d["_btx_static_x"] = self.static_input
+            else:
+                d.pop("_btx_lanes", None)
+                d.pop("_btx_lane_batch", None)
+                d.pop("_btx_static_x", None)
+                d["_btx_sample_dev"] = None
+            d["_btx_pre"] = None
 
     def _launch_lanes(self, skip_mu):
         _rng.presample(self.model, 0, cache=self._tiles, skip_mu=skip_mu)
@@ -242,19 +296,38 @@ class GraphedMC:
         if self.packed is None:
             self.logits_shape = (bs, logits.shape[1])
             self.packed = torch.zeros(packed_numel(bs, logits.shape[1]), dtype=torch.float32, device=logits.device)
-        for k in range(self.lanes):
-            accumulate(self.packed, logits[k * bs:(k + 1) * bs], self.kl)
-            if self.keep_logits:
+        accumulate_lanes(self.packed, logits, self.lanes, self.kl)  # one launch for all lanes of the replay
+        if self.keep_logits:
+            for k in range(self.lanes):
                 self.lane_logits[k] = logits[k * bs:(k + 1) * bs]
 
     def refresh_weights(self):
-        """lane_mode "launch": rewrite the cached mean tiles after an in-place parameter update (the replays sample
-        sigma*eps only).  The sample words keep their values."""
+        """lane_mode "launch": rewrite the cached mean tiles and sigma after an in-place parameter update (the replays
+        sample sigma*eps only).  The sample words keep their values.  Works whatever happened to the model since the
+        capture (plain forwards, a training step, another GraphedMC): the lane state of THIS graph is re-applied for the
+        call, so the sampling pass writes the buffers the captured launches read."""
         if self.lanes > 1 and self.lane_mode == "launch":
+            if not self._tiles:
+                raise _lib.BtxError("GraphedMC.refresh_weights() after close()")
             with torch.no_grad():
-                _rng.presample(self.model, 0, cache=self._tiles, skip_mu=False)
+                self._set_lane_state(True)
+                try:
+                    n_before = len(self._tiles)
+                    _rng.presample(self.model, 0, cache=self._tiles, skip_mu=False)
+                    if len(self._tiles) != n_before:  # a cache miss would fill NEW buffers the replays never read
+                        raise _lib.BtxError("GraphedMC.refresh_weights(): the model's layers no longer match the captured graph")
+                finally:
+                    self._set_lane_state(False)
+
+    def set_input(self, x):
+        """copy a new batch (same shape / dtype) into the captured input; with static_input the row-fused stem's packed
+        copy — what the captured launches read — is refilled from it"""
+        self.x.copy_(x)
+        if self.static_input:
+            with torch.no_grad():
                 for m in self._layers:
-                    m.__dict__["_btx_pre"] = None
+                    if hasattr(m, "_static_repack"):
+                        m._static_repack(self.x)
 
     def _lane(self, k):
         for m in self._layers:
@@ -295,4 +368,6 @@ class GraphedMC:
             m._btx_pre = None
             m.__dict__.pop("_btx_lanes", None)
             m.__dict__.pop("_btx_lane_batch", None)
+            m.__dict__.pop("_btx_static_x", None)
+            m.__dict__.pop("_btx_static_pack", None)
         self._tiles = {}

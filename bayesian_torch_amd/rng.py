@@ -29,6 +29,14 @@ def seed():
     return _seed
 
 
+def cpu_sample_seed(sample_idx):
+    """torch-generator seed of MC sample `sample_idx` on the ATen (CPU) route: mc.mc_forward forks the generator and seeds it
+    with this for the duration of one forward, so a sample is the same draw on whichever rank evaluates it"""
+    x = (seed() ^ (0x9E3779B97F4A7C15 * (int(sample_idx) + 1))) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 31
+    return x & 0x7FFFFFFFFFFFFFFF
+
+
 def next_layer_id():
     return next(_layer_counter)
 
@@ -64,7 +72,10 @@ def set_sample_lanes(model, indices, batch=None, presample=False, sample_dev=Non
     in one launch per layer (btx_contract_fwd_lanes).  Feed the model its input ONCE (`batch` images: the first layers
     read it for every lane) — every activation behind the first variational layer, and the model's output, hold the
     lanes back to back along the batch axis ([len(indices) * batch, ...]).  Lane l computes bit for bit what a plain
-    forward with set_sample_index(model, indices[l]) would.  `indices=None` (or one index) returns to plain forwards.
+    forward with set_sample_index(model, indices[l]) planned for throughput (functional.concurrent_plan(), i.e.
+    BTX_FLAG_CONCURRENT — a launch with lanes always takes that plan's K split) would; against the default latency plan
+    the f32 summation order of small-map layers can differ by rounding.  `indices=None` (or one index) returns to plain
+    forwards.
     GPU-only; the indices live in a device tensor (`sample_dev`: an int32 tensor to (re)use — mc.GraphedMC keeps one
     per graph and rewrites it between replays)."""
     import torch

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BTX_ABI_VERSION 5
+#define BTX_ABI_VERSION 6
 
 /* argument-error codes (negative) */
 #define BTX_E_NULL        (-1)   /* required pointer is NULL */
@@ -57,6 +57,11 @@ extern "C" {
 /* contraction precision */
 #define BTX_PREC_F32  0   /* v_mfma_f32_32x32x2_f32: exact f32 fma chain (parity mode) */
 #define BTX_PREC_BF16 1   /* v_mfma_f32_32x32x16_bf16, f32 accumulate (throughput mode) */
+#define BTX_PREC_BF16X3 2 /* split-bf16: f32 activations, every operand as hi + lo bf16 (hi = rn(v), lo = rn(v - hi)), three
+                             v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), f32 accumulate: the f32 result of
+                             the reference's F.conv*d / F.linear to ~1e-6 rel-L2 per layer (the tolerance north_star states is
+                             1e-4) at a third of the bf16 matrix rate instead of a sixteenth.  Kernel family and workspace
+                             sizes are those of BTX_PREC_F32; sampled-weight tiles (btx_sample_weights) are specific to it. */
 /* flags */
 #define BTX_FLAG_TRANSPOSED   1u  /* ConvTranspose gather rule */
 #define BTX_FLAG_KL_ACCUM     2u  /* btx_kl_gauss: add to *kl_out instead of overwriting */
@@ -218,7 +223,9 @@ int btx_contract_fwd_ex(int kind, const BtxGeom* g,
  * layer in ONE launch: lane l reads x + l*x_stride (x_stride 0: the lanes share the input, e.g. the network's first
  * layer), uses the MC sample index rng->sample_idx + l (rng->sample_idx_dev[l] when given: n consecutive words) and
  * writes out + l*out_stride (residual + l*res_stride).  Strides in bytes, multiples of 16.  Every lane computes bit for
- * bit what btx_contract_fwd_ex would for its sample (the noise indices are relative to the lane's own tensors).
+ * bit what btx_contract_fwd_ex with BTX_FLAG_CONCURRENT would for its sample (the noise indices are relative to the lane's
+ * own tensors; a launch with lanes is always planned for throughput, and the K split — the f32 summation order — of that
+ * plan is decided by the grid of ONE lane, so it does not depend on n).
  * noise->sampled_w: the buffer btx_sample_weights_lanes filled for the same n.  Explicit noise tensors: n == 1 only.
  * ws: btx_contract_workspace_bytes(..., flags | BTX_FLAG_LANES(n)). */
 typedef struct BtxLanes {
@@ -327,6 +334,11 @@ int btx_fill_sign(int8_t* out, size_t n, const BtxRng* rng, uint32_t rng_stream,
 size_t btx_mc_packed_floats(int bs, int C);
 int btx_mc_accumulate(const void* logits, int bs, int C, int act_dtype, float kl,
                       float* packed, void* stream);
+/* the same for the logits of `lanes` MC samples back to back ([lanes][bs][C], what a btx_contract_fwd_lanes forward leaves):
+ * ONE launch; a workgroup owns a batch row and folds its lanes in order, so the result is bit for bit that of `lanes`
+ * btx_mc_accumulate calls. */
+int btx_mc_accumulate_lanes(const void* logits, int lanes, int bs, int C, int act_dtype, float kl,
+                            float* packed, void* stream);
 
 #ifdef __cplusplus
 }

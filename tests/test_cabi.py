@@ -28,7 +28,7 @@ def test_abi_version_and_argument_errors_without_gpu():
     """pure host-side calls: version, strerror, shape arithmetic, argument validation (no kernel is launched)"""
     from bayesian_torch_amd import _lib
     L = _lib.lib()
-    assert L.btx_abi_version() == 5
+    assert L.btx_abi_version() == 6
     assert b"NULL" in L.btx_strerror(-1)
     g = _lib.Geom()
     g.NB, g.D, g.H, g.W, g.C, g.N = 64, 1, 56, 56, 64, 128
@@ -59,6 +59,11 @@ def test_abi_version_and_argument_errors_without_gpu():
     g.C = g.N = 64
     # (+ 4 KiB, 256-byte aligned: the image-group queues of the persistent form of the tap-unrolled 3x3 kernel)
     assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 1, 1, 0) == 2 * 64 * 576 * 2 + 4096
+    # BTX_PREC_BF16X3 (split-bf16): the f32 mode's kernel family, tiles of [hi | lo] bf16 = 4 bytes per weight
+    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 0, 2, 0) == L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 0, 0, 0)
+    assert L.btx_sampled_w_bytes(ctypes.byref(g), 1, 2) == L.btx_sampled_w_bytes(ctypes.byref(g), 1, 0) > 0
+    assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 0, 3, 0) == 0  # unknown precision code
+    assert L.btx_mc_accumulate_lanes(None, 2, 4, 10, 0, 0.0, None, None) == -1
 
 
 def test_argument_errors_of_the_sampling_and_format_entry_points():

@@ -5,6 +5,7 @@ distribution of MC samples against fixtures generated from the reference itself.
 
 Tolerances (also in DESIGN.md §2):
   f32 parity mode   per layer rel-L2 <= 1e-4 (north_star's output bar)
+  bf16x3 (split-bf16, three MFMAs per product, f32 activations) per layer rel-L2 <= 1e-4 — the same bar as the f32 mode
   bf16 throughput   per layer rel-L2 <= 1e-2 against the f32 chain on the same (bf16-valued) input: operands rounded to 8
                     mantissa bits, f32 accumulation (measured 2.4-2.7e-3); logits of the graphed + fused configuration
                     <= 1e-2 for ResNet18 and ResNet50+MOPED (measured 3.8-5.5e-3)
@@ -82,7 +83,7 @@ def _check_every_layer(model, x, typ, sample, tol):
     return worst[0], worst[1], logits
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 1e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 1e-2), ("bf16x3", 1e-4)])
 @pytest.mark.parametrize("typ", ["Reparameterization", "Flipout"])
 def test_resnet18_bs64_every_layer(typ, prec, tol):
     """BASELINE cfg3 (Reparameterization) / cfg4 (Flipout): dnn_to_bnn(ResNet18), 224^2, batch 64"""
@@ -101,7 +102,7 @@ def test_resnet18_bs64_every_layer(typ, prec, tol):
         bt.set_precision("f32")
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 1e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16", 1e-2), ("bf16x3", 1e-4)])
 def test_resnet50_moped_bs128_every_layer(prec, tol):
     """BASELINE cfg5 (per-GPU shard): dnn_to_bnn(ResNet50) Flipout with moped_enable=True (delta 0.5), batch 128"""
     import bayesian_torch_amd as bt
@@ -124,11 +125,14 @@ def test_resnet50_moped_bs128_every_layer(prec, tol):
         bt.set_precision("f32")
 
 
-@pytest.mark.parametrize("arch,typ,moped,bs,tol", [("resnet18", "Flipout", False, 64, 1e-2),
-                                                    ("resnet18", "Reparameterization", False, 64, 1e-2),
-                                                    ("resnet50", "Flipout", True, 128, 1e-2)])
-def test_benched_configuration_end_to_end(arch, typ, moped, bs, tol):
-    """bench.py's configuration — bf16, eval-BN/ReLU/residual folded into the epilogues (fuse_resnet), one weight
+@pytest.mark.parametrize("arch,typ,moped,bs,prec,tol", [("resnet18", "Flipout", False, 64, "bf16", 1e-2),
+                                                         ("resnet18", "Reparameterization", False, 64, "bf16", 1e-2),
+                                                         ("resnet50", "Flipout", True, 128, "bf16", 1e-2),
+                                                         ("resnet18", "Flipout", False, 64, "bf16x3", 1e-4),
+                                                         ("resnet50", "Flipout", True, 128, "bf16x3", 1e-4)])
+def test_benched_configuration_end_to_end(arch, typ, moped, bs, prec, tol):
+    """bench.py's configurations — bf16 (headline) and bf16x3 (extra.cfg4_bf16x3 / cfg5_bf16x3: f32 activations, split-bf16
+    MFMAs, logits inside north_star's 1e-4), eval-BN/ReLU/residual folded into the epilogues (fuse_resnet), one weight
     sampling launch for all lanes, hipGraph replay with BENCH_LANES MC samples as lanes of one launch per layer (bench.py's
     default) — against the UNFUSED f32-parity-mode op chain of the same parameters evaluated eagerly with the same sample
     indices (same BTX-RNG noise).  Two replays: the second one reads the cached mean tiles (BTX_SAMPLE_SKIP_MU)."""
@@ -150,10 +154,11 @@ def test_benched_configuration_end_to_end(arch, typ, moped, bs, tol):
                 bt.set_sample_index(ref_m, samples[k])
                 refs.append(ref_m(x).float().clone())
         del ref_m
-        bt.set_precision("bf16")
-        m = _build(arch, typ, moped, dev, True)
+        bt.set_precision(prec)
+        m = _build(arch, typ, moped, dev, prec == "bf16")
         fuse_resnet(m)
-        g = mc.GraphedMC(m, x.to(torch.bfloat16), kl=0.0, lanes=BENCH_LANES, keep_logits=True)
+        g = mc.GraphedMC(m, x.to(torch.bfloat16) if prec == "bf16" else x, kl=0.0, lanes=BENCH_LANES, keep_logits=True,
+                         static_input=True)
         errs = []
         for rep in range(2):
             g.run_many(samples[rep * BENCH_LANES:(rep + 1) * BENCH_LANES])
@@ -164,8 +169,8 @@ def test_benched_configuration_end_to_end(arch, typ, moped, bs, tol):
         g.close()
         assert len(errs) == len(checked)
         assert not torch.equal(refs[0], refs[1])
-        print("%s %s%s bs%d: logits rel-L2 of the graphed bf16 configuration vs the unfused f32 chain: %s" % (
-            arch, typ, "+MOPED" if moped else "", bs, ", ".join("%.3g" % e for e in errs)))
+        print("%s %s%s bs%d: logits rel-L2 of the graphed %s configuration vs the unfused f32 chain: %s" % (
+            arch, typ, "+MOPED" if moped else "", bs, prec, ", ".join("%.3g" % e for e in errs)))
         assert max(errs) < tol, errs
     finally:
         bt.set_precision("f32")

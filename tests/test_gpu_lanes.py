@@ -37,7 +37,7 @@ LAYER_CASES = [
 ]
 
 
-@pytest.mark.parametrize("prec,act", [("bf16", torch.bfloat16), ("f32", torch.float32)])
+@pytest.mark.parametrize("prec,act", [("bf16", torch.bfloat16), ("f32", torch.float32), ("bf16x3", torch.float32)])
 @pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] + str(c[2]) for c in LAYER_CASES])
 def test_lanes_equal_single_sample_launches(case, prec, act):
     import bayesian_torch_amd as bt
@@ -183,3 +183,126 @@ def test_rank_partition_of_samples_is_rank_count_independent():
             assert torch.allclose(tot, one, rtol=1e-5, atol=1e-6), R
     finally:
         bt.set_precision("f32")
+
+
+def _small_net(dev):
+    import bayesian_torch_amd as bt
+    torch.manual_seed(4)
+    net = torch.nn.Sequential(torch.nn.Conv2d(32, 64, 3, padding=1, bias=False), torch.nn.ReLU(),
+                              torch.nn.Conv2d(64, 64, 3, padding=1, bias=True), torch.nn.ReLU(),
+                              torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(64, 16))
+    bt.dnn_to_bnn(net, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Flipout",
+                            moped_enable=False, moped_delta=0.5))
+    net = net.to(dev).eval()
+    bt.assign_layer_ids(net)
+    return net
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_graphed_mc_refresh_weights_after_parameter_update(prec):
+    """lane_mode "launch" caches the Flipout mean tiles and sigma inside the graph.  After an in-place parameter
+    update, refresh_weights() must make the replays see the new parameters whatever ran on the model in between (plain
+    forwards, another graph), and the capture must not leave the lane state on the model."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc, functional as BF
+    dev = _dev()
+    bt.manual_seed(8)
+    bt.set_precision(prec)
+    try:
+        net = _small_net(dev)
+        x = torch.randn(4, 32, 12, 12, device=dev)
+        idx = [5, 6, 7]
+
+        def eager():
+            outs = []
+            with torch.no_grad(), BF.concurrent_plan():
+                for i in idx:
+                    bt.set_sample_index(net, i, presample=True)
+                    outs.append(net(x).float().clone())
+            return outs
+        g = mc.GraphedMC(net, x, kl=0.0, lanes=3, keep_logits=True)
+        with torch.no_grad():
+            assert net(x).shape[0] == 4  # a plain forward between replays is a plain forward (no lanes left on the model)
+        before = eager()
+        g.run_many(idx)
+        torch.cuda.synchronize()
+        for l in range(3):
+            assert torch.equal(g.lane_logits[l].float(), before[l])
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.add_(0.05 * torch.randn_like(p_))
+        g2 = mc.GraphedMC(net, x, kl=0.0, lanes=2)  # another graph on the same model: its own tile buffers
+        after = eager()
+        assert not torch.equal(after[0], before[0])
+        g.run_many(idx)  # stale tiles: still the old mean weights (documented: call refresh_weights())
+        torch.cuda.synchronize()
+        assert not torch.equal(g.lane_logits[0].float(), after[0])
+        g.refresh_weights()
+        g.run_many(idx)
+        torch.cuda.synchronize()
+        for l in range(3):
+            assert torch.equal(g.lane_logits[l].float(), after[l]), l
+        g.close()
+        g2.close()
+        with pytest.raises(Exception):
+            g.refresh_weights()
+    finally:
+        bt.set_precision("f32")
+
+
+def test_lanes_with_unaligned_lane_strides_fall_back_to_single_launches():
+    """a 10-class head at an odd batch has per-lane outputs that are not multiples of 16 bytes —
+    btx_contract_fwd_lanes refuses them (BTX_E_ALIGN); the host runs such a layer lane by lane instead of raising"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L, functional as BF
+    dev = _dev()
+    bt.manual_seed(3)
+    torch.manual_seed(1)
+    layer = L.LinearFlipout(64, 10).to(dev)
+    bs, idx = 3, [2, 9, 10]
+    xs = [torch.randn(bs, 64, device=dev) for _ in idx]
+    with torch.no_grad():
+        with BF.concurrent_plan():
+            singles = [layer._forward_hip(xs[l], sample_idx=idx[l]) for l in range(3)]
+        bt.set_sample_lanes(layer, idx, batch=bs)
+        out = layer._forward_hip(torch.cat(xs, 0))
+        bt.set_sample_lanes(layer, None)
+    assert out.shape == (9, 10)
+    for l in range(3):
+        assert torch.equal(out[l * bs:(l + 1) * bs], singles[l])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_mc_accumulate_lanes_equals_sequential_accumulates(dt):
+    from bayesian_torch_amd import mc
+    dev = _dev()
+    torch.manual_seed(0)
+    lanes, bs, C = 5, 7, 1000
+    lg = (3 * torch.randn(lanes * bs, C, device=dev)).to(dt)
+    a = torch.zeros(mc.packed_numel(bs, C), device=dev)
+    b = torch.zeros_like(a)
+    for rep in range(2):
+        mc.accumulate_lanes(a, lg, lanes, 1.5)
+        for k in range(lanes):
+            mc.accumulate(b, lg[k * bs:(k + 1) * bs], 1.5)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert float(a[-1]) == 2 * lanes
+
+
+def test_lstm_refuses_device_resident_sample_index():
+    """every LSTM time step must draw fresh noise; a pinned device-resident sample index cannot provide that"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    from bayesian_torch_amd._lib import BtxError
+    dev = _dev()
+    torch.manual_seed(0)
+    lstm = L.LSTMFlipout(16, 16).to(dev)
+    X = torch.randn(2, 3, 16, device=dev)
+    with torch.no_grad():
+        lstm(X)
+        sdev = bt.set_sample_lanes(lstm, [1, 2], batch=2)
+        with pytest.raises(BtxError):
+            lstm(X)
+        bt.set_sample_lanes(lstm, None)
+        lstm(X)
