@@ -638,6 +638,9 @@ static double tall_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, Pat
   }
   return best;
 }
+#ifndef BTX_TALL_MIN_DEFAULT
+#define BTX_TALL_MIN_DEFAULT 1.15
+#endif
 // tile of `tp` output pixels whose patch holds at most `ppcap` pixels
 static bool patch_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, PatchPlan* pt) {
   const int Ho = pl.Ho, Wo = pl.Wo;
@@ -694,7 +697,9 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
     // measured (tools/kbench.py --throughput-plan, batch 256 / 512 = the tiles of 4 / 8 MC sample lanes): the heavier
     // tile (4 full waves, a store side 50 % longer) pays off only where it removes >= ~15 % of the workgroups (28x28:
     // 19 %, +3 / +8 %; 14x14: 16 %, -5 / +2 %); on 56x56 (9 % fewer workgroups) and 7x7 (6 %) it loses 4-7 %
-    if (eff_tall > eff_old * 1.15) *pt = tp;
+    const char* te = tune_env("BTX_TALL_MIN");  // A/B: the gain in pixel-slot efficiency from which tall strips are taken
+    const double tall_min = te ? atof(te) : BTX_TALL_MIN_DEFAULT;
+    if (eff_tall > eff_old * tall_min) *pt = tp;
   }
   const int pieces = (pt->PP + 15) / 16;
   pt->NI = (pieces + pt->nw - 1) / pt->nw;
@@ -1197,6 +1202,11 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
         }
       }
     }
+    // store side straight from the fragment registers (direct_epilogue_pm): the tap-unrolled 4-wave kernel, bf16 in and out,
+    // one K split, whole aligned 64-channel tiles, hashed s_out, offsets with an out-of-range value to spare
+    p.ep_direct = (pt.taps == 33 && pt.kg == 1 && pl.ksplits == 1 && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 &&
+                   out_bf16 && (pl.Ng % 64) == 0 && (g->N % 32) == 0 && !(noise && noise->sign_out) &&
+                   (long long)pl.M * g->N * 2 < 0x7ff00000LL && !tune_env("BTX_NO_DIRECT")) ? 1 : 0;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg * lanes, st)
          : (prec == BTX_PREC_BF16X3) ? launch_contract_patch_x3(kind, p, pl.nwg * lanes, st)
                                      : launch_contract_patch_f32(kind, p, pl.nwg * lanes, st);

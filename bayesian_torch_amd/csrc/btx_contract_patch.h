@@ -403,9 +403,9 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
   }
 #endif
   if (p.pt_taps == 33) {  // 3x3, 4-wave K-groups: the tap-unrolled kernel (btx_contract_taps.h)
-#define BTX_LAUNCH_TP(KIND, KG)                                                                                    \
+#define BTX_LAUNCH_TP(KIND, KG, ...)                                                                               \
   do {                                                                                                            \
-    auto kfn = contract_taps_kernel<PREC, KIND, 3, 3, KG>;                                                          \
+    auto kfn = contract_taps_kernel<PREC, KIND, 3, 3, KG, ##__VA_ARGS__>;                                           \
     static bool attr_done = false;                                                                                \
     if (!attr_done) {                                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);   \
@@ -415,7 +415,15 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
     hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256 * KG), p.pt_lds, st, p);                                          \
   } while (0)
     if (p.pt_kg == 2) { if (kind == 0) BTX_LAUNCH_TP(0, 2); else BTX_LAUNCH_TP(1, 2); }
-    else { if (kind == 0) BTX_LAUNCH_TP(0, 1); else BTX_LAUNCH_TP(1, 1); }
+    else {
+      if constexpr (PREC == 1) {
+        if (p.ep_direct) {  // the store side from the fragment registers (host-checked conditions, btx_api.hip)
+          if (kind == 0) BTX_LAUNCH_TP(0, 1, true); else BTX_LAUNCH_TP(1, 1, true);
+          return (int)hipGetLastError();
+        }
+      }
+      if (kind == 0) BTX_LAUNCH_TP(0, 1); else BTX_LAUNCH_TP(1, 1);
+    }
 #undef BTX_LAUNCH_TP
     return (int)hipGetLastError();
   }

@@ -76,8 +76,12 @@ constexpr int tp_pieces(int t) {
 // (measured: 1800 cycles per stage), so a K-group's stage is two halves — H1: DMA issue + the LDS reads of THIS stage's
 // fragments, H2: the MFMAs — with a barrier after each, and group 1 runs half a stage behind group 0 (one extra barrier
 // before its first stage, group 0 one after its last): one group's MFMA half sits beside the other's load half.
-template <int PREC, int KIND, int KH, int KW, int KG>
+// DIRECT (bf16, KG == 1; the host launches it when ContractParams.ep_direct): the store side runs from the fragment registers
+// (direct_epilogue, btx_epilogue.h) — its own instantiation of the kernel, because with both store sides behind a run-time
+// branch of one kernel hipcc spills (the staged side's address arithmetic is interleaved with the fold).
+template <int PREC, int KIND, int KH, int KW, int KG, bool DIRECT = false>
 __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const ContractParams) {
+  static_assert(!DIRECT || (PREC == 1 && KG == 1), "direct store side: bf16, one K-group");
   BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   constexpr int NW = 4, NT = 256, MI = 2, T = KH * KW;
   static_assert(T >= 5 && T <= 32, "tap-unrolled kernel: 5..32 taps");
@@ -464,8 +468,24 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     const uint32_t m0 = (uint32_t)(img0 * pe.Ho + row0) * (uint32_t)pe.Wo;
     const PixTall pmt = {pe, row0, col0};
     if constexpr (KG == 1) {
-      if (tall) staged_epilogue_pm<KIND, NW, PixTall>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pmt);
-      else staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+      if constexpr (DIRECT) {
+        // opaque copies of the thread's ids: without them the compiler computes the store side's lane-dependent addresses
+        // in front of the K loop and keeps them alive across it (the loop then spills)
+        int lane_o = lane, tid_o = tid;
+        asm volatile("" : "+v"(lane_o), "+v"(tid_o));
+        uint32_t gp[2];
+        bool gok[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int pl = wave * 64 + mi * 32 + (lane_o & 31);
+          if (tall) gp[mi] = pmt(pl, gok[mi]);
+          else { gok[mi] = pl < nvalid; gp[mi] = m0 + (uint32_t)pl; }
+        }
+        direct_epilogue<KIND>(pe, rl, accm, accd, smem, tid_o, lane_o, ntile, group, gp, gok);
+      } else {
+        if (tall) staged_epilogue_pm<KIND, NW, PixTall>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pmt);
+        else staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+      }
     } else {
       // Every wave is behind the barrier of its last stage: the whole LDS is free.  Group 1 -> exchange area
       // [chunk i][thread] x 16 B (a wave writes 1 KiB per instruction; 128 KiB Flipout, 64 KiB Reparameterization),

@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 // [4 bf16 hi | 4 bf16 lo] of its 4 k), so their fragments need no VALU at all.
 // One K-step of the 32x32x16 MFMA per stage: the lane's 8 k are granule rows h and 2+h.
 __device__ __forceinline__ void split_bf16_pair(uint32_t x0, uint32_t x1, uint32_t& hi, uint32_t& lo) {
+#pragma clang fp contract(off)
   const f32x2 v = {u2f(x0), u2f(x1)};
   hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32 (round to nearest even)
   const f32x2 r = {v[0] - u2f(hi << 16), v[1] - u2f(hi & 0xffff0000u)};   // exact in f32

@@ -21,6 +21,9 @@ namespace btx {
 // call with that index.
 // split-bf16 tiles (PREC == 2, btx_mma.h): the quad's granule holds [4 bf16 hi | 4 bf16 lo], hi = rn(w), lo = rn(w - hi)
 __device__ __forceinline__ u32x4 pack_quad_split(const float* w) {
+  // no fused multiply-add across the split: `w` is the ROUNDED f32 product sigma*eps in every kernel that samples (hipcc
+  // contracts `sigma * eps - hi` into one fma in some call sites and not in others: tiles would differ by an ulp of lo)
+#pragma clang fp contract(off)
   const f32x4 v = {w[0], w[1], w[2], w[3]};
   const u32x2 hb = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
   const f32x4 r = {w[0] - u2f(hb[0] << 16), w[1] - u2f(hb[0] & 0xffff0000u), w[2] - u2f(hb[1] << 16),
