@@ -11,6 +11,7 @@ ACT_F32, ACT_BF16 = 0, 1
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 PREC_CODE = {"f32": 0, "bf16": 1, "bf16x3": 2}
 FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_GATHER, FLAG_SWAP_SIGNS, FLAG_CONCURRENT = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_REVERSE = 256
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
 ABI_VERSION = 6

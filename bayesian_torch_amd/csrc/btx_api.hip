@@ -1108,6 +1108,7 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   // BTX_FLAG_SWAP_SIGNS (data gradient of a Flipout layer): the op's input carries the forward's s_out, its output the
   // forward's s_in
   p.swap_signs = (flags & BTX_FLAG_SWAP_SIGNS) ? 1 : 0;
+  p.reverse = (flags & BTX_FLAG_REVERSE) ? 1 : 0;
   sign_keys(rng, p.swap_signs ? BTX_STREAM_SIGN_OUT : BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
   sign_keys(rng, p.swap_signs ? BTX_STREAM_SIGN_IN : BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
   {

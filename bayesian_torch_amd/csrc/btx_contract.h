@@ -149,6 +149,7 @@ struct ContractParams {
   FastDiv fd_lane_nwg;
   long long lane_x, lane_out, lane_res, lane_wt, lane_partial;
   int lane_wt_delta;  // 1 (Flipout): the lanes share the mu tiles at wt, lane l's delta tiles sit at wt_delta_off + l*lane_wt
+  int reverse;        // BTX_FLAG_REVERSE: the grid's tiles in descending order
   int ep_direct;      // the store side runs from the fragment registers (direct_epilogue_pm, btx_epilogue.h): host-checked
   int pt_persist;     // > 0: the persistent form of the tap-unrolled kernel (btx_contract_taps3.h) with this many workgroups
   uint32_t* pt_queue; // persistent form: one zeroed counter per tile position (the image-group queue of its workgroups)
@@ -167,6 +168,7 @@ __device__ __forceinline__ int xcd_logical() {
 // noise indices are relative to the lane's own tensors, so a lane computes bit for bit what a launch of its own would.
 __device__ __forceinline__ ContractParams lane_view(const ContractParams& q, int& logical) {
   ContractParams p = q;
+  if (q.reverse) logical = (int)gridDim.x - 1 - logical;
   if (q.lanes > 1) {
     uint32_t lane, loc;
     fdivmod((uint32_t)logical, q.fd_lane_nwg, (uint32_t)q.lane_nwg, lane, loc);

@@ -33,6 +33,10 @@ def get_precision():
     return _PRECISION
 
 
+# Successive contraction launches walk their tiles in alternating directions (BTX_FLAG_REVERSE on every other call): a
+# layer then starts on the activations its producer wrote last.  Values do not depend on it.  BTX_ALT_ORDER=0 disables (A/B).
+_ALT_ORDER = os.environ.get("BTX_ALT_ORDER", "1") != "0"
+_ORDER_TOGGLE = [0]
 _OUT_LAYOUT = "channels_last"
 _CONCURRENT = False  # set by mc.GraphedMC(lanes > 1) while it captures: BTX_FLAG_CONCURRENT on every contraction launch
 
@@ -330,6 +334,10 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     flags = (_lib.FLAG_TRANSPOSED if op.transposed else 0) | extra_flags | (_lib.FLAG_CONCURRENT if _CONCURRENT else 0)
     if lanes > 1:
         flags |= lanes << _lib.FLAG_LANES_SHIFT
+    rev = 0
+    if _ALT_ORDER:
+        _ORDER_TOGGLE[0] ^= 1
+        rev = _lib.FLAG_REVERSE if _ORDER_TOGGLE[0] else 0
     if out_dtype is not None and out_dtype != x.dtype:
         flags |= _lib.FLAG_OUT_BF16 if out_dtype == torch.bfloat16 else _lib.FLAG_OUT_F32
     # the geometry struct and the workspace size depend on shapes only: built once per (op, batch, extent, modes)
@@ -409,7 +417,7 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     args = (kind, ctypes.byref(g), xp.data_ptr(), mu_p.data_ptr(), rho_p.data_ptr(),
             mu_b.data_ptr() if mu_b is not None else None, rho_b.data_ptr() if rho_b is not None else None,
             out.data_ptr(), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None,
-            act, prec_c, flags, ws.data_ptr() if ws is not None else None,
+            act, prec_c, flags | rev, ws.data_ptr() if ws is not None else None,
             ws.numel() if ws is not None else 0, stream, ctypes.byref(ep) if ep is not None else None)
     if lanes > 1:
         ln = _lib.Lanes()

@@ -482,7 +482,10 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
     else:
         mine = [k * world + rank for k in range(steps)]
         n_global = steps * world
-    warm = [20_000_000 + w * world + rank for w in range(prewarm)] + [10_000_000 + w * world + rank for w in range(warmup)]
+    nwarm = prewarm + warmup
+    if graph and lanes > 1:  # whole replays (the warm-up is not timed; a ragged one would only capture one more graph)
+        nwarm = -(-nwarm // lanes) * lanes
+    warm = [10_000_000 + w * world + rank for w in range(nwarm)]
     runner = Runner(model, x, kl, 1000, lanes, graph, presample, sizes=(len(mine), len(warm)), concurrent_hint=concurrent_hint,
                     lane_mode=lane_mode)
     runs = timed_mc(runner, mine, warm, world, dev, repeats=repeats)
@@ -660,6 +663,16 @@ def summarise_extra(name, r, prec, table=False):
     return out
 
 
+def auto_lanes(steps, cap=32):
+    """MC samples per hipGraph replay: the whole timed region when it fits, else its largest divisor <= cap (>= 8), else 16"""
+    if steps <= cap:
+        return max(1, steps)
+    for d in range(cap, 7, -1):
+        if steps % d == 0:
+            return d
+    return 16
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def self_launch(n, argv, dry_run):
     """re-exec under torch.distributed.run with one rank per GPU (rendezvous on 127.0.0.1, a free port)"""
@@ -741,8 +754,11 @@ def main():
                     "(BASELINE cfg4: 32 over 8 GPUs)")
     ap.add_argument("--no-fuse", action="store_true", help="keep BatchNorm/ReLU/residual as separate torch ops")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of every MC sample from Python")
-    ap.add_argument("--lanes", type=int, default=8, help="MC samples evaluated by one hipGraph replay; independent noise, "
-                    "identical results to one at a time")
+    ap.add_argument("--lanes", type=int, default=0, help="MC samples evaluated by one hipGraph replay (lanes of one launch "
+                    "per layer); independent noise, identical results to one at a time.  0 (default): as many as the timed "
+                    "region holds, up to 32 — a launch of 20 lanes has 2.5x the tiles of one of 8: its ramp-up and its last, "
+                    "partly filled round of workgroups weigh less (measured: 4 / 8 / 16 lanes = 0.377 / 0.382 / 0.406 of the MFMA "
+                    "peak on the dominant kernel)")
     ap.add_argument("--lane-mode", default="launch", choices=["launch", "streams"], help="launch: the samples of a replay "
                     "are lanes of ONE launch per layer (btx_contract_fwd_lanes); streams: one launch per (layer, sample), "
                     "each sample on its own stream (the round-2 form)")
@@ -763,6 +779,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:], args.dry_run))
 
+    if args.lanes <= 0:
+        per_rank = args.steps if args.scaling == "weak" else max(1, -(-args.total_samples // max(1, args.gpus)))
+        args.lanes = auto_lanes(per_rank)
     if args.no_stem_pool:
         from bayesian_torch_amd.models import fuse as _fuse
         _fuse.STEM_POOL_FUSION = False
@@ -863,22 +882,22 @@ def main():
         if world == 1 and not args.no_extras:
             extra = {}
             try:
-                r = run_resnet_config("resnet18", "Reparameterization", "bf16", 64, False, 15, 3, args.lanes, dev, parity=True,
+                r = run_resnet_config("resnet18", "Reparameterization", "bf16", 64, False, 16, 3, 16, dev, parity=True,
                                       prewarm=3)
                 extra["cfg3"] = summarise_extra("cfg3: dnn_to_bnn(ResNet18) Reparameterization bs64 bf16", r, "bf16")
                 r = run_resnet_config("resnet18", "Flipout", "f32", 64, False, 3, 1, 1, dev, prewarm=1)
                 extra["cfg4_f32_parity_mode"] = summarise_extra(
                     "cfg4 shard in f32 parity mode (v_mfma_f32_32x32x2_f32, f32 activations)", r, "f32")
                 # north_star's 1e-4 tolerance at throughput: f32 activations, split-bf16 operands, three bf16 MFMAs per product
-                r = run_resnet_config("resnet18", "Flipout", "bf16x3", 64, False, 16, 3, args.lanes, dev, parity=True, prewarm=3)
+                r = run_resnet_config("resnet18", "Flipout", "bf16x3", 64, False, 16, 3, 16, dev, parity=True, prewarm=3)
                 extra["cfg4_bf16x3"] = summarise_extra(
                     "cfg4 shard in split-bf16 mode (f32 activations, 3x v_mfma_f32_32x32x16_bf16 per product; fractions "
                     "against a third of the bf16 peak)", r, "bf16x3", table=True)
                 extra["cfg2"] = run_mlp_config(dev)
-                r = run_resnet_config("resnet50", "Flipout", "bf16", 128, True, 6, 2, args.lanes, dev, parity=True, prewarm=3)
+                r = run_resnet_config("resnet50", "Flipout", "bf16", 128, True, 16, 2, 16, dev, parity=True, prewarm=3)
                 extra["cfg5"] = summarise_extra("cfg5 shard: dnn_to_bnn(ResNet50) Flipout + MOPED(0.5) bs128 bf16", r, "bf16",
                                                 table=True)
-                r = run_resnet_config("resnet50", "Flipout", "bf16x3", 128, True, 8, 2, args.lanes, dev, parity=True, prewarm=2,
+                r = run_resnet_config("resnet50", "Flipout", "bf16x3", 128, True, 8, 2, 8, dev, parity=True, prewarm=2,
                                       per_launch=False)
                 extra["cfg5_bf16x3"] = summarise_extra("cfg5 shard in split-bf16 mode (f32 activations)", r, "bf16x3")
                 # the strong-scaling shape of cfg4 (32 samples over 8 GPUs): 4 MC samples on this rank, one replay — the

@@ -79,6 +79,11 @@ extern "C" {
 #define BTX_FLAG_CONCURRENT 128u  /* hint: other launches run beside this one (several MC samples in flight on their own
                                      streams): plan for device throughput — CU-time — rather than for the latency of this
                                      launch, i.e. do not split K through HBM just to fill idle CUs */
+#define BTX_FLAG_REVERSE    256u  /* walk the launch's workgroup tiles in DESCENDING order.  Results are identical (no launch
+                                     depends on its block order); a caller that chains layers alternates the flag so that each
+                                     launch starts on the activations its producer wrote LAST — the ones most likely still in
+                                     the 256-MB Infinity Cache when the tensors of a launch (MC sample lanes: hundreds of MB)
+                                     exceed it. */
 #define BTX_FLAG_GATHER      32u  /* force the element-wise gather kernel (any shape / alignment; samples in registers).
                                      The library picks it by itself whenever a fast kernel does not apply; the flag
                                      exists so tests can exercise it on shapes the fast kernels would take. */

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-BENCH_LANES = 8  # bench.py --lanes default
+BENCH_LANES = 20  # bench.py: the lanes of the driver's invocation (--steps 20)
 pytestmark = pytest.mark.gpu
 warnings.filterwarnings("ignore")
 
