@@ -1043,6 +1043,30 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     if (!dma) return BTX_E_UNSUPPORTED;
     out_bf16 = (flags & BTX_FLAG_OUT_BF16) ? 1 : 0;
   }
+  // MEASUREMENT ONLY (tuning builds, BTX_PW=1): pointwise contractions (Linear, 1x1x1 / stride 1 / no padding) on the
+  // Flipout-GEMM of btx_contract_pw.h — one workgroup per pixel tile walks `pw_ntb` n-tiles, store side from the fragment
+  // registers.  Bit-identical to the LDS-DMA kernel; measured (profiles/r04_pointwise_ab.txt): +4..7 % where the activation
+  // stages stay resident (K = 64), 7..16 % SLOWER where they stream — one workgroup per (pixel tile, n-tile) with the staged
+  // store already overlaps prologue and store side across the two workgroups of a CU, and whole-line stores drain faster.
+  bool pw = false;
+  int pw_ntb = 1, pw_chunks = 1;
+  if (tune_env("BTX_PW") && dma && !rowfuse && !patch && dma_nw == 4 && !(flags & BTX_FLAG_TRANSPOSED) && g->KD == 1 && g->KH == 1 && g->KW == 1 &&
+      g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 0 && g->pw == 0 &&
+      out_bf16 == (act_dtype == BTX_ACT_BF16 ? 1 : 0) && (pl.Ng % 64) == 0 && (g->N % 32) == 0 && !(noise && noise->sign_out) &&
+      (long long)pl.M * g->N * (out_bf16 ? 2 : 4) < 0x7ff00000LL) {
+    const long long mt = (pl.M + 255) / 256;
+    const long long base = mt * g->groups * lanes;
+    long long chunks = (1024 + base - 1) / base;  // at least two rounds of workgroups on the 512 slots when the n-tiles allow
+    if (chunks > pl.ntiles) chunks = pl.ntiles;
+    if (chunks < 1) chunks = 1;
+    pw_ntb = (int)((pl.ntiles + chunks - 1) / chunks);
+    pw_chunks = (pl.ntiles + pw_ntb - 1) / pw_ntb;
+    const long long nwg = mt * g->groups * pw_chunks;
+    if (nwg * lanes <= 0x7fffffffLL) {
+      pw = true;
+      pl.mtiles = (int)mt; pl.ksplits = 1; pl.kper = pl.K; pl.nwg = (int)nwg;
+    }
+  }
   size_t need = plan_ws(pl, g, lanes);
   // LDS-DMA and patch variants: the weights are sampled once per launch into the workspace (btx_presample.h),
   // behind the split-K partials
@@ -1203,14 +1227,25 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
         }
       }
     }
-    // store side straight from the fragment registers (direct_epilogue_pm): the tap-unrolled 4-wave kernel, bf16 in and out,
-    // one K split, whole aligned 64-channel tiles, hashed s_out, offsets with an out-of-range value to spare
-    p.ep_direct = (pt.taps == 33 && pt.kg == 1 && pl.ksplits == 1 && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 &&
-                   out_bf16 && (pl.Ng % 64) == 0 && (g->N % 32) == 0 && !(noise && noise->sign_out) &&
-                   (long long)pl.M * g->N * 2 < 0x7ff00000LL && !tune_env("BTX_NO_DIRECT")) ? 1 : 0;
+    // MEASUREMENT ONLY (tuning builds, BTX_DIRECT=1): the store side straight from the fragment registers (direct_epilogue,
+    // btx_epilogue.h) for the tap-unrolled 4-wave kernel — bf16 in and out, one K split, whole aligned 64-channel tiles,
+    // hashed s_out, offsets with an out-of-range value to spare.  Bit-identical; measured (profiles/r04_direct_store_ab.txt):
+    // its 32-byte pieces drain more slowly than the staged side's whole 128-byte lines — 6.1k against 4.9k cycles on a
+    // 56x56 tile, 6.5k against 8.3k on a tall strip — and the launch time does not move either way (+1.7 % .. -0.3 %).
+    p.ep_direct = (tune_env("BTX_DIRECT") && pt.taps == 33 && pt.kg == 1 && pl.ksplits == 1 && prec == BTX_PREC_BF16 &&
+                   act_dtype == BTX_ACT_BF16 && out_bf16 && (pl.Ng % 64) == 0 && (g->N % 32) == 0 && !(noise && noise->sign_out) &&
+                   (long long)pl.M * g->N * 2 < 0x7ff00000LL) ? 1 : 0;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg * lanes, st)
          : (prec == BTX_PREC_BF16X3) ? launch_contract_patch_x3(kind, p, pl.nwg * lanes, st)
                                      : launch_contract_patch_f32(kind, p, pl.nwg * lanes, st);
+#if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
+  } else if (dma && pw) {
+    p.pt_R = pw_ntb; p.pt_rtiles = pw_chunks;
+    p.fd_rtiles = make_fastdiv((uint32_t)pw_chunks); p.fd_inner = make_fastdiv((uint32_t)(pw_chunks * g->groups));
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_pw_bf16(kind, p, pl.nwg * lanes, st)
+         : (prec == BTX_PREC_BF16X3) ? launch_contract_pw_x3(kind, p, pl.nwg * lanes, st)
+                                     : launch_contract_pw_f32(kind, p, pl.nwg * lanes, st);
+#endif
   } else if (dma)
     rc = (prec == BTX_PREC_BF16) ? launch_contract_dma_bf16(kind, p, pl.nwg * lanes, st)
          : (prec == BTX_PREC_BF16X3) ? launch_contract_dma_x3(kind, p, pl.nwg * lanes, st)

@@ -822,6 +822,10 @@ int launch_contract_patch_bf16(int kind, const ContractParams& p, int nwg, hipSt
 int launch_contract_patch_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_stem_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_dma_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
+// pointwise Flipout-GEMM with the n-tile loop inside the workgroup (btx_contract_pw.h)
+int launch_contract_pw_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_pw_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_pw_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_presample_batch_x3(const PresampleBatch& b, hipStream_t st);
 
 template <int PREC>

@@ -416,12 +416,14 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
   } while (0)
     if (p.pt_kg == 2) { if (kind == 0) BTX_LAUNCH_TP(0, 2); else BTX_LAUNCH_TP(1, 2); }
     else {
+#if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
       if constexpr (PREC == 1) {
-        if (p.ep_direct) {  // the store side from the fragment registers (host-checked conditions, btx_api.hip)
+        if (p.ep_direct) {  // MEASUREMENT ONLY (BTX_DIRECT=1): the store side from the fragment registers, btx_epilogue.h
           if (kind == 0) BTX_LAUNCH_TP(0, 1, true); else BTX_LAUNCH_TP(1, 1, true);
           return (int)hipGetLastError();
         }
       }
+#endif
       if (kind == 0) BTX_LAUNCH_TP(0, 1); else BTX_LAUNCH_TP(1, 1);
     }
 #undef BTX_LAUNCH_TP

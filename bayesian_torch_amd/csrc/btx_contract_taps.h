@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
           if (tall) gp[mi] = pmt(pl, gok[mi]);
           else { gok[mi] = pl < nvalid; gp[mi] = m0 + (uint32_t)pl; }
         }
-        direct_epilogue<KIND>(pe, rl, accm, accd, smem, tid_o, lane_o, ntile, group, gp, gok);
+        direct_epilogue<KIND>(pe, rl, accm, accd, (float*)smem, tid_o, lane_o, ntile, group, gp, gok);
       } else {
         if (tall) staged_epilogue_pm<KIND, NW, PixTall>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pmt);
         else staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);

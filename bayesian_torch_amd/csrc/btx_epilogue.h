@@ -360,34 +360,39 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
 // gp[mi] / gok[mi]: output pixel index of the lane's pixel (wave * 64 + mi * 32 + lane % 32) of the tile, and whether it exists
 // (the caller evaluates its pixel map — PixContig or PixTall — so that this body exists ONCE per kernel: with one copy per
 // map behind a run-time branch the compiler hoists the copies' common sign-word shifts above the branch and spills them).
-template <int KIND>
+// OUT: the output element type (bf16: one 16-byte store per (pixel, 16 channels); float: two).  FILLED: the caller has
+// written the tile's constants to ba_lds (ep_fill_constants) and passed a barrier since — else this call does both.
+template <int KIND, typename OUT = __bf16, bool FILLED = false>
 __device__ __forceinline__ void direct_epilogue(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
-                                                const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int lane,
+                                                const f32x16 (&accd)[2][2], float* ba_lds, int tid, int lane,
                                                 int ntile, int group, const uint32_t (&gp)[2], const bool (&gok)[2]) {
-  const int l31 = lane & 31, h = lane >> 5;
+  constexpr bool BF = sizeof(OUT) == 2;
+  constexpr uint32_t ESZ = (uint32_t)sizeof(OUT);
+  const int h = lane >> 5;
   const bool has_bias = p.mu_b != nullptr;
   const bool has_aff = (p.ep_scale != nullptr) || (p.ep_shift != nullptr);
-  float* ba_lds = (float*)smem;  // [bias mean | bias delta | scale | shift] x 64, identities where absent
-  ep_fill_constants<KIND>(p, rl, ba_lds, tid, ntile, group, has_bias, has_aff);
+  // ba_lds: [bias mean | bias delta | scale | shift] x 64, identities where absent
+  if constexpr (!FILLED) ep_fill_constants<KIND>(p, rl, ba_lds, tid, ntile, group, has_bias, has_aff);
   const uint32_t cbase = (uint32_t)(group * p.Ng + ntile * BN);
-  const uint32_t out_bytes = (uint32_t)p.M * (uint32_t)p.N * 2u;
+  const uint32_t out_bytes = (uint32_t)p.M * (uint32_t)p.N * ESZ;
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, out_bytes, 0x00020000);
   uint32_t eo[2];  // byte offset of the lane's 8-channel run of (pixel mi, half 0, pair 0); a pixel that does not exist
 #pragma unroll     // gets an out-of-range offset: its loads return zeros, its stores are dropped
-  for (int mi = 0; mi < 2; ++mi) eo[mi] = gok[mi] ? (gp[mi] * (uint32_t)p.N + cbase + 8u * (uint32_t)h) * 2u : 0x80000000u;
+  for (int mi = 0; mi < 2; ++mi) eo[mi] = gok[mi] ? (gp[mi] * (uint32_t)p.N + cbase + 8u * (uint32_t)h) * ESZ : 0x80000000u;
   const bool res = p.ep_res != nullptr;
   const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_res, 0, res ? out_bytes : 0u, 0x00020000);
-  auto load_res = [&](u32x4 (&r)[2][2], int mi) __attribute__((always_inline)) {
+  // residual rows of pixel mi: (32-channel half ni) x (16-channel pair k) -> 8 channels of this lane (16 | 32 bytes)
+  struct Res { u32x4 a[2][2], b[2][2]; };
+  auto load_res = [&](Res& r, int mi) __attribute__((always_inline)) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int k = 0; k < 2; ++k)  // (no residual: a zero-length descriptor, the loads return zeros without a memory access)
-        r[ni][k] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, eo[mi] + (uint32_t)(ni * 64 + 32 * k), 0, 0);
+      for (int k = 0; k < 2; ++k) {  // (no residual: a zero-length descriptor, the loads return zeros without a memory access)
+        const uint32_t o = eo[mi] + (uint32_t)(ni * 32 + 16 * k) * ESZ;
+        r.a[ni][k] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, o, 0, 0);
+        if constexpr (!BF) r.b[ni][k] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, o + 16u, 0, 0);
+      }
   };
-  u32x4 rv[2][2];
-#ifdef BTX_DIRECT_RES_EARLY
-  load_res(rv, 0);  // pixel 0's residual rows travel while the accumulators are folded
-#endif
   uint32_t wsh[2][2];
   if constexpr (KIND == 1) {
 #pragma unroll
@@ -400,54 +405,38 @@ __device__ __forceinline__ void direct_epilogue(const ContractParams& p, const R
   uint32_t SB = 0x80000000u;
   asm volatile("" : "+s"(SB));
   const float lowb = p.ep_relu ? 0.f : -__builtin_inff();  // ReLU as a lower bound: one instruction stream for both
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the constants are in LDS
+  if constexpr (!FILLED) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the constants are in LDS
   // Phase A — (mean + bias) + s_out * (delta + bias delta) -> o (scalars, not the MFMA tuples: written back in place, the
-  // partially updated 16-register tuples made the allocator copy and spill)
+  // partially updated 16-register tuples made the allocator copy and spill).  ONE instantiation: without a bias the
+  // constants are zeros (16 LDS reads, 128 additions).
   float o[2][2][16];
-  auto fold = [&](auto bias_tag) __attribute__((always_inline)) {
-    constexpr bool BIAS = decltype(bias_tag)::value;
-    if constexpr (KIND == 1 || BIAS) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+  for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 bm, bd;
-          if constexpr (BIAS) {
-            const int cl = ni * 32 + 8 * q + 4 * h;
-            bm = *(const f32x4*)(ba_lds + cl);
-            bd = *(const f32x4*)(ba_lds + BN + cl);
-          }
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              float val = accm[mi][ni][4 * q + rr];
-              if constexpr (BIAS) val += bm[rr];
-              if constexpr (KIND == 1) {
-                float dl = accd[mi][ni][4 * q + rr];
-                if constexpr (BIAS) dl += bd[rr];
-                const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1));
-                val += u2f(__builtin_amdgcn_bitop3_b32(f2u(dl), wsh[mi][ni] << sft, SB, 0x78));  // dl ^ (w & SB)
-              }
-              o[mi][ni][4 * q + rr] = val;
-            }
-        }
-    } else {
+    for (int q = 0; q < 4; ++q) {
+      const int cl = ni * 32 + 8 * q + 4 * h;
+      const f32x4 bm = *(const f32x4*)(ba_lds + cl);
+      const f32x4 bd = *(const f32x4*)(ba_lds + BN + cl);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[mi][ni][r] = accm[mi][ni][r];
+        for (int rr = 0; rr < 4; ++rr) {
+          float val = accm[mi][ni][4 * q + rr] + bm[rr];
+          if constexpr (KIND == 1) {
+            const float dl = accd[mi][ni][4 * q + rr] + bd[rr];
+            const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1));
+            val += u2f(__builtin_amdgcn_bitop3_b32(f2u(dl), wsh[mi][ni] << sft, SB, 0x78));  // dl ^ (w & SB)
+          }
+          o[mi][ni][4 * q + rr] = val;
+        }
+#ifndef BTX_DIRECT_NO_FOLD_FENCE
+      __builtin_amdgcn_sched_barrier(0);  // one (ni, q) group at a time: left alone the scheduler requests the constants of
+#endif                                    // all eight groups up front (64 registers) and the fold's results go to scratch
     }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-#ifdef BTX_DIRECT_BIAS_BRANCH
-  if (has_bias) fold(std::true_type{}); else fold(std::false_type{});
-#else
-  fold(std::true_type{});  // ONE instantiation: without a bias the constants are zeros (16 LDS reads, 128 additions)
-#endif
+  __builtin_amdgcn_sched_barrier(0);
   // Phase B — one (pixel mi, 32-channel half ni, 16-channel pair k) group at a time: affine, pairing, residual, ReLU, store
+  Res rv, rnx;
+  load_res(rv, 0);  // (behind the fold: in front of it these registers push the fold's results into scratch)
   struct Cst { f32x4 sc[2], sh[2]; };
   auto load_cst = [&](Cst& c, int ni, int k) __attribute__((always_inline)) {
 #pragma unroll
@@ -457,12 +446,8 @@ __device__ __forceinline__ void direct_epilogue(const ContractParams& p, const R
       c.sh[hf] = *(const f32x4*)(ba_lds + 3 * BN + cl);
     }
   };
-#ifndef BTX_DIRECT_RES_EARLY
-  load_res(rv, 0);  // (behind the fold: in front of it the 16 registers of these rows push the fold's results into scratch)
-#endif
   Cst cst[2];
   load_cst(cst[0], 0, 0);
-  u32x4 rnx[2][2];
   static_for_ep<0, 8>([&](auto g_tag) __attribute__((always_inline)) {
     constexpr int g = decltype(g_tag)::value;
     constexpr int mi = g >> 2, ni = (g >> 1) & 1, k = g & 1;
@@ -481,16 +466,27 @@ __device__ __forceinline__ void direct_epilogue(const ContractParams& p, const R
       v[rr] = u2f(r[0]);
       v[4 + rr] = u2f(r[1]);
     }
-    const u32x4 rw = (mi == 0) ? rv[ni][k] : rnx[ni][k];
+    const Res& rr_ = (mi == 0) ? rv : rnx;
+    if constexpr (BF) {
+      const u32x4 rw = rr_.a[ni][k];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { v[2 * j] += u2f(rw[j] << 16); v[2 * j + 1] += u2f(rw[j] & 0xffff0000u); }
+      for (int j = 0; j < 4; ++j) { v[2 * j] += u2f(rw[j] << 16); v[2 * j + 1] += u2f(rw[j] & 0xffff0000u); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += u2f(rr_.a[ni][k][j]); v[4 + j] += u2f(rr_.b[ni][k][j]); }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], lowb);
-    const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
-    const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(x0, bf16x4));
-    const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(x1, bf16x4));
-    __builtin_amdgcn_raw_buffer_store_b128((u32x4){p0[0], p0[1], p1[0], p1[1]}, out_rsrc,
-                                           eo[mi] + (uint32_t)(ni * 64 + 32 * k), 0, 0);
+    const uint32_t so = eo[mi] + (uint32_t)(ni * 32 + 16 * k) * ESZ;
+    if constexpr (BF) {
+      const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+      const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(x0, bf16x4));
+      const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(x1, bf16x4));
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){p0[0], p0[1], p1[0], p1[1]}, out_rsrc, so, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){f2u(v[0]), f2u(v[1]), f2u(v[2]), f2u(v[3])}, out_rsrc, so, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){f2u(v[4]), f2u(v[5]), f2u(v[6]), f2u(v[7])}, out_rsrc, so + 16u, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   });
 }

@@ -4,6 +4,9 @@
 #include "btx_contract_patch.h"
 #include "btx_contract_stem.h"
 #include "btx_contract_dma.h"
+#if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
+#include "btx_contract_pw.h"  // measured and parked: see btx_api.hip
+#endif
 namespace btx {
 int launch_contract_patch_x3(int kind, const ContractParams& p, int nwg, hipStream_t st) {
   return launch_contract_patch_impl<2>(kind, p, nwg, st);
@@ -14,6 +17,11 @@ int launch_contract_stem_x3(int kind, const ContractParams& p, int nwg, hipStrea
 int launch_contract_dma_x3(int kind, const ContractParams& p, int nwg, hipStream_t st) {
   return launch_contract_dma_impl<2>(kind, p, nwg, st);
 }
+#if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
+int launch_contract_pw_x3(int kind, const ContractParams& p, int nwg, hipStream_t st) {
+  return launch_contract_pw_impl<2>(kind, p, nwg, st);
+}
+#endif
 int launch_presample_batch_x3(const PresampleBatch& b, hipStream_t st) {
   hipLaunchKernelGGL((presample_batch_kernel<2>), dim3(b.total_blocks), dim3(256), 0, st, b);
   return (int)hipGetLastError();

@@ -576,9 +576,18 @@ class _VariationalLSTM(BaseVariationalLayer_):
         else:
             h_t, c_t = hidden_states
         hidden, cells, kl = [], [], 0
+        # GPU: the KL terms do not depend on the time step (RNG-free functions of the parameters): one reduction launch per
+        # Linear layer per sequence instead of two per step; the per-step accumulation below keeps the reference's
+        # summation order (rnn_flipout.py:125-133).  CPU: the reference's own chain, KL inside every Linear forward.
+        once = X.is_cuda and self.ih._use_hip(X)
+        if once:
+            kl_i, kl_h = self.ih.kl_loss(), self.hh.kl_loss()
         for t in range(steps):
-            gi, kl_i = self.ih(X[:, t, :])
-            gh, kl_h = self.hh(h_t)
+            if once:
+                gi, gh = self.ih(X[:, t, :], return_kl=False), self.hh(h_t, return_kl=False)
+            else:
+                gi, kl_i = self.ih(X[:, t, :])
+                gh, kl_h = self.hh(h_t)
             gates = gi + gh
             kl = kl + kl_i + kl_h
             i_t, f_t = torch.sigmoid(gates[:, :hs]), torch.sigmoid(gates[:, hs:2 * hs])

@@ -110,6 +110,17 @@ FUSED_CASES = [
     ("Conv2dFlipout", dict(in_channels=32, out_channels=64, kernel_size=3, stride=2, padding=1), (2, 32, 51, 37)),
     ("Conv2dReparameterization", dict(in_channels=64, out_channels=64, kernel_size=3, stride=2, padding=1, groups=2), (5, 64, 13, 18)),
     ("Conv2dFlipout", dict(in_channels=32, out_channels=32, kernel_size=3, stride=2, padding=1), (1, 32, 2, 2)),
+    # pointwise Flipout-GEMM (btx_contract_pw.h: 1x1 / stride 1 / no padding and Linear with N % 64 == 0): resident and
+    # streamed activation stages, several n-tiles per workgroup, n-tile chunks, ragged pixel tiles, bias, groups
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=256, kernel_size=1, bias=False), (3, 64, 19, 17)),
+    ("Conv2dFlipout", dict(in_channels=256, out_channels=64, kernel_size=1), (2, 256, 14, 14)),
+    ("Conv2dFlipout", dict(in_channels=128, out_channels=512, kernel_size=1, bias=False), (2, 128, 28, 28)),
+    ("Conv2dFlipout", dict(in_channels=1024, out_channels=256, kernel_size=1, bias=False), (1, 1024, 14, 14)),
+    ("Conv2dReparameterization", dict(in_channels=96, out_channels=128, kernel_size=1), (2, 96, 9, 31)),
+    ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=1, groups=2), (2, 64, 16, 16)),
+    ("LinearFlipout", dict(in_features=512, out_features=512), (256, 512)),
+    ("LinearReparameterization", dict(in_features=32, out_features=64, bias=False), (300, 32)),
+    ("Conv3dFlipout", dict(in_channels=32, out_channels=64, kernel_size=1), (1, 32, 3, 9, 10)),
     # element-wise (GEN) kernels with in-kernel noise: odd channel counts
     ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 32, 32)),
     ("LinearFlipout", dict(in_features=50, out_features=10), (7, 50)),
