@@ -638,6 +638,9 @@ static double tall_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, Pat
   }
   return best;
 }
+#ifndef BTX_WG_MB_DEFAULT
+#define BTX_WG_MB_DEFAULT 3.0
+#endif
 #ifndef BTX_TALL_MIN_DEFAULT
 #define BTX_TALL_MIN_DEFAULT 1.15
 #endif
@@ -1153,10 +1156,13 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     // activations of a pixel tile (read by its ntiles*ksplits workgroups) or the sampled weights of an (n-tile, k-split)
     // (read by its mtiles workgroups).  ResNet18 layer4 (7x7 maps, 512 channels): 9.4 MB of weight tiles against 3.2 MB
     // of activations; measured HBM-side traffic of that launch in round 1 order: 92 MB for 25 MB algorithmic.
-    // Weight tiles up to ~2 MB stay resident in every XCD's 4-MB L2 whatever the order; beyond that the weight-major
-    // order is what keeps them on chip.
+    // Weight tiles up to ~3 MB stay resident in every XCD's 4-MB L2 whatever the order; beyond that the weight-major
+    // order is what keeps them on chip.  (Round 4, 20 MC sample lanes per launch, rocprofv3 FETCH/WRITE_SIZE: ResNet18
+    // layer3 — 2.36 MB of tiles per lane, 6.4 MB of activations — moves 2.98x its algorithmic bytes weight-major, where the
+    // activations are re-fetched once per n-tile, and 2.00x pixel-major; the launch time is the same either way.)
     const double w_b = (prec == BTX_PREC_BF16 ? 2.0 : 4.0) * (double)g->N * pl.K * (kind == BTX_KIND_FLIPOUT ? 2 : 1);
-    p.wg_order = (dma && pl.mtiles > 1 && w_b >= 2.0 * 1048576.0) ? 1 : 0;
+    const char* wmb = tune_env("BTX_WG_MB");  // A/B: the weight-tile size (MiB) from which the order turns weight-major
+    p.wg_order = (dma && pl.mtiles > 1 && w_b >= (wmb ? atof(wmb) : BTX_WG_MB_DEFAULT) * 1048576.0) ? 1 : 0;
     if (tune_env("BTX_WG_ORDER")) p.wg_order = atoi(tune_env("BTX_WG_ORDER"));
   }
   p.fd_Wo = make_fastdiv((uint32_t)pl.Wo); p.fd_Ho = make_fastdiv((uint32_t)pl.Ho); p.fd_Do = make_fastdiv((uint32_t)pl.Do);

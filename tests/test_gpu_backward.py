@@ -296,3 +296,58 @@ def test_rho_grad_kernel_matches_the_elementwise_formula():
     inplace = dw.clone()
     BF.rho_grad_hip(inplace, rho, 1234, 7, 5, _lib.STREAM_EPS_W, out=inplace)
     assert torch.equal(inplace, got)
+
+
+# BASELINE cfg4 (ResNet18, batch 64): the distinct variational layer shapes (cin, cout, hw, stride, k)
+RN18_SHAPES = [(3, 64, 224, 2, 7), (64, 64, 56, 1, 3), (64, 128, 56, 2, 3), (64, 128, 56, 2, 1), (128, 128, 28, 1, 3),
+               (128, 256, 28, 2, 3), (128, 256, 28, 2, 1), (256, 256, 14, 1, 3), (256, 512, 14, 2, 3), (256, 512, 14, 2, 1),
+               (512, 512, 7, 1, 3)]
+
+
+@pytest.mark.parametrize("prec,act,bar", [("f32", torch.float32, 1e-4), ("bf16", torch.bfloat16, 2e-2)])
+def test_backward_at_baseline_size_every_resnet18_layer_shape(prec, act, bar):
+    """per-layer gradients AT SIZE (cfg4 shapes, batch 64) — dx, dmu, drho of the HIP training path against
+    torch autograd through the reference op chain (oracle/bt_ref.py) evaluated by torch on the GPU in f32 with the noise BTX-RNG
+    defines.  f32 parity mode: <= 1e-4 (north_star's bar).  bf16 activations: the data gradient runs on the bf16 MFMA (bf16
+    operands, f32 accumulation, rounded to bf16 on store: bar 2e-2, measured ~3e-3), the weight gradients on bf16 x bf16
+    products with f32 accumulation over 200k..800k pixels against the f32 chain on the same bf16-valued inputs."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    from bayesian_torch_amd import functional as BF
+    from oracle import bt_ref
+    dev = _dev()
+    bt.manual_seed(77)
+    bt.set_precision(prec)
+    worst = {}
+    try:
+        for (cin, cout, hw, stride, k) in RN18_SHAPES:
+            torch.manual_seed(cin + cout + hw)
+            layer = L.Conv2dFlipout(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(dev)
+            x = torch.randn(64, cin, hw, hw, device=dev).to(act).requires_grad_(cin != 3)
+            bt.set_sample_index(layer, 4)
+            out = layer(x, return_kl=False)
+            gy = (torch.randn(out.shape, device=dev) / 64.0).to(act)
+            (out.float() * gy.float()).sum().backward()
+            mu, rho = layer._w()
+            got = dict(mu=mu.grad.float().clone(), rho=rho.grad.float().clone())
+            if cin != 3:
+                got["x"] = x.grad.float().clone()
+            with torch.no_grad():
+                nz = layer.materialize_noise(4, tuple(x.shape), tuple(out.shape), x.dtype)
+            xr = x.detach().float().clone().requires_grad_(cin != 3)
+            mur = BF.plain_layout(mu.detach()).requires_grad_(True)
+            rhor = BF.plain_layout(rho.detach()).requires_grad_(True)
+            ref = bt_ref.flipout_forward(xr, mur, rhor, None, None, nz["eps_w"], None, nz["sign_in"].float().reshape(x.shape),
+                                         nz["sign_out"].float().reshape(out.shape), _op_of(layer))
+            (ref * gy.float()).sum().backward()
+            want = dict(mu=mur.grad, rho=rhor.grad)
+            if cin != 3:
+                want["x"] = xr.grad
+            for kk in want:
+                err = _rel(got[kk], want[kk])
+                worst[kk] = max(worst.get(kk, 0.0), err)
+                assert err < bar, ((cin, cout, hw, stride, k), prec, kk, err)
+            del layer, x, out, gy, xr, ref
+        print("backward at size (%s): worst rel-L2 %s" % (prec, {k_: "%.3g" % v for k_, v in worst.items()}))
+    finally:
+        bt.set_precision("f32")

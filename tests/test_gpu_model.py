@@ -595,7 +595,9 @@ def test_lstm_wrappers_on_the_hip_linear_kernels():
         layer = getattr(L, cls)(24, 16).to(dev)
         x = torch.randn(5, 7, 24, device=dev)
         calls = []
-        hooks = [m.register_forward_hook(lambda mod, inp, out: calls.append((mod, inp[0].detach(), out[0].detach())))
+        # (on the GPU the LSTM asks its Linear layers for the output only: the KL terms are evaluated once per sequence)
+        hooks = [m.register_forward_hook(lambda mod, inp, out: calls.append(
+                     (mod, inp[0].detach(), (out[0] if isinstance(out, tuple) else out).detach())))
                  for m in (layer.ih, layer.hh)]
         with torch.no_grad():
             hs, (hs2, cs), kl = layer(x)

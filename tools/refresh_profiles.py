@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
-"""One command per file under profiles/ (round 3 on).  Run the collecting steps on a GPU box, e.g.
+"""One command per file under profiles/ (round 3 on; the files of the current round carry PREFIX).  Run the collecting steps on a GPU box, e.g.
 
     gpurun --timeout 2400 -- 'python tools/refresh_profiles.py bench trace pmc'     # writes gpurun_out/profiles/*
     python tools/refresh_profiles.py install                                        # here: gpurun_out/profiles/* -> profiles/
 
 steps (each writes the files named in its docstring, with the command that produced them in the header):
-  bench       profiles/r03_bench_line.json (+ _summary.txt)            python bench.py (the driver's default invocation)
-  trace       profiles/r03_bench_kernel_trace_stats.txt, _lanes1.txt   rocprofv3 --kernel-trace of the bench command
-  pmc         profiles/r03_pmc_taps_lanes.txt                          SQ counters of contract_taps_kernel, many-tiles regime
-  phase       profiles/r03_phase_timers.txt, r03_phase_timers_sustained.txt   block phase timers (trace build)
-  ablation    profiles/r03_kloop_ablation.txt                          what the K loop pays for (ablation builds)
-  ubench      profiles/r03_mfma_mix_ubench.txt                         tools/ubench/mfma_mix.hip
-  persistent  profiles/r03_persistent_kbench.txt                       persistent kernel A/B (tuning build)
-  tall        profiles/r03_tall_tiles_ab.txt                           tall-strip tiles A/B
-  power       profiles/r03_power_probe.txt                             socket power / clock under sustained launches
+  bench       profiles/<PREFIX>_bench_line.json (+ _summary.txt)            python bench.py (the driver's default invocation)
+  trace       profiles/<PREFIX>_bench_kernel_trace_stats.txt, _lanes1.txt   rocprofv3 --kernel-trace of the bench command
+  pmc         profiles/<PREFIX>_pmc_taps_lanes.txt                          SQ counters of contract_taps_kernel, many-tiles regime
+  phase       profiles/<PREFIX>_phase_timers.txt, r03_phase_timers_sustained.txt   block phase timers (trace build)
+  ablation    profiles/<PREFIX>_kloop_ablation.txt                          what the K loop pays for (ablation builds)
+  ubench      profiles/<PREFIX>_mfma_mix_ubench.txt                         tools/ubench/mfma_mix.hip
+  persistent  profiles/<PREFIX>_persistent_kbench.txt                       persistent kernel A/B (tuning build)
+  tall        profiles/<PREFIX>_tall_tiles_ab.txt                           tall-strip tiles A/B
+  power       profiles/<PREFIX>_power_probe.txt                             socket power / clock under sustained launches
 The measurement builds (build_variants/libbtx_{tune,trace,abl*}.so) are made by tools/build_variants.sh when missing.
 """
 import glob
@@ -26,6 +26,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
 ENV = dict(os.environ, TMPDIR="/tmp")
+PREFIX = "r04"  # file-name prefix of the round being measured
 SHAPES = ["64,64,56,1,3", "128,128,28,1,3", "256,256,14,1,3", "512,512,7,1,3"]
 
 
@@ -48,11 +49,11 @@ def variant(name, flags):
 
 
 def step_bench():
-    out = sh("python bench.py", timeout=2400)
+    out = sh("python bench.py --steps 20 --warmup 5", timeout=2400)  # the driver's invocation
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     os.makedirs(OUT, exist_ok=True)
-    json.dump(d, open(os.path.join(OUT, "r03_bench_line.json"), "w"), indent=1)
+    json.dump(d, open(os.path.join(OUT, PREFIX + "_bench_line.json"), "w"), indent=1)
     r = d["roofline"]
     body = "value %.1f %s  ms/step %.4f  regions %s\n" % (d["value"], d["unit"], d["ms_per_step"], ["%.3f" % v for v in d["ms_per_step_runs"]])
     body += "roofline.frac %.4f (contraction only %.4f)  e2e %.4f  sampling %.1f us per %d-lane launch\n" % (
@@ -64,21 +65,23 @@ def step_bench():
     for k, v in d.get("extra", {}).items():
         body += "%s: %s\n" % (k, json.dumps(v)[:600])
     body += "cpu_baseline: %s\n" % json.dumps(d.get("cpu_baseline"))[:400]
-    write("r03_bench_summary.txt", "python bench.py   (1 MI355X; the JSON line is profiles/r03_bench_line.json)", body)
+    write(PREFIX + "_bench_summary.txt", "python bench.py --steps 20 --warmup 5   (the driver's invocation; 1 MI355X; the JSON line is profiles/" + PREFIX + "_bench_line.json)", body)
 
 
 def step_trace():
+    # --steps / --warmup are multiples of the lane count (20 = the driver's --steps 20): every contract_taps_kernel launch of
+    # the traced run carries the same number of MC sample lanes, so the trace's average IS the bench's avg_launch_us
     for tag, extra in (("stats", ""), ("lanes1", " --lanes 1")):
-        d = os.path.join(ROOT, "gpurun_out", "r3_kt_" + tag)
+        d = os.path.join(ROOT, "gpurun_out", "r4_kt_" + tag)
         shutil.rmtree(d, ignore_errors=True)
-        cmd = "python %s/bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline --no-traffic%s" % (ROOT, extra)
+        cmd = "python %s/bench.py --steps 20 --warmup 20 --no-extras --no-cpu-baseline --no-traffic%s" % (ROOT, extra)
         sh("rocprofv3 --kernel-trace --stats -d %s -o kt -- %s" % (d, cmd), cwd="/tmp", timeout=1200)
         db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
         body = sh("python tools/trace_report.py %s" % db[0]) if db else "(no trace written)\n"
-        write("r03_bench_kernel_trace_%s.txt" % tag,
+        write(PREFIX + "_bench_kernel_trace_%s.txt" % tag,
               "cd /tmp && rocprofv3 --kernel-trace --stats -- %s   (1 MI355X; tools/trace_report.py on the result)\n"
               "%s" % (cmd.replace(ROOT + "/", ""), "lanes 1: one MC sample per launch — the dominant kernel's average here is a single-sample launch"
-                      if extra else "the bench's default: 8 MC samples per launch (lanes), per-launch replays included"), body)
+                      if extra else "the bench's default for --steps 20: 20 MC samples per launch (lanes), the per-launch timing replays included"), body)
 
 
 def derived(rep):
@@ -103,15 +106,15 @@ def step_pmc():
     body = ""
     for shp in SHAPES[:2]:
         for i, s in enumerate(sets):
-            d = os.path.join(ROOT, "gpurun_out", "r3_pmc%d_%s" % (i, shp.replace(",", "_")))
+            d = os.path.join(ROOT, "gpurun_out", "r4_pmc%d_%s" % (i, shp.replace(",", "_")))
             shutil.rmtree(d, ignore_errors=True)
             sh("rocprofv3 --pmc %s --kernel-trace -d %s -o pmc -- python %s/tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 "
-               "--bs 256 --shape %s" % (s, d, ROOT, shp), cwd="/tmp", timeout=400)
-        rep = sh("python tools/pmc_report.py 'gpurun_out/r3_pmc*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
+               "--bs 1280 --shape %s" % (s, d, ROOT, shp), cwd="/tmp", timeout=400)
+        rep = sh("python tools/pmc_report.py 'gpurun_out/r4_pmc*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
         body += "== %s\n" % shp + derived(rep) + rep
-    write("r03_pmc_taps_lanes.txt",
-          "rocprofv3 --pmc <set> --kernel-trace -- python tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 --bs 256 --shape <s>\n"
-          "(one pass per counter set; batch 256 = the tiles of 4 MC sample lanes; contract_taps_kernel; tools/pmc_report.py)", body)
+    write(PREFIX + "_pmc_taps_lanes.txt",
+          "rocprofv3 --pmc <set> --kernel-trace -- python tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 --bs 1280 --shape <s>\n"
+          "(one pass per counter set; batch 1280 = the tiles of the bench's 20 MC sample lanes; contract_taps_kernel; tools/pmc_report.py)", body)
 
 
 def step_phase():
@@ -122,7 +125,7 @@ def step_phase():
             body += "== %s %s\n" % (shp, v) + "".join(
                 l + "\n" for l in sh("env %s python tools/gpu_diag.py trace --prec bf16 --shape %s" % (v, shp), env={"BTX_LIB": lib}).splitlines()
                 if " wave " not in l and "column 7" not in l)
-    write("r03_phase_timers.txt", "BTX_LIB=build_variants/libbtx_trace.so python tools/gpu_diag.py trace --prec bf16 --shape <s>  (batch 64, one launch;\n"
+    write(PREFIX + "_phase_timers.txt", "BTX_LIB=build_variants/libbtx_trace.so python tools/gpu_diag.py trace --prec bf16 --shape <s>  (batch 64, one launch;\n"
           "X=0: tall-strip tiles where the plan takes them, BTX_NO_TALL=1: plain tiles, BTX_TAPS_TUNE=128: prologue sub-stamps)", body)
     body = ""
     for shp in SHAPES[:2]:
@@ -130,7 +133,7 @@ def step_phase():
             body += "== %s %s (600 warm launches)\n" % (shp, v) + "".join(
                 l + "\n" for l in sh("env %s BTX_NO_TALL=1 python tools/gpu_diag.py trace --throughput-plan --bs 256 --warm 600 --prec bf16 --shape %s" % (v, shp),
                                      env={"BTX_LIB": lib}).splitlines() if " wave " not in l and "column 7" not in l)
-    write("r03_phase_timers_sustained.txt", "BTX_LIB=build_variants/libbtx_trace.so [BTX_PERSIST=1] BTX_NO_TALL=1 python tools/gpu_diag.py trace --throughput-plan --bs 256\n"
+    write(PREFIX + "_phase_timers_sustained.txt", "BTX_LIB=build_variants/libbtx_trace.so [BTX_PERSIST=1] BTX_NO_TALL=1 python tools/gpu_diag.py trace --throughput-plan --bs 256\n"
           "--warm 600 --prec bf16 --shape <s>: block phase timers and the shader clock (s_memtime / s_memrealtime) under sustained load,\n"
           "persistent kernel (contract_taps3_kernel) against contract_taps_kernel.  Reading: per tile the persistent kernel needs fewer\n"
           "cycles (56x56: (K loops + store sides) / 7 tiles ~ 29k against ~35k for a one-tile block) but runs at a lower clock under the\n"
@@ -147,7 +150,7 @@ def step_ablation():
     for name, flags in (("tune", "-DBTX_TUNING"), ("abl4", "-DBTX_TUNING -DBTX_PT_ABL=4"), ("abl16", "-DBTX_TUNING -DBTX_PT_ABL=16"),
                         ("abl2", "-DBTX_TUNING -DBTX_PT_ABL=2"), ("abl22", "-DBTX_TUNING -DBTX_PT_ABL=22")):
         body += "## %s\n" % name + kbench(variant(name, flags), ["-"], [SHAPES[0], SHAPES[1], SHAPES[3]], env={"BTX_NO_TALL": "1"})
-    write("r03_kloop_ablation.txt", "BTX_NO_TALL=1 BTX_LIB=build_variants/libbtx_<v>.so python tools/kbench.py --throughput-plan --env - --bs 256 ...\n"
+    write(PREFIX + "_kloop_ablation.txt", "BTX_NO_TALL=1 BTX_LIB=build_variants/libbtx_<v>.so python tools/kbench.py --throughput-plan --env - --bs 256 ...\n"
           "builds with -DBTX_PT_ABL=<bits>: 4 no weight/patch DMA in the K loop, 16 no s_in masks, 2 no LDS fragment reads, 22 all three\n"
           "(results wrong by construction; time only).  Reading (128->128, 28x28): no DMA -19 %, no masks -7 %, no fragment reads -27 %,\n"
           "none of the three: the floor set by MFMA issue, barriers, prologue and store side (118 GFLOP at ~2.1 GHz = 54 us of matrix time)", body)
@@ -155,7 +158,7 @@ def step_ablation():
 
 def step_ubench():
     sh("/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip", timeout=900)
-    write("r03_mfma_mix_ubench.txt", "hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip && tools/ubench/mfma_mix\n"
+    write(PREFIX + "_mfma_mix_ubench.txt", "hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_mix tools/ubench/mfma_mix.hip && tools/ubench/mfma_mix\n"
           "The instruction mix of one K-stage of the Flipout tap kernel (LDS fragment reads, s_in masks, mean + delta MFMAs, a barrier; NO\n"
           "global traffic) per register-tile shape, 12 x 50 ms launches per line, two rounds; TFLOP/s from HIP events (the cycles/stage\n"
           "column is block 0's s_memtime delta: only meaningful for the 1-block/CU lines).\n"
@@ -171,7 +174,7 @@ def step_ubench():
 
 def step_persistent():
     lib = variant("tune", "-DBTX_TUNING")
-    write("r03_persistent_kbench.txt", "BTX_NO_TALL=1 BTX_LIB=build_variants/libbtx_tune.so python tools/kbench.py --throughput-plan --env BTX_PERSIST=1 - --bs 256 ...\n"
+    write(PREFIX + "_persistent_kbench.txt", "BTX_NO_TALL=1 BTX_LIB=build_variants/libbtx_tune.so python tools/kbench.py --throughput-plan --env BTX_PERSIST=1 - --bs 256 ...\n"
           "(contract_taps3_kernel against contract_taps_kernel; '== variant0: True' = bit-identical results)",
           sh("python tools/kbench.py --throughput-plan --env BTX_PERSIST=1 - --bs 256 --rounds 3 --reps 10 --shapes %s" % " ".join(SHAPES),
              env={"BTX_LIB": lib, "BTX_NO_TALL": "1"}, timeout=900))
@@ -182,12 +185,12 @@ def step_tall():
     body = ""
     for bs in (64, 256, 512):
         body += "## batch %d\n" % bs + kbench(lib, ["-", "BTX_NO_TALL=1"], SHAPES, bs=bs)
-    write("r03_tall_tiles_ab.txt", "BTX_LIB=build_variants/libbtx_tune.so python tools/kbench.py --throughput-plan --env - BTX_NO_TALL=1 --bs <b> ...\n"
+    write(PREFIX + "_tall_tiles_ab.txt", "BTX_LIB=build_variants/libbtx_tune.so python tools/kbench.py --throughput-plan --env - BTX_NO_TALL=1 --bs <b> ...\n"
           "(tall-strip tiles where the plan takes them against plain tiles)", body)
 
 
 def step_power():
-    """profiles/r03_power_probe.txt: socket power and sclk (rocm-smi, every ~0.3 s) while 60 000 back-to-back launches of one
+    """profiles/<PREFIX>_power_probe.txt: socket power and sclk (rocm-smi, every ~0.3 s) while 60 000 back-to-back launches of one
     layer run — contract_taps_kernel against the persistent kernel; needs the tuning build"""
     import threading
     import time
@@ -220,7 +223,7 @@ def step_power():
                     len(busy), sum(w for w, _ in busy) / len(busy), max(w for w, _ in busy), sum(c for _, c in busy) / len(busy))
             else:
                 body += "   (no busy samples)\n"
-    write("r03_power_probe.txt", "BTX_LIB=build_variants/libbtx_tune.so BTX_NO_TALL=1 [BTX_PERSIST=1] python tools/gpu_diag.py timeone --throughput-plan\n"
+    write(PREFIX + "_power_probe.txt", "BTX_LIB=build_variants/libbtx_tune.so BTX_NO_TALL=1 [BTX_PERSIST=1] python tools/gpu_diag.py timeone --throughput-plan\n"
           "--prec bf16 --bs 256 --iters 60000 --shape <s>, with `rocm-smi --showpower --showclocks` polled meanwhile (1 MI355X).\n"
           "Reading: both kernels run at 92-99 % of the 1400 W package limit with the clock throttled to 1.86-2.03 GHz (peak 2.4 GHz;\n"
           "boxes of the pool differ by a few percent): the operating point is set by power, and a kernel that keeps the matrix pipe\n"
