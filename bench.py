@@ -550,13 +550,16 @@ def run_mlp_config(dev, steps=8):
     with torch.no_grad():
         for s in range(4):
             g.run(1000 + s)
-        g.packed.zero_()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for s in range(steps):
-            g.run(s)
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
+        els = []
+        for _ in range(5):  # the region is ~0.8 ms: five of them, the median (one host hiccup is 40x the region)
+            g.packed.zero_()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for s in range(steps):
+                g.run(s)
+            torch.cuda.synchronize(dev)
+            els.append(time.perf_counter() - t0)
+        el = sorted(els)[len(els) // 2]
         g.close()
         # parity figure: bf16 logits vs the f32 parity mode, same sample index
         bt.set_sample_index(net, 3)

@@ -82,6 +82,7 @@ def step_trace():
               "cd /tmp && rocprofv3 --kernel-trace --stats -- %s   (1 MI355X; tools/trace_report.py on the result)\n"
               "%s" % (cmd.replace(ROOT + "/", ""), "lanes 1: one MC sample per launch — the dominant kernel's average here is a single-sample launch"
                       if extra else "the bench's default for --steps 20: 20 MC samples per launch (lanes), the per-launch timing replays included"), body)
+        shutil.rmtree(d, ignore_errors=True)  # the raw trace (tens of MB) stays on the box: gpurun merges at most 64 MiB back
 
 
 def derived(rep):
@@ -112,6 +113,8 @@ def step_pmc():
                "--bs 1280 --shape %s" % (s, d, ROOT, shp), cwd="/tmp", timeout=400)
         rep = sh("python tools/pmc_report.py 'gpurun_out/r4_pmc*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
         body += "== %s\n" % shp + derived(rep) + rep
+        for d in glob.glob(os.path.join(ROOT, "gpurun_out", "r4_pmc*_%s" % shp.replace(",", "_"))):
+            shutil.rmtree(d, ignore_errors=True)
     write(PREFIX + "_pmc_taps_lanes.txt",
           "rocprofv3 --pmc <set> --kernel-trace -- python tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 --bs 1280 --shape <s>\n"
           "(one pass per counter set; batch 1280 = the tiles of the bench's 20 MC sample lanes; contract_taps_kernel; tools/pmc_report.py)", body)
