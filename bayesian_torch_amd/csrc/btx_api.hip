@@ -850,7 +850,7 @@ static bool make_stem_plan(const BtxGeom* g, int act_dtype, int prec, const Plan
 struct StemPoolPlan {
   int PB, bands, Rp, astage, sbytes, lds, patch_bytes, nwg, Hq, Wq;
 };
-static bool make_stem_pool_plan(const BtxGeom* g, int act_dtype, int prec, const Plan& pl, StemPoolPlan* sp) {
+static bool make_stem_pool_plan(const BtxGeom* g, int act_dtype, int prec, const Plan& pl, StemPoolPlan* sp, int lanes = 1) {
   if (prec != BTX_PREC_BF16 || act_dtype != BTX_ACT_BF16) return false;
   if (g->D != 1 || g->KD != 1 || pl.Do != 1 || g->groups != 1) return false;
   const int bk = NG * 8;
@@ -868,9 +868,12 @@ static bool make_stem_pool_plan(const BtxGeom* g, int act_dtype, int prec, const
   // weights | raw patch x2 | signed patch copy | sign words x2 | store-side rows r0, r1, carry (128 B per pixel) | constants
   const long long lds = (long long)nstages * 8192 + 3 * astage + 2 * sb16 + 3LL * pl.Wo * 128 + 1024;
   if (lds > 163840) return false;
-  // bands: about one workgroup per CU (every band pays two phases of fill / drain and a closing one-row half tile)
+  // bands: about one workgroup per CU (every band pays two phases of fill / drain, a closing one-row half tile and the
+  // fetch of the layer's weight tiles).  With MC sample lanes the launch has `lanes` times the (image, n-tile) units, so the
+  // bands get longer — 20 lanes of a ResNet stem at batch 64: one band per image instead of four.  Which workgroup computes a
+  // row does not change how it is computed: results are bit-identical whatever the band length.
   const long long units = (long long)g->NB * pl.ntiles;
-  long long PB = ((long long)Hq * units) / 256;
+  long long PB = ((long long)Hq * units * (lanes > 1 ? lanes : 1)) / 256;
   if (PB < 4) PB = 4;
   if (PB > Hq) PB = Hq;
   const int bands = (Hq + (int)PB - 1) / (int)PB;
@@ -1028,7 +1031,7 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     Plan sp;
     if (ep->pool != 1 || !stem || ep->residual || (noise && (noise->sign_in || noise->sign_out)) ||
         (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_SWAP_SIGNS)) || make_plan(g, prec, flags, DBM, &sp) ||
-        !make_stem_pool_plan(g, act_dtype, prec, sp, &spp))
+        !make_stem_pool_plan(g, act_dtype, prec, sp, &spp, tune_env("BTX_STEM_SHORT_BANDS") ? 1 : lanes))
       return BTX_E_UNSUPPORTED;
     pl.nwg = spp.nwg;
   }
