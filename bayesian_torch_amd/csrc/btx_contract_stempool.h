@@ -43,6 +43,9 @@
 
 namespace btx {
 
+#ifndef BTX_STEM_STEPS
+#define BTX_STEM_STEPS 1  // step layout of a Flipout K phase (run_k): 0 = round 2's (sign copy + mean) | delta 0-3 | delta 4-6,
+#endif                    // 1 = sign copy | mean | delta
 constexpr int SP_HROWS = 2;  // conv rows per half tile
 constexpr int SP_LROWS = 3;  // LDS rows (64 channels each) of the store side: r0, r1 and the carry row
 constexpr int SP_MAXST = 7;  // K-stages whose weight tiles stay resident
@@ -297,9 +300,23 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     const unsigned char* raw = smem + A_OFF + (u & 1) * p.pt_astage;
     int nb;
     if constexpr (KIND == 1) {
+#if BTX_STEM_STEPS == 0
       run_pass(raw, 0, accm, -1, -1, mia_tag);
       SP_BARRIER();  // the signed copy is complete (build_signed ran before this pass)
       nb = 1 + run_pass(smem + X_OFF, 4096, accd, (nstages + 1) >> 1, -1, mia_tag);
+#else
+      // steps of the phase: sign copy | mean pass | delta pass, against the store group's stage 0-31 | stage 32-63 | pool.
+      // Phase timers (profiles/r02_stem_pool.txt, per wave and step): sign copy 2.35k cycles, each pass 2.6k; store steps 1.9k,
+      // 1.9k, 2.5k.  With the mean pass in the first step (round 2) the phase cost max(4.95, 1.9) + max(1.5, 1.9) + max(1.1,
+      // 2.5) = 9.35k; one K step per store step: 2.35 + 2.6 + 2.6 = 7.55k.  Measured at 20 lanes: 1300 -> 1200 us per launch.
+      // (Also measured, not kept: the sign copy sliced into the shadow of the mean pass's MFMAs with the delta pass in two
+      // steps: 1350 us; the copy's LDS reads four chunks deep instead of one at a time: no change.)
+      SP_BARRIER();  // the signed copy is complete (build_signed ran before this call)
+      run_pass(raw, 0, accm, -1, -1, mia_tag);
+      SP_BARRIER();
+      run_pass(smem + X_OFF, 4096, accd, -1, -1, mia_tag);
+      nb = 2;
+#endif
     } else {
       const int t3 = (nstages + 2) / 3;
       nb = run_pass(raw, 0, accm, t3, 2 * t3, mia_tag);
