@@ -147,15 +147,25 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_stem_kernel(const Contrac
       l_e += BK;
       if (++l_j == spr) { l_j = 0; l_rowE += RowE; l_e = l_rowE; }
     };
+    // split-bf16 (PREC == 2): a stage reads its own fragments — with the next stage's prefetched beside the hi / lo halves of
+    // this one's the Flipout kernel spilt 5 VGPRs inside the loop, and a scratch reload's vmcnt(0) drains the weight ring
+    constexpr bool PF = (PREC != 2);
     StageFrag fa, fb;
-    load_frag(fa, 0, 0);
-    advance_load();
+    if constexpr (PF) {
+      load_frag(fa, 0, 0);
+      advance_load();
+    }
     auto iter = [&](int s, StageFrag& cur, StageFrag& nxt) __attribute__((always_inline)) {
       int m2 = nissued;
       if (s + WD - 1 < nstages) { issue_w(s + WD - 1); nissued += w_nops; m2 = nissued; }
       DeltaFrag dfrag;  // this stage's delta weights first, then the prefetch of the next stage's fragments
       load_delta<KIND>(dfrag, smem + W_OFF + (s & (WD - 1)) * DW_STAGE, l31, h);
-      if (s + 1 < nstages) { load_frag(nxt, l_e, (s + 1) & (WD - 1)); advance_load(); }
+      if constexpr (PF) {
+        if (s + 1 < nstages) { load_frag(nxt, l_e, (s + 1) & (WD - 1)); advance_load(); }
+      } else {
+        load_frag(cur, l_e, s & (WD - 1));
+        advance_load();
+      }
       stage_mma<PREC, KIND>(cur, dfrag, accm, accd, l31, h);
       wait_vmcnt(nissued - m1);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
