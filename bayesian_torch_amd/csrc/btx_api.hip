@@ -638,6 +638,9 @@ static double tall_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, Pat
   }
   return best;
 }
+#ifndef BTX_GEMM8_MINK_DEFAULT
+#define BTX_GEMM8_MINK_DEFAULT 128
+#endif
 #ifndef BTX_WG_MB_DEFAULT
 #define BTX_WG_MB_DEFAULT 3.0
 #endif
@@ -1049,6 +1052,26 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     if (!dma) return BTX_E_UNSUPPORTED;
     out_bf16 = (flags & BTX_FLAG_OUT_BF16) ? 1 : 0;
   }
+  // Pointwise Flipout contractions with a long K on the 8-wave GEMM of btx_contract_gemm8.h: one workgroup per CU, a
+  // 256-pixel x 128-channel tile, rings of four (conditions in that header).
+  bool gemm8 = false;
+  int g8_pairs = 1;
+  {
+    const char* mk = tune_env("BTX_GEMM8_MINK");
+    const int min_k = mk ? atoi(mk) : BTX_GEMM8_MINK_DEFAULT;
+    if (dma && !rowfuse && !patch && kind == BTX_KIND_FLIPOUT && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 &&
+        !(flags & BTX_FLAG_TRANSPOSED) && g->KD == 1 && g->KH == 1 && g->KW == 1 && g->sd == 1 && g->sh == 1 && g->sw == 1 &&
+        g->pd == 0 && g->ph == 0 && g->pw == 0 && (pl.K % 32) == 0 && pl.K >= 128 && pl.K >= min_k && (pl.Ng % 128) == 0 &&
+        !tune_env("BTX_NO_GEMM8")) {
+      const long long mt = (pl.M + 255) / 256;
+      g8_pairs = pl.Ng / 128;
+      const long long nwg = mt * g->groups * g8_pairs;
+      if (nwg * lanes <= 0x7fffffffLL) {
+        gemm8 = true;
+        pl.mtiles = (int)mt; pl.ksplits = 1; pl.kper = pl.K; pl.nwg = (int)nwg;
+      }
+    }
+  }
   // MEASUREMENT ONLY (tuning builds, BTX_PW=1): pointwise contractions (Linear, 1x1x1 / stride 1 / no padding) on the
   // Flipout-GEMM of btx_contract_pw.h — one workgroup per pixel tile walks `pw_ntb` n-tiles, store side from the fragment
   // registers.  Bit-identical to the LDS-DMA kernel; measured (profiles/r04_pointwise_ab.txt): +4..7 % where the activation
@@ -1056,7 +1079,7 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   // store already overlaps prologue and store side across the two workgroups of a CU, and whole-line stores drain faster.
   bool pw = false;
   int pw_ntb = 1, pw_chunks = 1;
-  if (tune_env("BTX_PW") && dma && !rowfuse && !patch && dma_nw == 4 && !(flags & BTX_FLAG_TRANSPOSED) && g->KD == 1 && g->KH == 1 && g->KW == 1 &&
+  if (tune_env("BTX_PW") && !gemm8 && dma && !rowfuse && !patch && dma_nw == 4 && !(flags & BTX_FLAG_TRANSPOSED) && g->KD == 1 && g->KH == 1 && g->KW == 1 &&
       g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 0 && g->pw == 0 &&
       out_bf16 == (act_dtype == BTX_ACT_BF16 ? 1 : 0) && (pl.Ng % 64) == 0 && (g->N % 32) == 0 && !(noise && noise->sign_out) &&
       (long long)pl.M * g->N * (out_bf16 ? 2 : 4) < 0x7ff00000LL) {
@@ -1247,6 +1270,10 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     rc = (prec == BTX_PREC_BF16) ? launch_contract_patch_bf16(kind, p, pl.nwg * lanes, st)
          : (prec == BTX_PREC_BF16X3) ? launch_contract_patch_x3(kind, p, pl.nwg * lanes, st)
                                      : launch_contract_patch_f32(kind, p, pl.nwg * lanes, st);
+  } else if (dma && gemm8) {
+    p.pt_rtiles = g8_pairs;
+    p.fd_rtiles = make_fastdiv((uint32_t)g8_pairs); p.fd_inner = make_fastdiv((uint32_t)(g8_pairs * g->groups));
+    rc = launch_contract_gemm8_bf16(kind, p, pl.nwg * lanes, st);
 #if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
   } else if (dma && pw) {
     p.pt_R = pw_ntb; p.pt_rtiles = pw_chunks;

@@ -822,6 +822,7 @@ int launch_contract_patch_bf16(int kind, const ContractParams& p, int nwg, hipSt
 int launch_contract_patch_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_stem_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_dma_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_gemm8_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);  // btx_contract_gemm8.h
 // pointwise Flipout-GEMM with the n-tile loop inside the workgroup (btx_contract_pw.h)
 int launch_contract_pw_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_pw_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);

@@ -1,6 +1,7 @@
 // Instantiates the bf16-MFMA (throughput mode) variants of the fused contraction: v_mfma_f32_32x32x16_bf16.
 #include "btx_contract.h"
 #include "btx_contract_dma.h"
+#include "btx_contract_gemm8.h"
 #if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
 #include "btx_contract_pw.h"  // measured and parked: see btx_api.hip
 #endif
@@ -16,4 +17,7 @@ int launch_contract_pw_bf16(int kind, const ContractParams& p, int nwg, hipStrea
   return launch_contract_pw_impl<1>(kind, p, nwg, st);
 }
 #endif
+int launch_contract_gemm8_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st) {
+  return launch_contract_gemm8(kind, p, nwg, st);
+}
 }  // namespace btx

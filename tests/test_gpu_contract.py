@@ -121,6 +121,11 @@ FUSED_CASES = [
     ("LinearFlipout", dict(in_features=512, out_features=512), (256, 512)),
     ("LinearReparameterization", dict(in_features=32, out_features=64, bias=False), (300, 32)),
     ("Conv3dFlipout", dict(in_channels=32, out_channels=64, kernel_size=1), (1, 32, 3, 9, 10)),
+    # 8-wave pointwise GEMM (btx_contract_gemm8.h; bf16 activations + MFMA, K >= 128, N/groups % 128 == 0): ragged pixel tile,
+    # bias, groups, several n-tile pairs, odd stage counts
+    ("Conv2dFlipout", dict(in_channels=256, out_channels=256, kernel_size=1, groups=2), (3, 256, 11, 13)),
+    ("Conv2dFlipout", dict(in_channels=160, out_channels=384, kernel_size=1, bias=False), (2, 160, 17, 9)),
+    ("LinearFlipout", dict(in_features=2048, out_features=128), (70, 2048)),
     # element-wise (GEN) kernels with in-kernel noise: odd channel counts
     ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 32, 32)),
     ("LinearFlipout", dict(in_features=50, out_features=10), (7, 50)),
