@@ -1059,9 +1059,10 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   {
     const char* mk = tune_env("BTX_GEMM8_MINK");
     const int min_k = mk ? atoi(mk) : BTX_GEMM8_MINK_DEFAULT;
-    if (dma && !rowfuse && !patch && kind == BTX_KIND_FLIPOUT && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 &&
+    const int bk8 = NG * (prec == BTX_PREC_BF16 ? 8 : 4);  // (dma: the activation dtype is the contraction's)
+    if (dma && !rowfuse && !patch && kind == BTX_KIND_FLIPOUT &&
         !(flags & BTX_FLAG_TRANSPOSED) && g->KD == 1 && g->KH == 1 && g->KW == 1 && g->sd == 1 && g->sh == 1 && g->sw == 1 &&
-        g->pd == 0 && g->ph == 0 && g->pw == 0 && (pl.K % 32) == 0 && pl.K >= 128 && pl.K >= min_k && (pl.Ng % 128) == 0 &&
+        g->pd == 0 && g->ph == 0 && g->pw == 0 && (pl.K % bk8) == 0 && pl.K >= 4 * bk8 && pl.K >= min_k && (pl.Ng % 128) == 0 &&
         !tune_env("BTX_NO_GEMM8")) {
       const long long mt = (pl.M + 255) / 256;
       g8_pairs = pl.Ng / 128;
@@ -1273,7 +1274,9 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   } else if (dma && gemm8) {
     p.pt_rtiles = g8_pairs;
     p.fd_rtiles = make_fastdiv((uint32_t)g8_pairs); p.fd_inner = make_fastdiv((uint32_t)(g8_pairs * g->groups));
-    rc = launch_contract_gemm8_bf16(kind, p, pl.nwg * lanes, st);
+    rc = (prec == BTX_PREC_BF16) ? launch_contract_gemm8_bf16(kind, p, pl.nwg * lanes, st)
+         : (prec == BTX_PREC_BF16X3) ? launch_contract_gemm8_x3(kind, p, pl.nwg * lanes, st)
+                                     : launch_contract_gemm8_f32(kind, p, pl.nwg * lanes, st);
 #if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
   } else if (dma && pw) {
     p.pt_R = pw_ntb; p.pt_rtiles = pw_chunks;

@@ -823,6 +823,8 @@ int launch_contract_patch_x3(int kind, const ContractParams& p, int nwg, hipStre
 int launch_contract_stem_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_dma_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_gemm8_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);  // btx_contract_gemm8.h
+int launch_contract_gemm8_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
+int launch_contract_gemm8_x3(int kind, const ContractParams& p, int nwg, hipStream_t st);
 // pointwise Flipout-GEMM with the n-tile loop inside the workgroup (btx_contract_pw.h)
 int launch_contract_pw_f32(int kind, const ContractParams& p, int nwg, hipStream_t st);
 int launch_contract_pw_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st);

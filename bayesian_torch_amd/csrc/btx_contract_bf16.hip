@@ -18,6 +18,6 @@ int launch_contract_pw_bf16(int kind, const ContractParams& p, int nwg, hipStrea
 }
 #endif
 int launch_contract_gemm8_bf16(int kind, const ContractParams& p, int nwg, hipStream_t st) {
-  return launch_contract_gemm8(kind, p, nwg, st);
+  return launch_contract_gemm8_impl<1>(kind, p, nwg, st);
 }
 }  // namespace btx

@@ -1,6 +1,7 @@
 // Instantiates the f32-MFMA (parity mode) variants of the fused contraction: v_mfma_f32_32x32x2_f32.
 #include "btx_contract.h"
 #include "btx_contract_dma.h"
+#include "btx_contract_gemm8.h"
 #if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
 #include "btx_contract_pw.h"  // measured and parked: see btx_api.hip
 #endif
@@ -16,4 +17,7 @@ int launch_contract_pw_f32(int kind, const ContractParams& p, int nwg, hipStream
   return launch_contract_pw_impl<0>(kind, p, nwg, st);
 }
 #endif
+int launch_contract_gemm8_f32(int kind, const ContractParams& p, int nwg, hipStream_t st) {
+  return launch_contract_gemm8_impl<0>(kind, p, nwg, st);
+}
 }  // namespace btx

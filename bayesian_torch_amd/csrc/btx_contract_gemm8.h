@@ -1,7 +1,7 @@
 // btx_contract_gemm8.h — pointwise Flipout contractions with a long K (1x1x1 convolutions at stride 1 without padding and
 // Linear layers, K >= 256: the "reduce" and 3x3-neighbour 1x1 convolutions of a ResNet50 bottleneck, reference
 // models/deterministic/resnet_large.py:85-105, layers/flipout_layers/conv_flipout.py:376-417) as ONE 8-wave workgroup per CU
-// with the K loop of the tap-unrolled kernel (gfx950, bf16).
+// with the K loop of the tap-unrolled kernel (gfx950; bf16, and the f32 / split-bf16 precisions on f32 activations).
 //
 // contract_dma_kernel runs these GEMMs at 0.23-0.29 of the MFMA peak: its 256-pixel tile needs 16 KB of activations per
 // K-stage, rings of three is all that fits twice into a CU's LDS, so a stage reads its own fragments (LDS latency exposed every
@@ -28,10 +28,6 @@
 #include "btx_mma.h"
 #include "btx_presample.h"
 
-#ifndef BTX_G8_OFFSET
-#define BTX_G8_OFFSET 1  // waves 4-7 run half a stage behind waves 0-3 (0: all eight in lock-step; A/B)
-#endif
-
 namespace btx {
 
 struct G8Lds {
@@ -48,12 +44,18 @@ struct G8Lds {
 };
 static_assert(G8Lds::MAIN <= G8Lds::C_OFF && G8Lds::BYTES <= 163840, "LDS budget");
 
-template <int KIND>
+template <int PREC, int KIND>
 __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractParams) {
   static_assert(KIND == 1, "Flipout only: every wave issues the same number of weight DMAs per stage");
   BTX_SECTION_PARAMS(p, logical);
   using LD = G8Lds;
-  constexpr int G = 8, BK = NG * G, TP = LD::TP;
+  using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
+  constexpr int G = (PREC == 1) ? 8 : 4, BK = NG * G, TP = LD::TP;
+  constexpr uint32_t ESZ = (uint32_t)sizeof(ACT);
+  // bf16: the NEXT stage's fragments are read while this one multiplies (two fragment sets).  f32 / split-bf16: a stage reads
+  // its own fragments in its first part (the split's hi / lo halves take the registers of the second set) — their latency hides
+  // behind the other wave group's MFMAs either way
+  constexpr bool PF = (PREC == 1);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t smp = p.sample;
   if (p.sample_ptr) smp = *p.sample_ptr;
@@ -94,12 +96,12 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   for (int j = 0; j < 2; ++j) {
     const int piece = 2 * wave + j;
     const int mq = mtile * TP + piece * 16 + (lane >> 2);
-    a_src[j] = mq < p.M ? ((uint32_t)mq * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) * 2u : DMA_OOB;
+    a_src[j] = mq < p.M ? ((uint32_t)mq * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) * ESZ : DMA_OOB;
     a_dst[j] = LD::A_OFF + piece * 1024;
   }
   auto issue = [&](int s) __attribute__((always_inline)) {  // all L2 -> LDS traffic of stage s: 4 DMA instructions per wave
     const int slot = s & (LD::RD - 1);
-    const uint32_t wo = (uint32_t)s * (uint32_t)NG * 1024u, ao = (uint32_t)(s * BK) * 2u;
+    const uint32_t wo = (uint32_t)s * (uint32_t)NG * 1024u, ao = (uint32_t)(s * BK) * ESZ;
 #pragma unroll
     for (int j = 0; j < 2; ++j) dma16(wt_rsrc, w_src[j] + wo, smem + w_dst[j] + slot * LD::W_STAGE);
 #pragma unroll
@@ -125,7 +127,8 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   auto write_signs = [&](int s) __attribute__((always_inline)) {
     if (half == 0) {  // wave-uniform
       const uint32_t off = sg_off + (uint32_t)(s * BK);
-      const uint32_t w = p.sign_in ? sign_word_explicit(p.sign_in, off, p.x_bytes / 2u) : btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
+      uint32_t w = p.sign_in ? sign_word_explicit(p.sign_in, off, p.x_bytes / ESZ) : btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
+      if constexpr (G == 4) w <<= 8 * ((off >> 4) & 1);
       *(uint32_t*)(smem + LD::S_OFF + (s & (LD::RD - 1)) * LD::S_STAGE + (tid & 255) * 4) = w;
     }
   };
@@ -156,62 +159,57 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   // stages 0 and 1 landed (stage 2's four DMAs may be in flight); meet
   asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   Frag fa, fb;
-  load_frag(fa, 0);
-#if BTX_G8_OFFSET
+  if constexpr (PF) load_frag(fa, 0);
+  else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accd[a][b][r] = 0.f; }
+  }
   // Eight waves marching in lock-step request, read and multiply together: the two waves of a SIMD queue for the matrix pipe
   // and then leave it idle together.  A stage is therefore two parts with a workgroup barrier after each — A: requests of
-  // stage s+3, this stage's delta fragments, the next stage's fragments; B: the MFMAs — and waves 4-7 run one part behind waves
-  // 0-3 (one extra barrier in front of their first part, one behind the last part of waves 0-3): on every SIMD one wave
-  // multiplies while the other loads (the K-group scheme of btx_contract_taps.h).  A wave that requested in part A leaves
-  // those four DMAs in flight at both of the stage's barriers; stage s+2 (requested a stage ago by BOTH groups, the later one
-  // three parts before its first reader) has landed.
+  // stage s+3, this stage's delta fragments, the next (bf16) or this (f32 / split-bf16) stage's fragments; B: the MFMAs — and
+  // waves 4-7 run one part behind waves 0-3 (one extra barrier in front of their first part, one behind the last part of waves
+  // 0-3): on every SIMD one wave multiplies while the other loads (the K-group scheme of btx_contract_taps.h; measured against
+  // all eight in lock-step: +0.4 .. 2 % on cfg5).  A wave that requested in part A leaves those four DMAs in flight at both of
+  // the stage's barriers; stage s+2 (requested a stage ago by BOTH groups, the later one three parts before its first reader)
+  // has landed.
   DeltaFrag df;
-  auto part_a = [&](int s, Frag& nxt) __attribute__((always_inline)) {
+  auto part_a = [&](int s, Frag& f) __attribute__((always_inline)) {  // f: bf16 the set of stage s+1, else of stage s
     const bool more = s + 3 < nstages;  // wave-uniform
     if (more) { issue(s + 3); write_signs(s + 3); }
     load_delta<KIND>(df, smem + LD::W_OFF + (s & (LD::RD - 1)) * LD::W_STAGE + half * DW_STAGE, l31, h);
-    if (s + 1 < nstages) load_frag(nxt, s + 1);
+    if constexpr (PF) { if (s + 1 < nstages) load_frag(f, s + 1); }
+    else load_frag(f, s);
     if (more) end_stage<4>(); else end_stage<0>();
   };
   auto part_b = [&](int s, Frag& cur, auto first_tag) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    if constexpr (FIRST) stage_mma<1, KIND, 2, 2, true>(cur, df, accm, accd, l31, h);
-    else stage_mma<1, KIND>(cur, df, accm, accd, l31, h);
+    if constexpr (FIRST && PREC == 1) stage_mma<PREC, KIND, 2, 2, true>(cur, df, accm, accd, l31, h);
+    else stage_mma<PREC, KIND>(cur, df, accm, accd, l31, h);
     if (s + 3 < nstages) end_stage<4>(); else end_stage<0>();
   };
   if (half == 1) asm volatile("s_barrier" ::: "memory");
-  part_a(0, fb);
-  part_b(0, fa, std::true_type{});
-  int s = 1;
-  for (; s + 1 < nstages; s += 2) {
-    part_a(s, fa);
-    part_b(s, fb, std::false_type{});
-    part_a(s + 1, fb);
-    part_b(s + 1, fa, std::false_type{});
+  if constexpr (PF) {
+    part_a(0, fb);
+    part_b(0, fa, std::true_type{});
+    int s = 1;
+    for (; s + 1 < nstages; s += 2) {
+      part_a(s, fa);
+      part_b(s, fb, std::false_type{});
+      part_a(s + 1, fb);
+      part_b(s + 1, fa, std::false_type{});
+    }
+    if (s < nstages) { part_a(s, fa); part_b(s, fb, std::false_type{}); }
+  } else {
+    for (int s = 0; s < nstages; ++s) {
+      part_a(s, fa);
+      part_b(s, fa, std::false_type{});
+    }
   }
-  if (s < nstages) { part_a(s, fa); part_b(s, fb, std::false_type{}); }
   if (half == 0) asm volatile("s_barrier" ::: "memory");
-#else
-  auto stage = [&](int s, Frag& cur, Frag& nxt, auto first_tag) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    const bool more = s + 3 < nstages;  // wave-uniform
-    if (more) { issue(s + 3); write_signs(s + 3); }
-    DeltaFrag df;
-    load_delta<KIND>(df, smem + LD::W_OFF + (s & (LD::RD - 1)) * LD::W_STAGE + half * DW_STAGE, l31, h);
-    if (s + 1 < nstages) load_frag(nxt, s + 1);
-    if constexpr (FIRST) stage_mma<1, KIND, 2, 2, true>(cur, df, accm, accd, l31, h);
-    else stage_mma<1, KIND>(cur, df, accm, accd, l31, h);
-    // stage s+2 (requested one iteration ago) has landed: at most this iteration's four DMAs stay in flight
-    if (more) end_stage<4>(); else end_stage<0>();
-  };
-  stage(0, fa, fb, std::true_type{});
-  int s = 1;
-  for (; s + 1 < nstages; s += 2) {
-    stage(s, fb, fa, std::false_type{});
-    stage(s + 1, fa, fb, std::false_type{});
-  }
-  if (s < nstages) stage(s, fb, fa, std::false_type{});
-#endif
 
   // =================== store side (btx_epilogue.h): every wave stages its own 64 x 64 tile ============================
   {
@@ -229,16 +227,17 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   }
 }
 
-static int launch_contract_gemm8(int kind, const ContractParams& p, int nwg, hipStream_t st) {
+template <int PREC>
+static int launch_contract_gemm8_impl(int kind, const ContractParams& p, int nwg, hipStream_t st) {
   if (kind != 1) return -3;
-  auto kfn = contract_gemm8_kernel<1>;
+  auto kfn = contract_gemm8_kernel<PREC, 1>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G8Lds::BYTES);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  int rc = launch_presample_impl<1>(kind, p, st);
+  int rc = launch_presample_impl<PREC>(kind, p, st);
   if (rc) return rc;
   hipLaunchKernelGGL(kfn, dim3(nwg), dim3(512), G8Lds::BYTES, st, p);
   return (int)hipGetLastError();

@@ -4,6 +4,7 @@
 #include "btx_contract_patch.h"
 #include "btx_contract_stem.h"
 #include "btx_contract_dma.h"
+#include "btx_contract_gemm8.h"
 #if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
 #include "btx_contract_pw.h"  // measured and parked: see btx_api.hip
 #endif
@@ -25,5 +26,8 @@ int launch_contract_pw_x3(int kind, const ContractParams& p, int nwg, hipStream_
 int launch_presample_batch_x3(const PresampleBatch& b, hipStream_t st) {
   hipLaunchKernelGGL((presample_batch_kernel<2>), dim3(b.total_blocks), dim3(256), 0, st, b);
   return (int)hipGetLastError();
+}
+int launch_contract_gemm8_x3(int kind, const ContractParams& p, int nwg, hipStream_t st) {
+  return launch_contract_gemm8_impl<2>(kind, p, nwg, st);
 }
 }  // namespace btx
