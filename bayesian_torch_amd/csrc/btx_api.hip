@@ -1061,7 +1061,7 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     const int min_k = mk ? atoi(mk) : BTX_GEMM8_MINK_DEFAULT;
     const int bk8 = NG * (prec == BTX_PREC_BF16 ? 8 : 4);  // (dma: the activation dtype is the contraction's)
     if (dma && !rowfuse && !patch && kind == BTX_KIND_FLIPOUT &&
-        !(flags & BTX_FLAG_TRANSPOSED) && g->KD == 1 && g->KH == 1 && g->KW == 1 && g->sd == 1 && g->sh == 1 && g->sw == 1 &&
+        !(flags & BTX_FLAG_TRANSPOSED) && g->KD == 1 && g->KH == 1 && g->KW == 1 &&
         g->pd == 0 && g->ph == 0 && g->pw == 0 && (pl.K % bk8) == 0 && pl.K >= 4 * bk8 && pl.K >= min_k && (pl.Ng % 128) == 0 &&
         !tune_env("BTX_NO_GEMM8")) {
       const long long mt = (pl.M + 255) / 256;

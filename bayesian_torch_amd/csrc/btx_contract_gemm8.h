@@ -1,5 +1,5 @@
-// btx_contract_gemm8.h — pointwise Flipout contractions with a long K (1x1x1 convolutions at stride 1 without padding and
-// Linear layers, K >= 256: the "reduce" and 3x3-neighbour 1x1 convolutions of a ResNet50 bottleneck, reference
+// btx_contract_gemm8.h — pointwise Flipout contractions with a long K (1x1x1 convolutions without padding, any stride, and
+// Linear layers, K >= 128: the "reduce" and 3x3-neighbour 1x1 convolutions of a ResNet50 bottleneck, reference
 // models/deterministic/resnet_large.py:85-105, layers/flipout_layers/conv_flipout.py:376-417) as ONE 8-wave workgroup per CU
 // with the K loop of the tap-unrolled kernel (gfx950; bf16, and the f32 / split-bf16 precisions on f32 activations).
 //
@@ -87,6 +87,16 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
                (set ? p.wt_delta_off : 0u);
     w_dst[j] = LD::W_OFF + hf * DW_STAGE + set * 4096 + row * 1024;
   }
+  // output pixel m -> input pixel: itself for stride 1 (a plain GEMM), else the strided position (1x1 down-sampling
+  // convolutions: no padding, so every output pixel has its input pixel)
+  auto pix_in = [&](int m) __attribute__((always_inline)) -> uint32_t {
+    if (p.pointwise) return (uint32_t)m;
+    uint32_t t, t2, ow, oh, od, nb;
+    fdivmod((uint32_t)m, p.fd_Wo, (uint32_t)p.Wo, t, ow);
+    fdivmod(t, p.fd_Ho, (uint32_t)p.Ho, t2, oh);
+    fdivmod(t2, p.fd_Do, (uint32_t)p.Do, nb, od);
+    return ((nb * (uint32_t)p.D + od * (uint32_t)p.sd) * (uint32_t)p.H + oh * (uint32_t)p.sh) * (uint32_t)p.W + ow * (uint32_t)p.sw;
+  };
   // ---- activation loader: the stage's 16 pieces of 1 KiB (16 pixels x 64 B) — pieces 2w, 2w+1 to wave w; source-side XOR
   //      swizzle as in btx_contract_dma.h; out-of-range pixels read zeros
   const int g_lane = (lane & 3) ^ ((lane >> 4) & 3);
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   for (int j = 0; j < 2; ++j) {
     const int piece = 2 * wave + j;
     const int mq = mtile * TP + piece * 16 + (lane >> 2);
-    a_src[j] = mq < p.M ? ((uint32_t)mq * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) * ESZ : DMA_OOB;
+    a_src[j] = mq < p.M ? (pix_in(mq) * (uint32_t)p.C + (uint32_t)(group * p.Cg + G * g_lane)) * ESZ : DMA_OOB;
     a_dst[j] = LD::A_OFF + piece * 1024;
   }
   auto issue = [&](int s) __attribute__((always_inline)) {  // all L2 -> LDS traffic of stage s: 4 DMA instructions per wave
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   }
   // ---- s_in words: thread t < 256 hashes the word of pixel t for a stage (32 channels = one word)
   const int m_own = mtile * TP + (tid & 255);
-  const uint32_t sg_off = (uint32_t)(m_own < p.M ? m_own : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+  const uint32_t sg_off = pix_in(m_own < p.M ? m_own : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
   auto write_signs = [&](int s) __attribute__((always_inline)) {
     if (half == 0) {  // wave-uniform
       const uint32_t off = sg_off + (uint32_t)(s * BK);

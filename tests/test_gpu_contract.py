@@ -126,6 +126,8 @@ FUSED_CASES = [
     ("Conv2dFlipout", dict(in_channels=256, out_channels=256, kernel_size=1, groups=2), (3, 256, 11, 13)),
     ("Conv2dFlipout", dict(in_channels=160, out_channels=384, kernel_size=1, bias=False), (2, 160, 17, 9)),
     ("LinearFlipout", dict(in_features=2048, out_features=128), (70, 2048)),
+    ("Conv2dFlipout", dict(in_channels=128, out_channels=256, kernel_size=1, stride=2, bias=False), (3, 128, 15, 13)),   # strided
+    ("Conv3dFlipout", dict(in_channels=128, out_channels=128, kernel_size=1, stride=(1, 2, 3)), (2, 128, 3, 9, 10)),
     # element-wise (GEN) kernels with in-kernel noise: odd channel counts
     ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 32, 32)),
     ("LinearFlipout", dict(in_features=50, out_features=10), (7, 50)),

@@ -33,6 +33,7 @@ LAYER_CASES = [
     ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 64, 64)),  # row-fused stem
     ("Conv2dFlipout", dict(in_channels=64, out_channels=256, kernel_size=1, bias=False), (4, 64, 28, 28)),              # pointwise GEMM, resident stages
     ("Conv2dFlipout", dict(in_channels=256, out_channels=128, kernel_size=1, bias=True), (3, 256, 14, 14)),            # pointwise GEMM, streamed stages
+    ("Conv2dFlipout", dict(in_channels=128, out_channels=256, kernel_size=1, stride=2, bias=False), (4, 128, 28, 28)),  # 8-wave GEMM, strided
     ("LinearFlipout", dict(in_features=512, out_features=1000), (8, 512)),
     ("LinearReparameterization", dict(in_features=128, out_features=64), (8, 128)),
     ("Conv2dFlipout", dict(in_channels=20, out_channels=24, kernel_size=3, padding=1), (2, 20, 9, 9)),                 # channel-padded -> gather/regstage
