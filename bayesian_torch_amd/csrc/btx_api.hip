@@ -1274,6 +1274,11 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   } else if (dma && gemm8) {
     p.pt_rtiles = g8_pairs;
     p.fd_rtiles = make_fastdiv((uint32_t)g8_pairs); p.fd_inner = make_fastdiv((uint32_t)(g8_pairs * g->groups));
+    // MEASUREMENT ONLY (tuning builds, BTX_G8_DIRECT=1): the store side from the fragment registers (direct_epilogue,
+    // btx_epilogue.h) where its contract holds — outputs of the activation dtype, hashed s_out, 32-bit byte offsets with an
+    // out-of-range value to spare (per lane).  Bit-identical and 5-25 % slower than the staged side.
+    p.ep_direct = (tune_env("BTX_G8_DIRECT") && (out_bf16 != 0) == (prec == BTX_PREC_BF16) && (g->N % 32) == 0 &&
+                   !(noise && noise->sign_out) && (long long)pl.M * g->N * (out_bf16 ? 2 : 4) < 0x7ff00000LL) ? 1 : 0;
     rc = (prec == BTX_PREC_BF16) ? launch_contract_gemm8_bf16(kind, p, pl.nwg * lanes, st)
          : (prec == BTX_PREC_BF16X3) ? launch_contract_gemm8_x3(kind, p, pl.nwg * lanes, st)
                                      : launch_contract_gemm8_f32(kind, p, pl.nwg * lanes, st);

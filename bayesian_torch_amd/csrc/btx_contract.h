@@ -200,6 +200,57 @@ __device__ __forceinline__ ContractParams lane_view(const ContractParams& q, int
   int logical_var = xcd_logical();                                                                                    \
   const ContractParams name = lane_view(*(const ContractParams*)name##_karg, logical_var)
 
+// The same view without control flow (btx_contract_gemm8.h: one workgroup per CU, so nobody covers this workgroup's scalar-load
+// round trips).  lane_view() reads the lane strides inside `if (lanes > 1)`, `if (ep_res)`, ...: five dependent batches of
+// s_load + s_waitcnt in front of the first DMA and five more in front of the store side.  Here every field is read
+// unconditionally — one batch — and the lane arithmetic runs for lanes == 1 as well (lane_nwg is the whole grid then: lane 0,
+// zero strides).
+__device__ __forceinline__ ContractParams lane_view_flat(const ContractParams& q, int& logical) {
+  ContractParams p = q;
+  // every field the lane arithmetic reads, as a value that exists HERE (the empty asm takes them as operands): without it the
+  // compiler turns the selects below back into branches and sinks each stride's load into its branch
+  const int q_rev = q.reverse, q_lnwg = q.lane_nwg, q_lwd = q.lane_wt_delta;
+  const FastDiv q_fd = {q.fd_lane_nwg.m, q.fd_lane_nwg.sh};
+  const long long q_lx = q.lane_x, q_lo = q.lane_out, q_lr = q.lane_res, q_lw = q.lane_wt, q_lp = q.lane_partial;
+  const unsigned char* q_x = (const unsigned char*)q.x;
+  unsigned char* q_out = (unsigned char*)q.out;
+  const unsigned char* q_res = (const unsigned char*)q.ep_res;
+  unsigned char* q_wt = (unsigned char*)q.wt;
+  unsigned char* q_part = (unsigned char*)q.partial;
+  const uint32_t* q_sp = q.sample_ptr;
+  const uint32_t q_smp = q.sample, q_wdo = q.wt_delta_off;
+  asm volatile("" ::"s"(q_rev), "s"(q_lnwg), "s"(q_lwd), "s"(q_fd.m), "s"(q_fd.sh), "s"(q_lx), "s"(q_lo), "s"(q_lr), "s"(q_lw), "s"(q_lp), "s"(q_x),
+               "s"(q_out), "s"(q_res), "s"(q_wt), "s"(q_part), "s"(q_sp), "s"(q_smp), "s"(q_wdo));
+  logical = q_rev ? (int)gridDim.x - 1 - logical : logical;
+  uint32_t lane, loc;
+  fdivmod((uint32_t)logical, q_fd, (uint32_t)q_lnwg, lane, loc);
+  logical = (int)loc;
+  const long long l = (long long)lane;
+  const long long wo = l * q_lw;
+  p.x = q_x + l * q_lx;
+  p.out = q_out + l * q_lo;
+  p.ep_res = q_res ? (const void*)(q_res + l * q_lr) : nullptr;
+  p.wt_delta_off = q_wdo + (q_lwd ? (uint32_t)wo : 0u);
+  p.wt = q_wt ? (void*)(q_wt + (q_lwd ? 0ll : wo)) : nullptr;
+  p.partial = q_part ? (float*)(q_part + l * q_lp) : nullptr;
+  p.sample_ptr = q_sp ? q_sp + lane : nullptr;
+  p.sample = q_smp + lane;
+  return p;
+}
+#define BTX_SECTION_PARAMS_FLAT(name, logical_var)                                                                    \
+  const __attribute__((address_space(4))) ContractParams* name##_karg =                                               \
+      (const __attribute__((address_space(4))) ContractParams*)__builtin_amdgcn_kernarg_segment_ptr();                \
+  asm volatile("" : "+s"(name##_karg));                                                                               \
+  int logical_var = xcd_logical();                                                                                    \
+  const ContractParams name = lane_view_flat(*(const ContractParams*)name##_karg, logical_var)
+
+// the MC sample word of a launch whose index lives in device memory, as a SCALAR load: the word does not change while the
+// kernel runs, so it may be read through the constant address space (s_load_dword, waited for where it is used) — a plain
+// dereference compiles to global_load_dword + s_waitcnt vmcnt(0) + v_readfirstlane at the head of the workgroup
+__device__ __forceinline__ uint32_t sample_word_scalar(const uint32_t* ptr) {
+  return *(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)ptr;
+}
+
 // ---- the (sample index, sign keys) a launch actually uses --------------------------------------------------------
 // BtxRng.sample_idx_dev lets a captured hipGraph be replayed for successive MC samples: the index — and the Flipout
 // sign keys derived from it — are then resolved on the device at run time instead of being baked into the arguments.

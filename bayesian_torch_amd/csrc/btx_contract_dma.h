@@ -33,6 +33,10 @@
 #include "btx_presample.h"
 #include "btx_mma.h"
 
+#ifndef BTX_DMA_RPRE
+#define BTX_DMA_RPRE 1  // residual rows requested in front of the store side's first stage (btx_epilogue.h, RES_PRE): +2 % on cfg5
+#endif
+
 namespace btx {
 
 constexpr int DBM = 512;                    // pixels per workgroup tile, 8-wave blocks (one per CU)
@@ -384,10 +388,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
 #endif
 #ifdef BTX_EP_TRACE
     uint32_t ep_t[2] = {0, 0};
-    staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid, ep_t);
+    staged_epilogue<KIND, NW, BTX_DMA_RPRE != 0>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid, ep_t);
     tr_ab = ep_t[0] - tr_t2; tr_bc = ep_t[1] - ep_t[0];
 #else
-    staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    staged_epilogue<KIND, NW, BTX_DMA_RPRE != 0>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
 #endif
   }
 #ifdef BTX_PT_TRACE

@@ -26,25 +26,49 @@ __device__ __forceinline__ void static_for_ep(F&& f) {
 
 // per-channel constants of the tile in LDS: [bias_mean | bias_delta | scale | shift] x 64 (identity where absent);
 // written by threads t = 0..63 of the caller, who also provides the barrier before they are read
+struct EpRaw {  // what thread t of the filling wave read from memory for channel t of the tile
+  float mu, rho, eps, sc, sh;
+};
+__device__ __forceinline__ EpRaw ep_load_constants(const ContractParams& p, int t, int ntile, int group, bool has_bias,
+                                                   bool has_aff) {
+  EpRaw r = {0.f, 0.f, 0.f, 1.f, 0.f};
+  if (t < BN) {
+    const int col = ntile * BN + t;
+    const int gcol = group * p.Ng + (col < p.Ng ? col : 0);
+    if (has_bias && col < p.Ng) {
+      r.mu = p.mu_b[gcol];
+      r.rho = p.rho_b[gcol];
+      if (p.eps_b) r.eps = p.eps_b[gcol];
+    }
+    if (has_aff && p.ep_scale) r.sc = p.ep_scale[gcol];
+    if (has_aff && p.ep_shift) r.sh = p.ep_shift[gcol];
+  }
+  return r;
+}
 template <int KIND>
-__device__ __forceinline__ void ep_fill_constants(const ContractParams& p, const RngLive& rl, float* ba_lds, int t,
-                                                  int ntile, int group, bool has_bias, bool has_aff) {
+__device__ __forceinline__ void ep_store_constants(const ContractParams& p, const RngLive& rl, const EpRaw& r, float* ba_lds,
+                                                   int t, int ntile, int group, bool has_bias) {
   if (t < BN) {
     const int col = ntile * BN + t;
     const int gcol = group * p.Ng + (col < p.Ng ? col : 0);
     float bm = 0.f, bdl = 0.f;
     if (has_bias && col < p.Ng) {
-      const float eb = p.eps_b ? p.eps_b[gcol]
-                               : btx_normal1((unsigned long long)gcol, rl.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
-      const float sb_ = btx_softplus_fast(p.rho_b[gcol]);
-      if constexpr (KIND == 0) { bm = __builtin_fmaf(sb_, eb, p.mu_b[gcol]); }
-      else { bm = p.mu_b[gcol]; bdl = sb_ * eb; }
+      const float eb = p.eps_b ? r.eps : btx_normal1((unsigned long long)gcol, rl.sample, p.layer, 1u, p.seed_lo, p.seed_hi);
+      const float sb_ = btx_softplus_fast(r.rho);
+      if constexpr (KIND == 0) { bm = __builtin_fmaf(sb_, eb, r.mu); }
+      else { bm = r.mu; bdl = sb_ * eb; }
     }
     ba_lds[t] = bm;
     ba_lds[BN + t] = bdl;
-    ba_lds[2 * BN + t] = (has_aff && p.ep_scale) ? p.ep_scale[gcol] : 1.f;
-    ba_lds[3 * BN + t] = (has_aff && p.ep_shift) ? p.ep_shift[gcol] : 0.f;
+    ba_lds[2 * BN + t] = r.sc;
+    ba_lds[3 * BN + t] = r.sh;
   }
+}
+template <int KIND>
+__device__ __forceinline__ void ep_fill_constants(const ContractParams& p, const RngLive& rl, float* ba_lds, int t,
+                                                  int ntile, int group, bool has_bias, bool has_aff) {
+  const EpRaw r = ep_load_constants(p, t, ntile, group, has_bias, has_aff);
+  ep_store_constants<KIND>(p, rl, r, ba_lds, t, ntile, group, has_bias);
 }
 
 // Tile pixel -> output pixel.  The default: the tile's pixels are consecutive output pixels from m0 on, the first `nvalid`
@@ -99,12 +123,23 @@ struct PixTall {  // tile = pt_R virtual rows from row0 x pt_Wt columns from col
   }
 };
 
-template <int KIND, int NW, class PM = PixContig>
+// RES_PRE (btx_contract_gemm8.h: one workgroup per CU, nobody covers this one's waits): a bf16 residual is requested in front
+// of stage 1 — all 8 rows of the lane, 32 registers — and arrives while the fragments are staged, instead of two rounds of four
+// loads each waited for in stage 2.
+struct EpNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// HOOK: called once behind the residual requests and in front of stage 1 (btx_contract_gemm8.h issues its L2 touches there:
+// requests the wave does not wait for, queued BEHIND the residual rows it does wait for).
+template <int KIND, int NW, class PM = PixContig, bool RES_PRE = false, class HOOK = EpNoHook>
 __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
                                                    const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int wave,
                                                    int lane, int ntile, int group, int split, const PM& pm,
                                                    uint32_t* ep_t = nullptr, int pwave = -1, bool first = true,
-                                                   float* ba_ext = nullptr) {
+                                                   float* ba_ext = nullptr, const HOOK& hook = HOOK{},
+                                                   const uint32_t* wsh_ext = nullptr) {
+  // wsh_ext: the four hashed s_out words of the lane's fragment blocks ([mi][ni], already shifted by 2h), computed by the
+  // caller where it had idle issue slots (btx_contract_gemm8.h: while its first stages travel); only read on the fast path
   // pwave: index of the 64-pixel group of the tile these fragments hold (default: the wave index); `wave` selects the
   // wave-private staging area.  first == false: the per-channel constants are already in LDS (second half of a wave
   // that owns 128 pixels).  ba_ext: the constants were written (and a barrier passed) by the caller, at this address.
@@ -123,6 +158,24 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
   }
   unsigned char* ep = smem + wave * EP_WAVE;
 
+  u32x4 rpre[8];
+  if constexpr (RES_PRE) {
+    const bool all_vec = ((p.N & 7) == 0) && (((group * p.Ng) & 7) == 0) && (ntile * BN + BN <= p.Ng);
+    if (all_vec && !to_partial && p.ep_res != nullptr && p.out_bf16) {  // exactly the case fast<1, RES> of stage 2 handles
+      const uint32_t cbase = (uint32_t)(group * p.Ng + ntile * BN + (lane & 7) * 8);
+      auto wk = pm.walk(pwave * 64 + (lane >> 3));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        bool ok;
+        const uint32_t gp = wk.get(ok);
+        wk.step8();
+        rpre[i] = *(const u32x4*)((const __bf16*)p.ep_res + (ok ? gp * (uint32_t)p.N + cbase : cbase + pm.first() * (uint32_t)p.N));
+      }
+    }
+  }
+
+  hook();
+
   // ---- stage 1: fragments -> f32 tile in LDS.  The common case — the whole 64-channel tile exists and the s_out words
   // are aligned with the fragment columns — runs without a branch per value: one hashed word per (32 pixels x 32
   // channels), two shifts and a mask per element.
@@ -135,52 +188,71 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
     uint32_t SB = 0x80000000u;
     asm volatile("" : "+s"(SB));
     if constexpr (KIND == 1) {
+      if (wsh_ext) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        bool pok;  // a pixel that does not exist hashes some word: its values are never stored
-        const uint32_t orow = pm(pwave * 64 + mi * 32 + l31, pok) * (uint32_t)p.N + (uint32_t)(group * p.Ng + ntile * BN);
+        for (int i = 0; i < 4; ++i) wsh[i >> 1][i & 1] = wsh_ext[i];
+      } else {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          wsh[mi][ni] = btx_sign_word((orow + 32u * ni) >> 5, rl.kout_a, rl.kout_b) << (2 * h);
+        for (int mi = 0; mi < 2; ++mi) {
+          bool pok;  // a pixel that does not exist hashes some word: its values are never stored
+          const uint32_t orow = pm(pwave * 64 + mi * 32 + l31, pok) * (uint32_t)p.N + (uint32_t)(group * p.Ng + ntile * BN);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            wsh[mi][ni] = btx_sign_word((orow + 32u * ni) >> 5, rl.kout_a, rl.kout_b) << (2 * h);
+        }
       }
     }
-    auto body = [&](auto ba_tag) __attribute__((always_inline)) {
-      constexpr bool BA = decltype(ba_tag)::value;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cl = ni * 32 + 8 * q + 4 * h;
-          f32x4 bm, bd, sc, sh;
-          if constexpr (BA) {
-            bm = *(const f32x4*)(ba_lds + cl);
-            bd = *(const f32x4*)(ba_lds + BN + cl);
-            sc = *(const f32x4*)(ba_lds + 2 * BN + cl);
-            sh = *(const f32x4*)(ba_lds + 3 * BN + cl);
-          }
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            f32x4 v;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              float val = accm[mi][ni][4 * q + rr];
-              if constexpr (BA) val += bm[rr];
-              if constexpr (KIND == 1) {
-                float dl = accd[mi][ni][4 * q + rr];
-                if constexpr (BA) dl += bd[rr];
-                // element e = 8q + 4h + rr of the word sits at bit ((e&1) ? 31 : 15) - (e>>1); wsh is pre-shifted by 2h
-                constexpr int dummy = 0;
-                const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1)) + dummy;
-                val += u2f(__builtin_amdgcn_bitop3_b32(f2u(dl), wsh[mi][ni] << sft, SB, 0x78));  // dl ^ (w & SB)
-              }
-              if constexpr (BA) val = __builtin_fmaf(val, sc[rr], sh[rr]);
-              v[rr] = val;
-            }
-            *(f32x4*)(ep + (mi * 32 + l31) * EP_ROW + cl * 4) = v;
-          }
+    // three forms of the body: nothing per channel | BN affine only (every convolution of a converted ResNet: no bias) |
+    // bias and affine (identity scale / shift where absent) — the bias adds are a quarter of the body's VALU work
+    auto body = [&](auto bias_tag, auto aff_tag) __attribute__((always_inline)) {
+      constexpr bool BIAS = decltype(bias_tag)::value, BA = decltype(aff_tag)::value;
+      // eight groups of (32-channel half ni, 8-channel run q); the constants of group g+1 are requested in front of group g's
+      // arithmetic (two register sets): read where they are used, every group starts with an LDS round trip — eight of them,
+      // 1.2k+ of the ~3.4k cycles a wave spends in this stage when nobody covers it (btx_contract_gemm8.h)
+      struct Cst { f32x4 bm, bd, sc, sh; };
+      auto ldc = [&](int g, Cst& c) __attribute__((always_inline)) {
+        const int cl = (g >> 2) * 32 + 8 * (g & 3) + 4 * h;
+        if constexpr (BIAS) {
+          c.bm = *(const f32x4*)(ba_lds + cl);
+          c.bd = *(const f32x4*)(ba_lds + BN + cl);
         }
+        if constexpr (BA) {
+          c.sc = *(const f32x4*)(ba_lds + 2 * BN + cl);
+          c.sh = *(const f32x4*)(ba_lds + 3 * BN + cl);
+        }
+      };
+      Cst c0, c1;
+      ldc(0, c0);
+      static_for_ep<0, 8>([&](auto g_tag) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_tag)::value, ni = g >> 2, q = g & 3;
+        Cst& cur = (g & 1) ? c1 : c0;
+        Cst& nxt = (g & 1) ? c0 : c1;
+        if constexpr (g < 7) ldc(g + 1, nxt);
+        const int cl = ni * 32 + 8 * q + 4 * h;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          f32x4 v;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float val = accm[mi][ni][4 * q + rr];
+            if constexpr (BIAS) val += cur.bm[rr];
+            if constexpr (KIND == 1) {
+              float dl = accd[mi][ni][4 * q + rr];
+              if constexpr (BIAS) dl += cur.bd[rr];
+              // element e = 8q + 4h + rr of the word sits at bit ((e&1) ? 31 : 15) - (e>>1); wsh is pre-shifted by 2h
+              const int sft = 31 - (((rr & 1) ? 31 : 15) - 4 * q - (rr >> 1));
+              val += u2f(__builtin_amdgcn_bitop3_b32(f2u(dl), wsh[mi][ni] << sft, SB, 0x78));  // dl ^ (w & SB)
+            }
+            if constexpr (BA) val = __builtin_fmaf(val, cur.sc[rr], cur.sh[rr]);
+            v[rr] = val;
+          }
+          *(f32x4*)(ep + (mi * 32 + l31) * EP_ROW + cl * 4) = v;
+        }
+      });
     };
-    if (has_ba) body(std::true_type{}); else body(std::false_type{});
+    if (has_bias) body(std::true_type{}, std::true_type{});
+    else if (has_ba) body(std::false_type{}, std::true_type{});
+    else body(std::false_type{}, std::false_type{});
   } else {
     // generic path: ragged channel tiles, unaligned s_out words, explicit sign arrays (parity mode)
 #pragma unroll 1
@@ -247,31 +319,35 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
       constexpr int OUTK = decltype(outk_tag)::value;
       constexpr bool RES = decltype(res_tag)::value, RELU = decltype(relu_tag)::value;
       auto wk = pm.walk(pwave * 64 + (lane >> 3));
+      // two rounds of four pixels: half the registers, still four loads in flight.  RES_PRE (the accumulators are dead and the
+      // caller has the registers: one workgroup per CU): one round of eight — all 16 LDS reads in front of the arithmetic
+      constexpr int NP = RES_PRE ? 8 : 4;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {  // two rounds of four pixels: half the registers, still four loads in flight
-        uint32_t idx[4];
-        bool pk[4];
-        u32x4 r0[4], r1[4];
+      for (int hf = 0; hf < 8 / NP; ++hf) {
+        uint32_t idx[NP];
+        bool pk[NP];
+        u32x4 r0[NP], r1[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
           const uint32_t gp = wk.get(pk[i]);
           wk.step8();
           idx[i] = gp * (uint32_t)p.N + cbase;
           if constexpr (RES) {
             const uint32_t li = pk[i] ? idx[i] : cbase + pm.first() * (uint32_t)p.N;
-            if constexpr (OUTK == 1) r0[i] = *(const u32x4*)((const __bf16*)p.ep_res + li);
+            if constexpr (OUTK == 1 && RES_PRE) r0[i] = rpre[hf * NP + i];
+            else if constexpr (OUTK == 1) r0[i] = *(const u32x4*)((const __bf16*)p.ep_res + li);
             else { r0[i] = *(const u32x4*)((const float*)p.ep_res + li); r1[i] = *(const u32x4*)((const float*)p.ep_res + li + 4); }
           }
         }
-        f32x4 lo[4], hi[4];
+        f32x4 lo[NP], hi[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int pix = (hf * 4 + i) * 8 + (lane >> 3);
+        for (int i = 0; i < NP; ++i) {
+          const int pix = (hf * NP + i) * 8 + (lane >> 3);
           lo[i] = *(const f32x4*)(ep + pix * EP_ROW + cg * 32);
           hi[i] = *(const f32x4*)(ep + pix * EP_ROW + cg * 32 + 16);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
           float v[8] = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
           if constexpr (RES) {
             if constexpr (OUTK == 1) {
@@ -492,15 +568,15 @@ __device__ __forceinline__ void direct_epilogue(const ContractParams& p, const R
 }
 
 // the contiguous-tile form every other kernel uses
-template <int KIND, int NW>
+template <int KIND, int NW, bool RES_PRE = false>
 __device__ __forceinline__ void staged_epilogue(const ContractParams& p, const RngLive& rl, const f32x16 (&accm)[2][2],
                                                 const f32x16 (&accd)[2][2], unsigned char* smem, int tid, int wave,
                                                 int lane, int ntile, int group, int split, uint32_t m0, int nvalid,
                                                 uint32_t* ep_t = nullptr, int pwave = -1, bool first = true,
                                                 float* ba_ext = nullptr) {
   const PixContig pm = {m0, nvalid};
-  staged_epilogue_pm<KIND, NW, PixContig>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pm, ep_t, pwave,
-                                          first, ba_ext);
+  staged_epilogue_pm<KIND, NW, PixContig, RES_PRE>(p, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pm, ep_t, pwave,
+                                                   first, ba_ext);
 }
 
 }  // namespace btx

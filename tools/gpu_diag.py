@@ -229,6 +229,64 @@ def trace(prec, cin=64, cout=64, hw=56, stride=1, k=3, typ="Flipout", bs=64, war
         print("   wave %3d: %s start %d" % (w, t[w, :6].tolist(), int(t0[w])))
 
 
+def g8trace(prec, cin=256, cout=1024, hw=14, stride=1, k=1, typ="Flipout", bs=512, warm=30, full=True):
+    """per-wave phase timings of contract_gemm8_kernel (-DBTX_PT_TRACE -DBTX_EP_TRACE build): prologue / K loop / store stage 1 /
+    store stage 2, and per CU the gap between the end of a workgroup and the start of the next one.  full: BN affine + residual
+    + ReLU in the store side (a ResNet50 expand convolution); else a bare layer."""
+    import os
+    import numpy as np
+    from bayesian_torch_amd import layers as L
+    dev = torch.device("cuda:0")
+    act = torch.bfloat16 if prec == "bf16" else torch.float32
+    torch.manual_seed(0)
+    layer = getattr(L, "Conv2d" + typ)(cin, cout, k, stride=stride, padding=0, bias=False).to(dev)
+    layer.precision = prec
+    x = torch.randn(bs, cin, hw, hw, device=dev).to(act).contiguous(memory_format=torch.channels_last)
+    ho = (hw - 1) // stride + 1
+    ep = None
+    if full:
+        ep = dict(scale=torch.rand(cout, device=dev) + 0.5, shift=torch.randn(cout, device=dev), relu=True,
+                  residual=torch.randn(bs, cout, ho, ho, device=dev).to(act).contiguous(memory_format=torch.channels_last))
+    buf = torch.zeros(1 << 22, dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        for i in range(warm):
+            layer._forward_hip(x, sample_idx=i, epilogue=ep)
+        os.environ["BTX_TRACE_PTR"] = hex(buf.data_ptr())
+        layer._forward_hip(x, sample_idx=7, epilogue=ep)
+        torch.cuda.synchronize()
+        del os.environ["BTX_TRACE_PTR"]
+    t = buf.cpu().numpy().view(np.uint32).reshape(-1, 8, 8)
+    t = t[t[:, 0, 5] != 0]
+    print("g8trace %d->%d %dx%d s%d bs %d %s: workgroups traced: %d" % (cin, cout, hw, hw, stride, bs, "full store side" if full else "bare", len(t)))
+    if not len(t):
+        return
+    f = t.astype(np.float64)
+    ghz = f[:, :, 5].mean() / f[:, :, 2].mean() * 0.1
+    print("  shader clock %.3f GHz;  K stages %d" % (ghz, cin // 32))
+    for g in (0, 1):
+        w = f[:, 4 * g:4 * g + 4, :]
+        print("  waves %d-%d: prologue %6.0f | K loop %6.0f (%.0f / stage) | store stage 1 %6.0f | stage 2 %6.0f | drain %5.0f | total %6.0f cycles" % (
+            4 * g, 4 * g + 3, w[:, :, 0].mean(), w[:, :, 1].mean(), w[:, :, 1].mean() / (cin // 32), w[:, :, 3].mean(), w[:, :, 4].mean(),
+            (w[:, :, 5] - w[:, :, 0] - w[:, :, 1] - w[:, :, 3] - w[:, :, 4]).mean(), w[:, :, 5].mean()))
+    start = t[:, :, 6].astype(np.int64)
+    base = start.min()
+    start = (start - base) & 0xffffffff
+    end = start + t[:, :, 5].astype(np.int64)
+    bs_, be_ = start.min(axis=1), end.max(axis=1)
+    key = (t[:, 0, 7] >> 8) & 0xfff  # XCC | SE | SH | CU
+    gaps, per = [], []
+    for kk in np.unique(key):
+        idx = np.where(key == kk)[0]
+        o = idx[np.argsort(bs_[idx])]
+        per.append(len(o))
+        gaps.extend((bs_[o[1:]] - be_[o[:-1]]).tolist())
+    gaps = np.array(gaps, dtype=np.float64)
+    print("  CUs seen %d, workgroups per CU %.1f; workgroup time (first wave start -> last wave end) mean %.0f; gap to the next workgroup of the CU: mean %.0f  median %.0f  min %.0f  max %.0f cycles" % (
+        len(per), np.mean(per), (be_ - bs_).mean(), gaps.mean() if len(gaps) else 0, np.median(gaps) if len(gaps) else 0,
+        gaps.min() if len(gaps) else 0, gaps.max() if len(gaps) else 0))
+    print("  kernel span %.0f cycles = %.1f us" % (be_.max(), be_.max() / ghz / 1e3))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["parity", "perf"])
@@ -239,6 +297,7 @@ if __name__ == "__main__":
     ap.add_argument("--warm", type=int, default=3)
     ap.add_argument("--lanes", type=int, default=8)
     ap.add_argument("--throughput-plan", action="store_true")
+    ap.add_argument("--bare", action="store_true", help="g8trace: no BN affine / residual / ReLU in the store side")
     a = ap.parse_args()
     if a.throughput_plan:
         from bayesian_torch_amd import functional as _BF
@@ -255,6 +314,9 @@ if __name__ == "__main__":
         c = [int(v) for v in a.shape.split(",")]
         us, tf = gtime(a.prec.split(",")[0], *c, bs=a.bs)
         print("shape %s bs %d: %.1f us / call  %.1f TFLOP/s" % (a.shape, a.bs, us, tf))
+    if "g8trace" in a.what:
+        c = [int(v) for v in a.shape.split(",")]
+        g8trace(a.prec.split(",")[0], *c, bs=a.bs, warm=a.warm, full=not a.bare)
     if "trace" in a.what:
         c = [int(v) for v in a.shape.split(",")]
         trace(a.prec.split(",")[0], *c, bs=a.bs, warm=a.warm)
