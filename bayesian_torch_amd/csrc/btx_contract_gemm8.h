@@ -236,6 +236,9 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   }
 #endif
 
+  // (pinned here: left alone the compiler sinks both computations back to their use behind the K loop)
+  asm volatile("" : "+v"(wsh_pre[0]), "+v"(wsh_pre[1]), "+v"(wsh_pre[2]), "+v"(wsh_pre[3]), "+v"(l2pf_off));
+
   f32x16 accm[2][2], accd[2][2];
   using Frag = StageFragT<2>;
   auto load_frag = [&](Frag& f, int s) __attribute__((always_inline)) {

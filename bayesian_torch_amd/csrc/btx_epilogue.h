@@ -158,18 +158,34 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
   }
   unsigned char* ep = smem + wave * EP_WAVE;
 
+  // BUFIO (RES_PRE on consecutive-pixel tiles, bf16 outputs): the lane's eight pixels are 8 * N elements apart, so the residual
+  // loads and the stores of stage 2 are buffer instructions with ONE vector offset (the first pixel) and the pixel step in the
+  // scalar offset — no per-pixel address arithmetic, no exec masks: pixels behind the tensor's end (the last tile) fall outside
+  // the descriptor's range (loads return zeros, stores are dropped).  Byte offsets fit 32 bits (host: M * N < 2^31).
+  constexpr bool BUFIO = RES_PRE && std::is_same<PM, PixContig>::value;
   u32x4 rpre[8];
+  auto io_off = [&](int lane_) __attribute__((always_inline)) -> uint32_t {  // (evaluated where it is used: not kept across stage 1)
+    return ((pm.first() + (uint32_t)(pwave * 64 + (lane_ >> 3))) * (uint32_t)p.N + (uint32_t)(group * p.Ng + ntile * BN + (lane_ & 7) * 8)) * 2u;
+  };
+  const uint32_t io_step = 8u * (uint32_t)p.N * 2u, io_bytes = (uint32_t)p.M * (uint32_t)p.N * 2u;
   if constexpr (RES_PRE) {
     const bool all_vec = ((p.N & 7) == 0) && (((group * p.Ng) & 7) == 0) && (ntile * BN + BN <= p.Ng);
     if (all_vec && !to_partial && p.ep_res != nullptr && p.out_bf16) {  // exactly the case fast<1, RES> of stage 2 handles
-      const uint32_t cbase = (uint32_t)(group * p.Ng + ntile * BN + (lane & 7) * 8);
-      auto wk = pm.walk(pwave * 64 + (lane >> 3));
+      if constexpr (BUFIO) {
+        const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_res, 0, io_bytes, 0x00020000);
+        const uint32_t io_voff = io_off(lane);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        bool ok;
-        const uint32_t gp = wk.get(ok);
-        wk.step8();
-        rpre[i] = *(const u32x4*)((const __bf16*)p.ep_res + (ok ? gp * (uint32_t)p.N + cbase : cbase + pm.first() * (uint32_t)p.N));
+        for (int i = 0; i < 8; ++i) rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, io_voff, io_step * (uint32_t)i, 0);
+      } else {
+        const uint32_t cbase = (uint32_t)(group * p.Ng + ntile * BN + (lane & 7) * 8);
+        auto wk = pm.walk(pwave * 64 + (lane >> 3));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          bool ok;
+          const uint32_t gp = wk.get(ok);
+          wk.step8();
+          rpre[i] = *(const u32x4*)((const __bf16*)p.ep_res + (ok ? gp * (uint32_t)p.N + cbase : cbase + pm.first() * (uint32_t)p.N));
+        }
       }
     }
   }
@@ -319,6 +335,9 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
       constexpr int OUTK = decltype(outk_tag)::value;
       constexpr bool RES = decltype(res_tag)::value, RELU = decltype(relu_tag)::value;
       auto wk = pm.walk(pwave * 64 + (lane >> 3));
+      int lane_s2 = lane;
+      asm volatile("" : "+v"(lane_s2));  // (opaque: the store offset is computed here, not kept from the residual requests)
+      const uint32_t io_voff = BUFIO ? io_off(lane_s2) : 0u;
       // two rounds of four pixels: half the registers, still four loads in flight.  RES_PRE (the accumulators are dead and the
       // caller has the registers: one workgroup per CU): one round of eight — all 16 LDS reads in front of the arithmetic
       constexpr int NP = RES_PRE ? 8 : 4;
@@ -329,6 +348,11 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
         u32x4 r0[NP], r1[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
+          if constexpr (BUFIO && OUTK == 1) {  // addressed by (io_voff, scalar step): no per-pixel index
+            pk[i] = true; idx[i] = 0;
+            if constexpr (RES) r0[i] = rpre[hf * NP + i];
+            continue;
+          }
           const uint32_t gp = wk.get(pk[i]);
           wk.step8();
           idx[i] = gp * (uint32_t)p.N + cbase;
@@ -371,7 +395,13 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
               const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
               const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(x0, bf16x4));
               const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(x1, bf16x4));
-              *(u32x4*)((__bf16*)p.out + idx[i]) = (u32x4){p0[0], p0[1], p1[0], p1[1]};
+              if constexpr (BUFIO) {
+                const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, io_bytes, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){p0[0], p0[1], p1[0], p1[1]}, out_rsrc, io_voff,
+                                                       io_step * (uint32_t)(hf * NP + i), 0);
+              } else {
+                *(u32x4*)((__bf16*)p.out + idx[i]) = (u32x4){p0[0], p0[1], p1[0], p1[1]};
+              }
             } else {
               float* dst = (float*)p.out + idx[i];
               *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
