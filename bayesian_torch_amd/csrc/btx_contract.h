@@ -155,6 +155,13 @@ struct ContractParams {
   uint32_t* pt_queue; // persistent form: one zeroed counter per tile position (the image-group queue of its workgroups)
 };
 
+// the MC sample word of a launch whose index lives in device memory, as a SCALAR load: the word does not change while the
+// kernel runs, so it may be read through the constant address space (s_load_dword, waited for where it is used) — a plain
+// dereference compiles to global_load_dword + s_waitcnt vmcnt(0) + v_readfirstlane at the head of the workgroup
+__device__ __forceinline__ uint32_t sample_word_scalar(const uint32_t* ptr) {
+  return *(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)ptr;
+}
+
 // ---- workgroup id -> logical id, XCD-aware: block b runs on XCD b % 8; every XCD gets a contiguous range of logical ids,
 // so the workgroups that share an operand (and, with MC sample lanes, the workgroups of one lane) share an L2
 __device__ __forceinline__ int xcd_logical() {
@@ -244,12 +251,6 @@ __device__ __forceinline__ ContractParams lane_view_flat(const ContractParams& q
   int logical_var = xcd_logical();                                                                                    \
   const ContractParams name = lane_view_flat(*(const ContractParams*)name##_karg, logical_var)
 
-// the MC sample word of a launch whose index lives in device memory, as a SCALAR load: the word does not change while the
-// kernel runs, so it may be read through the constant address space (s_load_dword, waited for where it is used) — a plain
-// dereference compiles to global_load_dword + s_waitcnt vmcnt(0) + v_readfirstlane at the head of the workgroup
-__device__ __forceinline__ uint32_t sample_word_scalar(const uint32_t* ptr) {
-  return *(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)ptr;
-}
 
 // ---- the (sample index, sign keys) a launch actually uses --------------------------------------------------------
 // BtxRng.sample_idx_dev lets a captured hipGraph be replayed for successive MC samples: the index — and the Flipout
@@ -261,7 +262,7 @@ template <int KIND>
 __device__ __forceinline__ RngLive rng_live(const ContractParams& p) {
   RngLive r = {p.sample, p.kin_a, p.kin_b, p.kout_a, p.kout_b};
   if (p.sample_ptr || p.lanes > 1) {  // lanes: the host's keys are those of lane 0
-    if (p.sample_ptr) r.sample = __builtin_amdgcn_readfirstlane(*p.sample_ptr);
+    if (p.sample_ptr) r.sample = __builtin_amdgcn_readfirstlane(sample_word_scalar(p.sample_ptr));
     if constexpr (KIND == 1) {
       const uint32_t si = p.swap_signs ? 3u : 2u, so = p.swap_signs ? 2u : 3u;  // BTX_STREAM_SIGN_IN = 2, _OUT = 3
       const BtxPhilox4 ki = btx_philox4x32_10(0u, r.sample, p.layer, si, p.seed_lo, p.seed_hi);

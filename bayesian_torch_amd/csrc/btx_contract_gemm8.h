@@ -96,7 +96,8 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
 #ifdef BTX_PT_TRACE
   const uint32_t tr_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
   const uint32_t tr_r0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-  uint32_t tr_t1 = 0, tr_t2 = 0, tr_e1 = 0;
+  uint32_t tr_t1 = 0, tr_t2 = 0;
+  uint32_t tr_ep[4] = {0, 0, 0, 0};  // store side: [0] stage 1 done, [1] end, [2] / [3] around the body of stage 1 (BTX_EP_TRACE2)
 #endif
 
   const int tid = threadIdx.x;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
         gok[mi] = (int)gp[mi] < pe.M;
       }
 #ifdef BTX_PT_TRACE
-      tr_e1 = tr_t2;  // (no stage split: the whole store side is reported as stage 2)
+      tr_ep[0] = tr_t2;  // (no stage split: the whole store side is reported as stage 2)
 #endif
       direct_epilogue<KIND, OUT, true>(pe, rl, accm, accd, ba, tid_o, lane_o, ntile0 + half, group, gp, gok);
       asm volatile("" ::"v"(l2pf));
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
     const uint32_t m0 = (uint32_t)mtile * (uint32_t)TP;
     const PixContig pm = {m0, min(TP, pe.M - (int)m0)};
 #ifdef BTX_PT_TRACE
-    uint32_t* const ep_tr = &tr_e1;
+    uint32_t* const ep_tr = tr_ep;
 #else
     uint32_t* const ep_tr = nullptr;
 #endif
@@ -445,7 +446,10 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
     if (lane == 0) {
       uint32_t* tr = (uint32_t*)p.trace + (size_t)(blockIdx.x * 8 + wave) * 8;
       tr[0] = tr_t1 - tr_t0; tr[1] = tr_t2 - tr_t1; tr[2] = (uint32_t)__builtin_amdgcn_s_memrealtime() - tr_r0;
-      tr[3] = tr_e1 - tr_t2; tr[4] = tr_t3s - tr_e1; tr[5] = tr_t3 - tr_t0;
+      tr[3] = tr_ep[0] - tr_t2; tr[4] = tr_t3s - tr_ep[0]; tr[5] = tr_t3 - tr_t0;
+#ifdef BTX_EP_TRACE2  // stage 1 split instead: head (parameters, residual requests, touch) | body | LDS drain
+      tr[0] = tr_ep[2] - tr_t2; tr[1] = tr_ep[3] - tr_ep[2]; tr[3] = tr_ep[0] - tr_ep[3];
+#endif
       tr[6] = tr_t0;
       tr[7] = (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffu) |
               (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 16);  // HW_ID[15:0] | XCC_ID << 16

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
 
   // the MC sample word first: its latency hides behind the index arithmetic and the first DMA issues
   uint32_t smp = p.sample;
-  if (p.sample_ptr) smp = *p.sample_ptr;
+  if (p.sample_ptr) smp = sample_word_scalar(p.sample_ptr);  // s_load: a plain dereference is a global load waited for on the spot
 
   const int tid = threadIdx.x & 255;  // thread / wave index inside the K-group
   const int lane = tid & 63;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   uint32_t smp = p.sample;
-  if (p.sample_ptr) smp = *p.sample_ptr;
+  if (p.sample_ptr) smp = sample_word_scalar(p.sample_ptr);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

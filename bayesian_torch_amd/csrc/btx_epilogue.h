@@ -266,9 +266,15 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
         }
       });
     };
+#ifdef BTX_EP_TRACE2
+    if (ep_t) { __builtin_amdgcn_sched_barrier(0); ep_t[2] = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
     if (has_bias) body(std::true_type{}, std::true_type{});
     else if (has_ba) body(std::false_type{}, std::true_type{});
     else body(std::false_type{}, std::false_type{});
+#ifdef BTX_EP_TRACE2
+    if (ep_t) { __builtin_amdgcn_sched_barrier(0); ep_t[3] = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
   } else {
     // generic path: ragged channel tiles, unaligned s_out words, explicit sign arrays (parity mode)
 #pragma unroll 1
