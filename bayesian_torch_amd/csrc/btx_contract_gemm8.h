@@ -39,6 +39,9 @@ namespace btx {
 #ifndef BTX_G8_RPRE
 #define BTX_G8_RPRE 1  // residual rows requested in front of the store side's first stage
 #endif
+#ifndef BTX_G8_HALF
+#define BTX_G8_HALF 0  // bf16: all eight waves in lock-step, operands pipelined half a stage (one 32x32x16 K-step) ahead: slower
+#endif
 #ifndef BTX_G8_ALGKM
 #define BTX_G8_ALGKM 1  // no LDS wait at the barrier behind part A
 #endif
@@ -303,6 +306,81 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   // part A): every barrier waits for all LDS reads.
   // Phase timers + ablation builds (tools/gpu_diag.py g8trace, -DBTX_PT_ABL): MFMAs + barriers alone 1280 cycles per stage
   // (1030 = the matrix pipe), s_in masks +200, DMA +70, sign words +55: 1480.
+  constexpr bool HALFP = (BTX_G8_HALF != 0) && (PREC == 1);
+  if constexpr (HALFP) {
+    // BTX_G8_HALF (measured, not shipped: 1 950 - 2 040 cycles per stage against 1 500, bit-identical, cfg5 -1 %) — the other
+    // way to keep the matrix pipe fed: ALL operands of a K-step (activation, mean AND delta fragments:
+    // 26 registers) are read half a stage before they are multiplied, into two alternating sets (52 registers against the 84 of
+    // two full fragment sets + the delta set), so that every wave has MFMAs to issue the moment a barrier releases it and its
+    // reads ride under them; all eight waves in lock-step, ONE barrier per stage, both waves of a SIMD multiply at the same time
+    // (a single wave issues a 32x32x16 MFMA every 40 cycles, two fill each other's gaps).  Same K order per accumulator.
+    struct HalfFrag { u32x4 a[2], wm[2], wd[2]; uint32_t sw[2]; };
+    auto load_half = [&](HalfFrag& f, int s, int kk) __attribute__((always_inline)) {
+      const int slot = s & (LD::RD - 1);
+      const unsigned char* as = smem + LD::A_OFF + slot * LD::A_STAGE;
+      const unsigned char* ss = smem + LD::S_OFF + slot * LD::S_STAGE;
+      const unsigned char* ws = smem + LD::W_OFF + slot * LD::W_STAGE + half * DW_STAGE;
+      const int row = 2 * kk + h;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        f.a[mi] = *(const u32x4*)(as + (w4 * 64 + mi * 32 + l31) * 64 + ((row ^ ((l31 >> 2) & 3)) * 16));
+        f.sw[mi] = *(const uint32_t*)(ss + (w4 * 64 + mi * 32 + l31) * 4);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        f.wm[ni] = *(const u32x4*)(ws + (row * BN + ni * 32 + l31) * 16);
+        f.wd[ni] = *(const u32x4*)(ws + NG * BN * 16 + (row * BN + ni * 32 + l31) * 16);
+      }
+    };
+    auto mma_half = [&](HalfFrag& f, int kk, auto zero_tag) __attribute__((always_inline)) {
+      constexpr bool ZERO = decltype(zero_tag)::value;
+      const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          accm[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.wm[ni]), __builtin_bit_cast(bf16x8, f.a[mi]),
+                                                                 ZERO ? zc : accm[mi][ni], 0, 0, 0);
+      const int row = 2 * kk + h;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const uint32_t swr = f.sw[mi] << (4 * row);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) f.a[mi][d] ^= ((swr << d) & 0x80008000u);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          accd[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.wd[ni]), __builtin_bit_cast(bf16x8, f.a[mi]),
+                                                                 ZERO ? zc : accd[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // a barrier guarantees: stage s+2 landed (at most this stage's four DMAs in flight) and every read of the slot that is
+    // requested next (stage s: read in this stage's first half, multiplied in its second) is back; the K-step read ahead for
+    // the next stage belongs to a slot that is requested two stages later
+    auto meet_h = [&](int s) __attribute__((always_inline)) {
+      if (s + 3 < nstages) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    HalfFrag h0, h1;
+    // (the prologue's load_frag(fa, 0) is dead code here: fa is not used)
+    load_half(h0, 0, 0);
+    using TTh = std::true_type;
+    using FFh = std::false_type;
+    for (int s = 0; s < nstages; ++s) {
+      if (s + 3 < nstages) { issue(s + 3); write_signs(s + 3); }  // wave-uniform
+      load_half(h1, s, 1);
+      if (s == 0) mma_half(h0, 0, TTh{}); else mma_half(h0, 0, FFh{});
+      // (unconditional — behind the last stage it reads a slot nobody writes any more and nobody multiplies: under a
+      // condition the compiler's wait insertion merges the two paths and makes the MFMAs below wait for THESE reads)
+      load_half(h0, s + 1, 0);
+      mma_half(h1, 1, FFh{});
+      meet_h(s);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the store side's staging area lies over the rings
+  } else {
   constexpr bool RELAX = PF && (BTX_G8_ALGKM != 0);
   DeltaFrag df;
   auto a_body = [&](int s, Frag& f) __attribute__((always_inline)) {  // f: bf16 the set of stage s+1, else of stage s
@@ -372,6 +450,7 @@ __global__ __launch_bounds__(512, 2) void contract_gemm8_kernel(const ContractPa
   if (half == 0) asm volatile("s_barrier" ::: "memory");
 #endif
 
+  }
 #ifdef BTX_PT_TRACE
   tr_t2 = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
