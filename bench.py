@@ -545,7 +545,7 @@ def run_mlp_config(dev, steps=8):
     net = build_mlp(dev)
     torch.manual_seed(1234)
     x = torch.randn(256, 784, device=dev).to(torch.bfloat16)
-    kl = float(bt.get_kl_loss(net))
+    kl = float(bt.get_kl_loss(net).detach())
     g = mc.GraphedMC(net, x, kl=kl, lanes=1)
     with torch.no_grad():
         for s in range(4):
