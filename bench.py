@@ -343,6 +343,100 @@ def measure_traffic(lanes=8, timeout_s=240):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# shader clock / package power while the GPU is busy (every fraction here is clock-limited: the chip is power-bound)
+# ------------------------------------------------------------------------------------------------------------------
+class ClockPowerSampler:
+    """polls the amdgpu hwmon files (power1_average / power1_input [uW], freq1_input [Hz]) of the device every 10 ms in a
+    thread; falls back to `rocm-smi --showpower --showclocks` (~0.3 s per poll).  Best effort: fields are None when the
+    box exposes neither."""
+
+    def __init__(self, index=0):
+        import glob
+        import threading
+        self.power, self.sclk, self._stop, self._thr = [], [], threading.Event(), None
+        self.src = None
+        self._pfile = self._ffile = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
+        if cards:
+            h = cards[min(index, len(cards) - 1)]
+            for n in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(h, n)):
+                    self._pfile = os.path.join(h, n)
+                    break
+            self._ffile = os.path.join(h, "freq1_input")
+            self.src = "hwmon"
+        else:
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.src = "rocm-smi"
+        self._threading = threading
+
+    def _poll(self):
+        import re
+        while not self._stop.is_set():
+            try:
+                if self.src == "hwmon":
+                    if self._pfile:
+                        self.power.append(float(open(self._pfile).read()) * 1e-6)
+                    self.sclk.append(float(open(self._ffile).read()) * 1e-9)
+                    time.sleep(0.01)
+                else:
+                    o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True,
+                                       timeout=10).stdout
+                    m = re.search(r"GPU\[0\].*?Power \(W\):\s*([0-9.]+)", o)
+                    if m:
+                        self.power.append(float(m.group(1)))
+                    m = re.search(r"GPU\[0\].*?sclk clock level:.*?\((\d+)Mhz\)", o)
+                    if m:
+                        self.sclk.append(float(m.group(1)) * 1e-3)
+            except Exception:  # noqa
+                time.sleep(0.05)
+
+    def __enter__(self):
+        if self.src:
+            self._thr = self._threading.Thread(target=self._poll, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thr is not None:
+            self._thr.join(timeout=15)
+
+    def summary(self, skip=0.25):
+        """mean over the samples after the first `skip` share of the window (ramp-up)"""
+        def mean(v):
+            v = v[int(len(v) * skip):]
+            return sum(v) / len(v) if v else None
+        return {"shader_clock_ghz": mean(self.sclk), "package_w": mean(self.power), "source": self.src,
+                "samples": len(self.sclk) or len(self.power)}
+
+
+def sustained_run(runner, lanes, dev, seconds=2.0):
+    """the timed region's graph replayed back to back for ~`seconds` with the clock/power sampler on: the rate the chip
+    holds at its settled clock (the 10 ms timed region starts from an idle-cool package)"""
+    n = max(1, lanes)
+    idx = list(range(20_000_000, 20_000_000 + n))
+    with torch.no_grad():
+        runner.zero()
+        torch.cuda.synchronize(dev)
+        done = 0
+        with ClockPowerSampler(dev.index or 0) as smp:
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(8):
+                    runner.run(idx)
+                    done += n
+                torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+        runner.zero()
+    out = {"value": done / el, "seconds": el, "mc_samples": done}
+    out.update(smp.summary())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # the timed MC loop
 # ------------------------------------------------------------------------------------------------------------------
 class Runner:
@@ -465,7 +559,7 @@ def logits_parity(model_fn, x, prec, sample=3):
 
 def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, world=1, rank=0, graph=True, fuse=True,
                       presample=True, scaling="weak", total=None, per_launch=True, parity=False, prewarm=PREWARM_STEPS,
-                      concurrent_hint=None, lane_mode="launch", repeats=5):
+                      concurrent_hint=None, lane_mode="launch", repeats=5, sustain=0.0):
     import bayesian_torch_amd as bt
     from bayesian_torch_amd import mc
     bt.manual_seed(2024)
@@ -492,6 +586,9 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
     elapsed = sorted(runs)[len(runs) // 2]  # median of the repeated regions; every region is reported
     stats = runner.packed.clone()
     lanes_used = runner.graphed.lanes if runner.graphed is not None else 0
+    sustained = None
+    if sustain and dev.type == "cuda" and world == 1 and runner.graphed is not None:
+        sustained = sustained_run(runner, lanes_used, dev, seconds=sustain)
     runner.close()
     u = mc.unpack(stats, bs, 1000)
     assert abs(float(u["samples"]) - n_global) < 0.5, "work was skipped inside the timed region"
@@ -500,6 +597,8 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
            "lane_mode": lane_mode if lanes_used > 1 else "single",
            "ms_per_step": 1e3 * elapsed / max(len(mine), 1), "value": n_global / elapsed,
            "ms_per_step_runs": [1e3 * r / max(len(mine), 1) for r in runs]}
+    if sustained is not None:
+        res["sustained"] = sustained
     known = KL_KNOWN.get((arch, moped))
     if known:
         res["kl_rel_err"] = abs(kl - known) / known
@@ -677,6 +776,109 @@ def auto_lanes(steps, cap=32):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# the final stdout line: compact (the driver parses ONE line and keeps an 8 KB stdout tail); the tables go to a file
+# ------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6144
+DETAIL_PATH = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def _sig(v, n=5):
+    """floats to n significant digits (keeps the line short), containers recursively"""
+    if isinstance(v, str):
+        return v if len(v) <= 360 else v[:357] + "..."
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (n, v))
+    if isinstance(v, dict):
+        return {k: _sig(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, n) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out):
+    """full result dict -> the ONE JSON line rank 0 prints last (<= LINE_LIMIT bytes).  Carries the contract keys, `roofline`
+    (incl. traffic ratio, clock/power, the readings inside north_star's 1e-4) and `cpu_baseline`; per-launch tables,
+    traffic breakdowns and prose stay in gpurun_out/bench_detail.json (also echoed to stderr)."""
+    top = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "ms_per_step_runs",
+           "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "dry_run", "total_samples",
+           "kl_rel_err", "logits_rel_l2_vs_unfused_f32", "gpu_over_cpu", "sustained")
+    line = {k: out[k] for k in top if k in out}
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "global_batch", "parallelism"))
+    rf = out.get("roofline")
+    if rf:
+        r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_name", "achieved_contraction_only",
+                       "frac_contraction_only", "avg_launch_us", "avg_sampling_share_us", "mc_samples_per_launch",
+                       "launches_per_forward", "achieved_e2e", "frac_e2e", "shader_clock_ghz", "package_w",
+                       "frac_min_dominant_row", "rows"))
+        r.setdefault("traffic", None)
+        td = rf.get("traffic_detail") or {}
+        if td:
+            r["algorithmic_bytes"] = td.get("algorithmic_bytes")
+            r["traffic_ratio"] = td.get("ratio")
+            r["traffic_launch"] = "layer4 3x3 s1 512ch 7x7 (worst ratio) incl. sampling"
+            lay = td.get("layers") or {}
+            r["traffic_ratio_by_layer"] = {k: v.get("ratio") for k, v in lay.items()}
+            r["traffic_source"] = "this run" if (rf.get("traffic_source") or "").startswith("measured") else "profiles/pmc_traffic.json"
+        modes = rf.get("modes_within_1e-4") or {}
+        if modes:
+            r["modes_within_1e-4"] = {m: _pick(v, ("value", "logits_rel_l2", "dominant_kernel_frac", "peak", "frac_e2e"))
+                                      for m, v in modes.items()}
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "cpu", "host_threads", "sample")) if cb else None
+    ex = out.get("extra")
+    if ex:
+        e2 = {}
+        for k, v in ex.items():
+            if not isinstance(v, dict):
+                e2[k] = v  # "error": "..."
+                continue
+            short = {"cfg4_strong_shape_4_per_rank": "strong_shape", "cfg4_f32_parity_mode": "cfg4_f32"}.get(k, k)
+            e2[short] = _pick(v, ("value", "ms_per_step", "frac_e2e", "dominant_kernel_frac", "kl_rel_err",
+                                  "logits_rel_l2_vs_unfused_f32", "logits_rel_l2_vs_f32_mode", "vs_weak_region",
+                                  "achieved_tflops", "hbm_rows_min_frac", "lanes"))
+        line["extra"] = e2
+    line["detail"] = "gpurun_out/bench_detail.json"
+    line = _sig(line)
+    s = json.dumps(line, separators=(",", ":"))
+    # belt and braces: shed optional blocks until the line fits
+    for drop in (("extra",), ("roofline", "rows"), ("roofline", "traffic_ratio_by_layer"), ("ms_per_step_runs",)):
+        if len(s) <= LINE_LIMIT:
+            break
+        tgt = line
+        for k in drop[:-1]:
+            tgt = tgt.get(k) or {}
+        tgt.pop(drop[-1], None)
+        s = json.dumps(line, separators=(",", ":"))
+    return s
+
+
+def emit(out):
+    """detail -> gpurun_out/bench_detail.json + stderr; the compact line -> stdout, LAST"""
+    try:
+        os.makedirs(os.path.dirname(DETAIL_PATH), exist_ok=True)
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        print("bench: could not write %s (%s)" % (DETAIL_PATH, e), file=sys.stderr)
+    print("bench detail: " + json.dumps(out), file=sys.stderr)
+    sys.stderr.flush()
+    print(compact_line(out))
+    sys.stdout.flush()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def self_launch(n, argv, dry_run):
     """re-exec under torch.distributed.run with one rank per GPU (rendezvous on 127.0.0.1, a free port)"""
     if not dry_run:
@@ -774,6 +976,7 @@ def main():
     ap.add_argument("--no-launch-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg2/cfg3/cfg5/f32 sub-results")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC traffic measurement")
+    ap.add_argument("--no-sustain", action="store_true", help="skip the ~2 s back-to-back replay with the clock/power sampler")
     ap.add_argument("--no-stem-pool", action="store_true", help="A/B: the stem's max-pool as its own kernel instead of folded "
                     "into the stem launch (BtxEpilogue.pool)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank protocol (no GPU)")
@@ -821,7 +1024,7 @@ def main():
                              per_launch=not args.no_launch_timing and rank == 0,
                              concurrent_hint=False if args.latency_plan else None,
                              parity=(rank == 0 and world == 1 and not args.no_extras), lane_mode=args.lane_mode,
-                             repeats=args.repeats)
+                             repeats=args.repeats, sustain=0.0 if args.no_sustain else 2.0)
     if rank == 0:
         peak = MFMA_PEAK_TFLOPS[args.prec]
         roofline = None
@@ -860,6 +1063,22 @@ def main():
                             "step / ms_per_step of the timed region",
                 "per_launch": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "dominant"}
                                for r in head["per_launch"]]}
+            roofline["kernel_name"] = "contract_taps_kernel<%s,%s,3,3>" % (args.prec, args.type)
+            # one figure per launch family (fraction of its own bound, sampling share included): what holds the step back
+            fam = {}
+            for r in head["per_launch"]:
+                lab = r["launch"].split()
+                hw = int(round((int(lab[-1][1:]) / args.batch / max(1, r.get("lanes") or 1)) ** 0.5)) if lab[-1].startswith("M") else 0
+                key = "%s_%s_%d" % (lab[1], lab[2], hw)
+                fam.setdefault(key, []).append((r.get("frac_incl_sampling", r["frac"]), r["us"]))
+            roofline["rows"] = {k: round(sum(f * u for f, u in v) / sum(u for _, u in v), 3) for k, v in fam.items()}
+            doms = [r.get("frac_incl_sampling", r["frac"]) for r in head["per_launch"] if r["dominant"]]
+            if doms:
+                roofline["frac_min_dominant_row"] = min(doms)
+            if head.get("sustained"):
+                roofline["shader_clock_ghz"] = head["sustained"].get("shader_clock_ghz")
+                roofline["package_w"] = head["sustained"].get("package_w")
+                roofline["clock_power_note"] = "sampled (%s) during the ~2 s back-to-back replay of the timed graph (`sustained`)" % head["sustained"].get("source")
         out = {
             "metric": "MC-samples/sec (Bayesian-%s, 224^2, bs=%d)" % ("ResNet18" if args.arch == "resnet18" else "ResNet50",
                                                                       args.batch),
@@ -880,6 +1099,8 @@ def main():
             "image_samples_per_s": args.batch * head["n_global"] / head["elapsed"],
             "kl": head["kl"], "kl_rel_err": head.get("kl_rel_err"), "roofline": roofline,
         }
+        if head.get("sustained"):
+            out["sustained"] = head["sustained"]
         if "logits_rel_l2_vs_unfused_f32" in head:
             out["logits_rel_l2_vs_unfused_f32"] = head["logits_rel_l2_vs_unfused_f32"]
         if world == 1 and not args.no_extras:
@@ -888,7 +1109,7 @@ def main():
                 r = run_resnet_config("resnet18", "Reparameterization", "bf16", 64, False, 16, 3, 16, dev, parity=True,
                                       prewarm=3)
                 extra["cfg3"] = summarise_extra("cfg3: dnn_to_bnn(ResNet18) Reparameterization bs64 bf16", r, "bf16")
-                r = run_resnet_config("resnet18", "Flipout", "f32", 64, False, 3, 1, 1, dev, prewarm=1)
+                r = run_resnet_config("resnet18", "Flipout", "f32", 64, False, 3, 1, 1, dev, prewarm=1, parity=True)
                 extra["cfg4_f32_parity_mode"] = summarise_extra(
                     "cfg4 shard in f32 parity mode (v_mfma_f32_32x32x2_f32, f32 activations)", r, "f32")
                 # north_star's 1e-4 tolerance at throughput: f32 activations, split-bf16 operands, three bf16 MFMAs per product
@@ -923,14 +1144,14 @@ def main():
                     if "dominant_kernel_frac" in e:
                         modes[tag] = {"dominant_kernel_frac": e["dominant_kernel_frac"], "dominant_kernel_tflops":
                                       e["dominant_kernel_tflops"], "peak": MFMA_PEAK_TFLOPS[tag], "value": e["value"],
-                                      "logits_rel_l2_vs_unfused_f32": e.get("logits_rel_l2_vs_unfused_f32")}
+                                      "frac_e2e": e.get("frac_e2e"), "logits_rel_l2": e.get("logits_rel_l2_vs_unfused_f32")}
                 roofline["modes_within_1e-4"] = modes
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.type, args.batch)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 
