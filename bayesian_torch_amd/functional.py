@@ -275,13 +275,16 @@ def sample_weights(items, seed, sample_idx, prec, device, sample_dev=None, lanes
 
 
 def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_id, prec=None, noise=None,
-                 extra_flags=0, out_dtype=None, epilogue=None, sampled_w=None, sample_dev=None, lanes=1, lane_batch=None):
+                 extra_flags=0, out_dtype=None, epilogue=None, sampled_w=None, sample_dev=None, lanes=1, lane_batch=None,
+                 self_sampling_weights=None):
     """One fused sample-and-contract forward on the GPU (btx_contract_fwd).  `mu_p`/`rho_p` are GEMM-major packed.
     `noise` (parity mode) = dict with optional eps_w (logical weight layout), eps_b, sign_in, sign_out.
     lanes > 1 (btx_contract_fwd_lanes): `lanes` MC samples in one launch.  x holds either the lanes' inputs back to
     back along the batch axis (lanes * lane_batch rows / images) or ONE input shared by all lanes (lane_batch rows);
     the output always holds the lanes back to back.  Sample indices: sample_idx + lane, or the `lanes` words of
-    sample_dev."""
+    sample_dev.  self_sampling_weights: callable -> (mu_p, rho_p) a launch that samples for itself must read, for callers
+    that pass `sampled_w` together with parameters the launch cannot sample from (the row-fused stem hands over its
+    UNPADDED mu/rho when pre-sampled tiles exist); used by the per-lane fallback below, which drops the lane-batched tiles."""
     L = _lib.lib()
     if not x.is_cuda:
         raise _lib.BtxError("contract_hip needs a CUDA (ROCm) tensor")
@@ -319,6 +322,11 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
         pooled = epilogue is not None and epilogue.get("pool")
         if ((x_lane | out_lane) & 15) and not pooled:
             outs = []
+            if sampled_w is not None and self_sampling_weights is not None:
+                mu_p, rho_p = self_sampling_weights()  # the single-lane launches sample in registers, from these
+            elif sampled_w is not None and (extra_flags & _lib.FLAG_ROWFUSE):
+                raise _lib.BtxError("row-fused launch with pre-sampled tiles and unaligned lane strides: the per-lane fallback "
+                                    "needs the padded parameters (self_sampling_weights)")
             xl = x.reshape((lanes, -1) + tuple(x.shape[1:])) if not x_shared else None
             res = epilogue.get("residual") if epilogue is not None else None
             for l in range(lanes):

@@ -321,7 +321,8 @@ class _VariationalNd(BaseVariationalLayer_):
             out = BF.contract_hip(kind, xin, mu_f, rho_f, mb, rb, plan["op"], _rng.seed(), sample_idx,
                                   self._btx_layer_id, prec=prec, extra_flags=_lib.FLAG_ROWFUSE, out_dtype=x.dtype,
                                   epilogue=epilogue, sampled_w=pre, sample_dev=getattr(self, "_btx_sample_dev", None),
-                                  lanes=lanes, lane_batch=lane_batch)
+                                  lanes=lanes, lane_batch=lane_batch,
+                                  self_sampling_weights=(lambda: BF.rowfuse_weights(mu_p, rho_p, plan)) if pre is not None else None)
             if epilogue is not None and epilogue.get("pool"):
                 return out  # pooled inside the launch (pool_fusable() vouched for the geometry)
             return out[:, :, :plan["Ho"], :plan["Wo"]]
@@ -345,21 +346,24 @@ class _VariationalNd(BaseVariationalLayer_):
     def _rowfuse_packed(self, x, plan, dtype):
         """the row-fused stem's input in its kernel layout (btx_rowfuse_pack).  mc.GraphedMC(static_input=True) vouches
         that the batch does not change between the MC samples it replays: the pack then happens once, at capture time,
-        instead of once per replay (GraphedMC.set_input() re-packs)."""
-        if not self.__dict__.get("_btx_static_x"):
+        instead of once per replay (GraphedMC.set_input() re-packs).  The packed copies belong to the GRAPH (`_btx_static_x`
+        is that graph's own {layer id: (key, tensor)} store): sibling graphs on one model never share or free each
+        other's buffers."""
+        store = self.__dict__.get("_btx_static_x")
+        if store is None or store is False:
             return BF.rowfuse_input(x, plan, dtype)
         key = (x.data_ptr(), tuple(x.shape), x.dtype, dtype)
-        st = self.__dict__.get("_btx_static_pack")
+        st = store.get(id(self))
         if st is None or st[0] != key:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.BtxError("static_input: the stem input must be packed before the capture starts")
             st = (key, BF.rowfuse_input(x, plan, dtype))
-            self.__dict__["_btx_static_pack"] = st
+            store[id(self)] = st
         return st[1]
 
-    def _static_repack(self, x):
+    def _static_repack(self, x, store):
         """mc.GraphedMC.set_input(): refill the packed copy the captured launches read (same buffer, new contents)"""
-        st = self.__dict__.get("_btx_static_pack")
+        st = store.get(id(self))
         if st is None or st[0][0] != x.data_ptr():
             return
         plan = self._rowfuse_plan(x)
@@ -568,8 +572,10 @@ class _VariationalLSTM(BaseVariationalLayer_):
             # device-resident sample index (mc.GraphedMC) or MC sample lanes pin one index for the whole forward, which
             # would reuse one (seed, sample, layer) draw for every step
             if X.is_cuda and steps > 1 and (lin.__dict__.get("_btx_lanes", 1) > 1 or getattr(lin, "_btx_sample_dev", None) is not None):
-                raise _lib.BtxError("LSTM layers need a fresh MC sample index per time step: run them with eager forwards "
-                                    "(mc.mc_forward(lanes=1)), not under mc.GraphedMC / MC sample lanes")
+                raise _lib.BtxError("LSTM layers need a fresh MC sample index per time step, but this layer's index is pinned "
+                                    "(MC sample lanes are set, or a live mc.GraphedMC keeps the index in a device word): "
+                                    "close() the GraphedMC / rng.set_sample_lanes(model, None), then run eager forwards "
+                                    "(mc.mc_forward(lanes=1))")
         if hidden_states is None:
             h_t = torch.zeros(nb, hs, device=X.device, dtype=X.dtype)
             c_t = torch.zeros(nb, hs, device=X.device, dtype=X.dtype)

@@ -113,11 +113,11 @@ def mc_forward(model, x, num_samples, sample_offset=0, with_kl=False, group=None
         else:
             # CPU tensors take the ATen route, whose noise comes from torch's generator (the reference's draw order): key
             # that generator on (seed, sample index) for the duration of the forward, so that sample s is the same draw on
-            # whichever rank evaluates it — the property the GPU path has by construction (BTX-RNG v1); the caller's
-            # generator state is left untouched
+            # whichever rank evaluates it — the property the GPU path has by construction (BTX-RNG v1); the caller's CPU
+            # generator state is restored by fork_rng and no CUDA generator is touched (torch.manual_seed would reseed them)
             _rng.set_sample_index(model, grp[0])
             with torch.random.fork_rng(devices=[]):
-                torch.manual_seed(_rng.cpu_sample_seed(grp[0]))
+                torch.default_generator.manual_seed(_rng.cpu_sample_seed(grp[0]))  # the CPU generator ONLY
                 logits = model(x)
         if isinstance(logits, tuple):
             logits = logits[0]
@@ -131,7 +131,8 @@ def mc_forward(model, x, num_samples, sample_offset=0, with_kl=False, group=None
             _rng.set_sample_index(model, sample_offset)
             shape = model(x).shape
         packed = torch.zeros(packed_numel(*shape), dtype=torch.float32, device=x.device)
-    if reduce and world > 1:
+    if reduce and dist.is_available() and dist.is_initialized() and (w0 > 1 or world == w0):
+        # also in a 1-rank group: the packed vector takes the same route (RCCL on a GPU) whatever the rank count
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return packed
 
@@ -198,6 +199,7 @@ class GraphedMC:
         self.model, self.x, self.kl, self.lanes = model, x, float(kl), int(lanes)
         self.lane_mode = lane_mode
         self.static_input = bool(static_input) and self.lanes > 1 and lane_mode == "launch"
+        self._static_packs = {}  # this graph's packed stem inputs {id(layer): (key, tensor)}: owned here, freed by close()
         if self.lanes > 1 and lane_mode == "launch":
             self._init_launch_lanes(warmup, keep_logits)
             return
@@ -279,7 +281,7 @@ class GraphedMC:
             d = m.__dict__
             if on:
                 d["_btx_lanes"], d["_btx_lane_batch"], d["_btx_sample_dev"] = self.lanes, self.bs, self.sample_dev
-                d["_btx_static_x"] = self.static_input
+                d["_btx_static_x"] = self._static_packs if self.static_input else None
             else:
                 d.pop("_btx_lanes", None)
                 d.pop("_btx_lane_batch", None)
@@ -327,7 +329,7 @@ class GraphedMC:
             with torch.no_grad():
                 for m in self._layers:
                     if hasattr(m, "_static_repack"):
-                        m._static_repack(self.x)
+                        m._static_repack(self.x, self._static_packs)
 
     def _lane(self, k):
         for m in self._layers:
@@ -368,6 +370,7 @@ class GraphedMC:
             m._btx_pre = None
             m.__dict__.pop("_btx_lanes", None)
             m.__dict__.pop("_btx_lane_batch", None)
-            m.__dict__.pop("_btx_static_x", None)
-            m.__dict__.pop("_btx_static_pack", None)
+            if m.__dict__.get("_btx_static_x") is self._static_packs:
+                m.__dict__.pop("_btx_static_x", None)
+        self._static_packs.clear()  # only this graph's buffers: sibling graphs keep theirs
         self._tiles = {}

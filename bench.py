@@ -480,7 +480,7 @@ class Runner:
                     logits = self.model(self.x)
                 else:  # ATen route (dry run): torch's generator keyed on the sample index, as mc.mc_forward does
                     with torch.random.fork_rng(devices=[]):
-                        torch.manual_seed(self._bt.rng.cpu_sample_seed(i))
+                        torch.default_generator.manual_seed(self._bt.rng.cpu_sample_seed(i))
                         logits = self.model(self.x)
                 self._mc.accumulate(self.packed, logits, self.kl)
             return
@@ -517,8 +517,9 @@ def timed_mc(runner, my_indices, warm_indices, world, dev, repeats=1):
             torch.cuda.synchronize(dev)
     runs = []
     with torch.no_grad():
+        grouped = dist.is_available() and dist.is_initialized()  # also a 1-rank group (torchrun --nproc-per-node 1)
         runner.run(warm_indices)
-        if world > 1:
+        if grouped:
             dist.all_reduce(runner.packed)  # warm the communicator too
         for _ in range(max(1, repeats)):  # the SAME timed region `repeats` times: a 20-step region is ~10 ms of GPU time
             runner.zero()
@@ -526,7 +527,7 @@ def timed_mc(runner, my_indices, warm_indices, world, dev, repeats=1):
             t0 = time.perf_counter()
             runner.run(my_indices)
             runner.fold()
-            if world > 1:
+            if grouped:
                 dist.all_reduce(runner.packed, op=dist.ReduceOp.SUM)
             barrier()
             runs.append(time.perf_counter() - t0)
@@ -808,7 +809,7 @@ def compact_line(out):
     (incl. traffic ratio, clock/power, the readings inside north_star's 1e-4) and `cpu_baseline`; per-launch tables,
     traffic breakdowns and prose stay in gpurun_out/bench_detail.json (also echoed to stderr)."""
     top = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "ms_per_step_runs",
-           "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "dry_run", "total_samples",
+           "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "dry_run", "total_samples", "collective",
            "kl_rel_err", "logits_rel_l2_vs_unfused_f32", "gpu_over_cpu", "sustained")
     line = {k: out[k] for k in top if k in out}
     cfg = out.get("config") or {}
@@ -1012,7 +1013,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_ranks = 1
-    if world > 1:
+    grouped = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
         rccl_ranks = dist.get_world_size()
@@ -1083,6 +1085,7 @@ def main():
             "metric": "MC-samples/sec (Bayesian-%s, 224^2, bs=%d)" % ("ResNet18" if args.arch == "resnet18" else "ResNet50",
                                                                       args.batch),
             "value": head["value"], "unit": "MC-samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "collective": "rccl all_reduce in the timed region" if grouped else "none (1 process, no group)",
             "steps": head["per_rank"], "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "ms_per_step_runs": head["ms_per_step_runs"], "timed_regions": len(head["ms_per_step_runs"]),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
@@ -1152,7 +1155,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         emit(out)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -61,7 +61,11 @@ extern "C" {
                              v_mfma_f32_32x32x16_bf16 per product (hi*hi + hi*lo + lo*hi), f32 accumulate: the f32 result of
                              the reference's F.conv*d / F.linear to ~1e-6 rel-L2 per layer (the tolerance north_star states is
                              1e-4) at a third of the bf16 matrix rate instead of a sixteenth.  Kernel family and workspace
-                             sizes are those of BTX_PREC_F32; sampled-weight tiles (btx_sample_weights) are specific to it. */
+                             sizes are those of BTX_PREC_F32; sampled-weight tiles (btx_sample_weights) are specific to it.
+                             RANGE: operands must be finite and below the bf16 maximum (|v| < 3.39e38): for +-inf, or a
+                             value whose hi rounds to inf, lo = rn(v - hi) = inf - inf = NaN and the product is NaN where the
+                             reference's f32 convolution gives inf or a finite value (the split is not guarded: it sits in
+                             the fragment-read path of the hot loop).  BTX_PREC_F32 has no such limit. */
 /* flags */
 #define BTX_FLAG_TRANSPOSED   1u  /* ConvTranspose gather rule */
 #define BTX_FLAG_KL_ACCUM     2u  /* btx_kl_gauss: add to *kl_out instead of overwriting */

@@ -248,3 +248,97 @@ def test_mc_distribution_matches_reference_fixture():
     print("MC distribution vs reference: max |z| %.2f, variance ratio %.2f..%.2f" % (z.max(), ratio.min(), ratio.max()))
     assert z.max() < 5.0, z.max()
     assert ratio.min() > 0.6 and ratio.max() < 1.6, (ratio.min(), ratio.max())
+
+
+# one layer per kernel family at the BASELINE batch, compared with the reference chain evaluated ON THE CPU (ATen / MKLDNN f32):
+# no GPU library sits between the HIP output and the reference arithmetic (conv_flipout.py:376-417, linear_flipout.py:149-174)
+CPU_CASES = [
+    # (name, class, kwargs, input shape, kernel family it lands on in bf16)
+    ("taps_56", "Conv2dFlipout", dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=False), (64, 64, 56, 56)),
+    ("taps_7", "Conv2dFlipout", dict(in_channels=512, out_channels=512, kernel_size=3, padding=1, bias=False), (64, 512, 7, 7)),
+    ("taps2_s2", "Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=3, stride=2, padding=1, bias=False), (64, 64, 56, 56)),
+    ("gemm8_pw", "Conv2dFlipout", dict(in_channels=512, out_channels=128, kernel_size=1, bias=False), (128, 512, 28, 28)),
+    ("dma_k64", "Conv2dFlipout", dict(in_channels=64, out_channels=256, kernel_size=1, bias=False), (128, 64, 56, 56)),
+    ("dma_n64", "Conv2dFlipout", dict(in_channels=256, out_channels=64, kernel_size=1, bias=False), (128, 256, 56, 56)),
+    ("stem", "Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (64, 3, 224, 224)),
+    ("fc", "LinearFlipout", dict(in_features=512, out_features=1000), (64, 512)),
+    ("reparam_28", "Conv2dReparameterization", dict(in_channels=128, out_channels=128, kernel_size=3, padding=1, bias=False), (64, 128, 28, 28)),
+]
+
+
+def _cpu_reference(layer, x, out_shape, sample, typ):
+    from oracle import bt_ref
+    nz = layer.materialize_noise(sample, tuple(x.shape), tuple(out_shape), x.dtype)
+    c = lambda t: None if t is None else t.detach().float().cpu()  # noqa: E731
+    mu, rho = layer._w()
+    if layer._op.nd == 0:
+        op = dict(kind="linear")
+    else:
+        op = dict(kind="conv", nd=2, stride=layer._op.stride[1:], padding=layer._op.padding[1:],
+                  dilation=layer._op.dilation[1:], groups=layer._op.groups)
+    mu_c = c(mu).contiguous()
+    rho_c = c(rho).contiguous()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        if typ == "flipout":
+            return bt_ref.flipout_forward(c(x).contiguous(), mu_c, rho_c, c(layer.mu_bias), c(layer.rho_bias), c(nz["eps_w"]).contiguous(),
+                                          c(nz.get("eps_b")), c(nz["sign_in"]).contiguous(), c(nz["sign_out"]).contiguous(), op)
+        return bt_ref.reparam_forward(c(x).contiguous(), mu_c, rho_c, c(layer.mu_bias), c(layer.rho_bias), c(nz["eps_w"]).contiguous(),
+                                      c(nz.get("eps_b")), op)
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("bf16", 1e-2)])
+@pytest.mark.parametrize("case", CPU_CASES, ids=[c[0] for c in CPU_CASES])
+def test_kernel_families_at_baseline_batch_vs_cpu_reference(case, prec, tol):
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    name, cls, kw, xshape = case
+    dev = _dev()
+    bt.manual_seed(2024)
+    torch.manual_seed(3)
+    layer = getattr(L, cls)(**kw).to(dev)
+    layer.precision = prec
+    act = torch.bfloat16 if prec == "bf16" else torch.float32
+    torch.manual_seed(1234)
+    x = torch.randn(*xshape).to(dev).to(act)
+    if len(xshape) == 4:
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        out = layer._forward_hip(x, sample_idx=9)
+        # the launch-lanes form of the same layer (what the bench replays): lane 1 of a 2-lane launch, same sample index
+        shared = kw.get("in_channels") == 3
+        bt.set_sample_lanes(layer, [8, 9], batch=xshape[0])
+        out2 = layer._forward_hip(x if shared else torch.cat([x, x], 0))[xshape[0]:]
+        bt.set_sample_lanes(layer, None)
+    torch.cuda.synchronize()
+    ref = _cpu_reference(layer, x, out.shape, 9, "flipout" if "Flipout" in cls else "reparam")
+    e1 = float((out.float().cpu() - ref).norm() / ref.norm())
+    e2 = float((out2.float().cpu() - ref).norm() / ref.norm())
+    print("%s %s batch %d vs CPU reference chain: rel-L2 %.3g (single launch) %.3g (lane of a 2-lane launch)" % (name, prec, xshape[0], e1, e2))
+    assert e1 < tol and e2 < tol, (name, prec, e1, e2)
+
+
+def test_stem_with_fused_bn_relu_maxpool_at_bs64_vs_cpu_reference():
+    """the one-launch stem of the bench (conv1 + eval-BN + ReLU + MaxPool2d(3,2,1), bf16) at batch 64 against the CPU chain:
+    reference conv_flipout.py:376-417 -> BatchNorm2d(eval) -> ReLU -> MaxPool2d, all ATen f32 on the host"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    dev = _dev()
+    bt.manual_seed(2024)
+    torch.manual_seed(3)
+    layer = L.Conv2dFlipout(3, 64, 7, stride=2, padding=3, bias=False).to(dev)
+    layer.precision = "bf16"
+    torch.manual_seed(1234)
+    x = torch.randn(64, 3, 224, 224).to(dev).to(torch.bfloat16)
+    scale = (0.5 + torch.rand(64)).to(dev)
+    shift = (0.1 * torch.randn(64)).to(dev)
+    assert layer.pool_fusable(x)
+    with torch.no_grad():
+        got = layer.forward_fused(x, scale, shift, None, True, pool=True)
+    torch.cuda.synchronize()
+    ref = _cpu_reference(layer, x, (64, 64, 112, 112), layer._btx_sample - 1, "flipout")
+    ref = torch.relu(ref * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1))
+    ref = torch.nn.functional.max_pool2d(ref, 3, 2, 1)
+    err = float((got.float().cpu() - ref).norm() / ref.norm())
+    print("stem + BN + ReLU + maxpool bf16 batch 64 vs CPU reference chain: rel-L2 %.3g" % err)
+    assert got.shape == (64, 64, 56, 56) and err < 1e-2, err

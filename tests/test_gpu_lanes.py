@@ -31,6 +31,9 @@ LAYER_CASES = [
     ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=1, stride=2, bias=False), (4, 64, 28, 28)),   # LDS-DMA kernel
     ("Conv2dFlipout", dict(in_channels=32, out_channels=32, kernel_size=5, padding=2, bias=False), (2, 32, 12, 12)),    # run-time-tap patch kernel
     ("Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 64, 64)),  # row-fused stem
+    # row-fused stem whose per-lane output is NOT a 16-byte multiple (1 x 9 x 9 x 6 bf16 = 972 B): the lanes fall back to
+    # single-sample launches, which must sample from the PADDED parameters although pre-sampled tiles were handed over
+    ("Conv2dFlipout", dict(in_channels=3, out_channels=6, kernel_size=7, stride=2, padding=3, bias=False), (1, 3, 18, 18)),
     ("Conv2dFlipout", dict(in_channels=64, out_channels=256, kernel_size=1, bias=False), (4, 64, 28, 28)),              # pointwise GEMM, resident stages
     ("Conv2dFlipout", dict(in_channels=256, out_channels=128, kernel_size=1, bias=True), (3, 256, 14, 14)),            # pointwise GEMM, streamed stages
     ("Conv2dFlipout", dict(in_channels=128, out_channels=256, kernel_size=1, stride=2, bias=False), (4, 128, 28, 28)),  # 8-wave GEMM, strided

@@ -484,6 +484,60 @@ def test_graphed_mc_replays_equal_eager_samples():
         bt.set_precision("f32")
 
 
+def test_sibling_static_input_graphs_own_their_packed_stem_inputs():
+    """two GraphedMC(static_input=True) on ONE model with different batches: each graph owns the packed copy of its stem
+    input (baked into its captured launches); closing one must leave the other replaying against live memory"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd.models.resnet import resnet18
+    from bayesian_torch_amd.models.fuse import fuse_resnet
+    dev = _dev()
+    bt.manual_seed(5)
+    torch.manual_seed(0)
+    m = resnet18()
+    bt.dnn_to_bnn(m, dict(PRIOR, type="Flipout"))
+    m = m.to(dev).eval()
+    bt.assign_layer_ids(m)
+    bt.set_precision("bf16")
+    try:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.to(torch.bfloat16)
+        fuse_resnet(m)
+        xa = torch.randn(2, 3, 224, 224, device=dev).to(torch.bfloat16)
+        xb = torch.randn(2, 3, 224, 224, device=dev).to(torch.bfloat16)
+        ga = mc.GraphedMC(m, xa, lanes=2, static_input=True, keep_logits=True)
+        gb = mc.GraphedMC(m, xb, lanes=2, static_input=True, keep_logits=True)
+        assert ga._static_packs and gb._static_packs and ga._static_packs is not gb._static_packs
+        pa = next(iter(ga._static_packs.values()))[1]
+        pb = next(iter(gb._static_packs.values()))[1]
+        assert pa.data_ptr() != pb.data_ptr()
+        ga.run_many([4, 9])
+        torch.cuda.synchronize()
+        want_a = [t.float().clone() for t in ga.lane_logits]
+        gb.run_many([4, 9])
+        torch.cuda.synchronize()
+        want_b = [t.float().clone() for t in gb.lane_logits]
+        assert not torch.equal(want_a[0], want_b[0])
+        gb.close()
+        junk = [torch.full((pb.numel(),), 7.0, dtype=pb.dtype, device=dev) for _ in range(4)]  # reuse freed blocks, if any
+        ga.run_many([4, 9])
+        torch.cuda.synchronize()
+        for w, t in zip(want_a, ga.lane_logits):
+            assert torch.equal(w, t.float())
+        assert ga._static_packs and next(iter(ga._static_packs.values()))[1].data_ptr() == pa.data_ptr()
+        # set_input() refills THIS graph's packed copy
+        ga.set_input(xb)
+        ga.run_many([4, 9])
+        torch.cuda.synchronize()
+        for w, t in zip(want_b, ga.lane_logits):
+            assert torch.equal(w, t.float())
+        ga.close()
+        del junk
+    finally:
+        bt.set_precision("f32")
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
