@@ -353,23 +353,31 @@ class ClockPowerSampler:
     def __init__(self, index=0):
         import glob
         import threading
-        self.power, self.sclk, self._stop, self._thr = [], [], threading.Event(), None
-        self.src = None
-        self._pfile = self._ffile = None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
-        if cards:
-            h = cards[min(index, len(cards) - 1)]
-            for n in ("power1_average", "power1_input"):
-                if os.path.exists(os.path.join(h, n)):
-                    self._pfile = os.path.join(h, n)
-                    break
-            self._ffile = os.path.join(h, "freq1_input")
+        self._stop, self._thr, self.src = threading.Event(), None, None
+        # the box's sysfs may list every GPU of the host while only the leased one is visible to HIP: match the PCI address
+        # of device `index`; when that cannot be read, sample every card and report the one drawing the most power
+        self.cards = []
+        for h in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*")):
+            if not os.path.exists(os.path.join(h, "freq1_input")):
+                continue
+            pf = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+            bdf = os.path.basename(os.path.realpath(os.path.join(h, "..", "..")))
+            self.cards.append({"bdf": bdf.lower(), "pfile": pf, "ffile": os.path.join(h, "freq1_input"), "power": [], "sclk": []})
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            hit = [c for c in self.cards if c["bdf"].startswith(want)]
+            if hit:
+                self.cards = hit
+        except Exception:  # noqa
+            pass
+        if self.cards:
             self.src = "hwmon"
         else:
             import shutil
             if shutil.which("rocm-smi"):
                 self.src = "rocm-smi"
+                self.cards = [{"bdf": "rocm-smi GPU[0]", "power": [], "sclk": []}]
         self._threading = threading
 
     def _poll(self):
@@ -377,19 +385,20 @@ class ClockPowerSampler:
         while not self._stop.is_set():
             try:
                 if self.src == "hwmon":
-                    if self._pfile:
-                        self.power.append(float(open(self._pfile).read()) * 1e-6)
-                    self.sclk.append(float(open(self._ffile).read()) * 1e-9)
+                    for c in self.cards:
+                        if c["pfile"]:
+                            c["power"].append(float(open(c["pfile"]).read()) * 1e-6)
+                        c["sclk"].append(float(open(c["ffile"]).read()) * 1e-9)
                     time.sleep(0.01)
                 else:
                     o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True,
                                        timeout=10).stdout
                     m = re.search(r"GPU\[0\].*?Power \(W\):\s*([0-9.]+)", o)
                     if m:
-                        self.power.append(float(m.group(1)))
+                        self.cards[0]["power"].append(float(m.group(1)))
                     m = re.search(r"GPU\[0\].*?sclk clock level:.*?\((\d+)Mhz\)", o)
                     if m:
-                        self.sclk.append(float(m.group(1)) * 1e-3)
+                        self.cards[0]["sclk"].append(float(m.group(1)) * 1e-3)
             except Exception:  # noqa
                 time.sleep(0.05)
 
@@ -405,12 +414,19 @@ class ClockPowerSampler:
             self._thr.join(timeout=15)
 
     def summary(self, skip=0.25):
-        """mean over the samples after the first `skip` share of the window (ramp-up)"""
+        """mean over the samples after the first `skip` share of the window (ramp-up); of several cards the busiest"""
         def mean(v):
             v = v[int(len(v) * skip):]
             return sum(v) / len(v) if v else None
-        return {"shader_clock_ghz": mean(self.sclk), "package_w": mean(self.power), "source": self.src,
-                "samples": len(self.sclk) or len(self.power)}
+        best = None
+        for c in self.cards:
+            p = mean(c["power"])
+            if best is None or (p or 0.0) > (best[0] or 0.0):
+                best = (p, mean(c["sclk"]), c)
+        if best is None:
+            return {"shader_clock_ghz": None, "package_w": None, "source": None, "samples": 0}
+        return {"shader_clock_ghz": best[1], "package_w": best[0], "source": self.src, "card": best[2]["bdf"],
+                "cards_sampled": len(self.cards), "samples": len(best[2]["sclk"]) or len(best[2]["power"])}
 
 
 def sustained_run(runner, lanes, dev, seconds=2.0):
