@@ -201,57 +201,82 @@ __global__ __launch_bounds__(256) void fill_sign_kernel(int8_t* __restrict__ out
 // -> mean(dim=0)  examples/main_bayesian_imagenet_dnn2bnn.py:483-499 ; predictive_entropy / mutual_information
 // utils/util.py:41-60.  One workgroup per batch row; the row is owned by that workgroup so no atomics.
 // ========================================================================================================
-// lanes > 1 (btx_mc_accumulate_lanes): the logits of `lanes` MC samples back to back ([lanes][bs][C]); the workgroup that
-// owns a batch row folds its lanes in order — the same additions, in the same order, as `lanes` single-sample launches
+// lanes > 1 (btx_mc_accumulate_lanes): the logits of `lanes` MC samples back to back ([lanes][bs][C]).  A workgroup owns a
+// batch row; its sixteen waves take the lanes round-robin — one wave computes one lane's softmax row (probabilities into LDS, the
+// lane's entropy beside them) with no workgroup barrier — then every thread adds its columns' probabilities lane by lane IN
+// ORDER: the same additions, in the same order, as `lanes` single-sample launches (which run this very code with one lane),
+// at a sixteenth of the serial depth (20 lanes: 78 -> ~20 us per replay of the bench).  The per-row reductions keep a fixed
+// shape — 256 "virtual threads" (4 per thread: column v + 256 k), a shuffle tree per virtual wave, ((r0 + r1) + r2) + r3 — so a
+// row's figures do not depend on which wave computed it.  LDS: min(lanes, LC) x C floats; more lanes run in chunks of LC.
 template <typename ACT>
-__global__ __launch_bounds__(256) void mc_accumulate_kernel(const ACT* __restrict__ logits, int bs, int C, float kl,
-                                                            float* __restrict__ packed, int lanes) {
+__global__ __launch_bounds__(1024) void mc_accumulate_kernel(const ACT* __restrict__ logits, int bs, int C, float kl,
+                                                            float* __restrict__ packed, int lanes, int LC) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) unsigned char mc_smem[];
+  float* const pr_lds = (float*)mc_smem;            // [LC][C]
+  float* const ent_lds = pr_lds + (size_t)LC * C;   // [LC]
   const int row = blockIdx.x;
-  __shared__ float red[4];
-  __shared__ float bc;
-  for (int ln = 0; ln < lanes; ++ln) {
-    const ACT* lr = logits + ((size_t)ln * bs + row) * C;
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, (float)lr[c]);
+  const int wave = threadIdx.x >> 6, li = threadIdx.x & 63;
+  float* const sp = packed + (size_t)row * C;
+  float* const sp2 = packed + (size_t)bs * C + (size_t)row * C;
+  for (int l0 = 0; l0 < lanes; l0 += LC) {
+    const int nl = min(LC, lanes - l0);
+    for (int k = wave; k < nl; k += 16) {  // wave-uniform
+      const ACT* lr = logits + ((size_t)(l0 + k) * bs + row) * C;
+      float* const pk = pr_lds + (size_t)k * C;
+      float mx = -INFINITY;
+      for (int c = li; c < C; c += 64) mx = fmaxf(mx, (float)lr[c]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    mx = bc;
-    float se = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) se += expf((float)lr[c] - mx);
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float se[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) se += __shfl_down(se, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
-    __syncthreads();
-    if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
-    const float inv = 1.0f / bc;
-    float ent = 0.f;
-    float* sp = packed + (size_t)row * C;
-    float* sp2 = packed + (size_t)bs * C + (size_t)row * C;
-    for (int c = threadIdx.x; c < C; c += 256) {
-      const float pr = expf((float)lr[c] - mx) * inv;
-      sp[c] += pr;
-      sp2[c] += pr * pr;
-      ent -= pr * logf(pr + 1e-15f);  // utils/util.py:44 epsilon
+      for (int j = 0; j < 4; ++j)
+        for (int c = j * 64 + li; c < C; c += 256) se[j] += expf((float)lr[c] - mx);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) se[j] += __shfl_down(se[j], off, 64);
+      const float tot = __shfl(((se[0] + se[1]) + se[2]) + se[3], 0, 64);
+      const float inv = 1.0f / tot;
+      float en[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        for (int c = j * 64 + li; c < C; c += 256) {
+          const float pv = expf((float)lr[c] - mx) * inv;
+          pk[c] = pv;
+          const float t = pv * logf(pv + 1e-15f);  // utils/util.py:44 epsilon
+          en[j] -= t;
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) en[j] += __shfl_down(en[j], off, 64);
+      if (li == 0) ent_lds[k] = ((en[0] + en[1]) + en[2]) + en[3];
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ent += __shfl_down(ent, off, 64);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ent;
-    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 1024) {
+      float a = sp[c], a2 = sp2[c];
+      for (int k = 0; k < nl; ++k) {
+        const float pv = pr_lds[(size_t)k * C + c];
+        a += pv;
+        const float q = pv * pv;
+        a2 += q;
+      }
+      sp[c] = a;
+      sp2[c] = a2;
+    }
     if (threadIdx.x == 0) {
-      packed[(size_t)2 * bs * C + row] += red[0] + red[1] + red[2] + red[3];
+      float e = packed[(size_t)2 * bs * C + row];
+      for (int k = 0; k < nl; ++k) e += ent_lds[k];
+      packed[(size_t)2 * bs * C + row] = e;
       if (row == 0) {
-        packed[(size_t)2 * bs * C + bs] += kl;
-        packed[(size_t)2 * bs * C + bs + 1] += 1.0f;
+        float a = packed[(size_t)2 * bs * C + bs], n = packed[(size_t)2 * bs * C + bs + 1];
+        for (int k = 0; k < nl; ++k) { a += kl; n += 1.0f; }
+        packed[(size_t)2 * bs * C + bs] = a;
+        packed[(size_t)2 * bs * C + bs + 1] = n;
       }
     }
+    __syncthreads();  // the next chunk overwrites the LDS rows
   }
 }
 
@@ -1173,6 +1198,7 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   }
 
   if (const char* tp = tune_env("BTX_TRACE_PTR")) p.trace = (void*)strtoull(tp, nullptr, 0);  // BTX_PT_TRACE builds only
+  p.pt_nopw = tune_env("BTX_NO_DMA_PW") ? 1 : 0;
   p.pt_nw = dma_nw;
   p.fd_inner = make_fastdiv((uint32_t)(pl.ntiles * g->groups * pl.ksplits)); p.fd_ksplits = make_fastdiv((uint32_t)pl.ksplits);
   p.fd_ntiles = make_fastdiv((uint32_t)pl.ntiles); p.fd_rtiles = make_fastdiv(1u);
@@ -1496,13 +1522,24 @@ int btx_mc_accumulate_lanes(const void* logits, int lanes, int bs, int C, int ac
   if (!logits || !packed) return BTX_E_NULL;
   if (bs <= 0 || C <= 0 || lanes <= 0) return BTX_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if (act_dtype == BTX_ACT_F32)
-    hipLaunchKernelGGL(mc_accumulate_kernel<float>, dim3(bs), dim3(256), 0, st, (const float*)logits, bs, C, kl, packed,
-                       lanes);
-  else if (act_dtype == BTX_ACT_BF16)
-    hipLaunchKernelGGL(mc_accumulate_kernel<__bf16>, dim3(bs), dim3(256), 0, st, (const __bf16*)logits, bs, C, kl,
-                       packed, lanes);
-  else
+  // lanes per LDS chunk: up to 96 KiB of probabilities (the default dynamic-LDS limit needs no opt-in below 64 KiB; above it
+  // the attribute is set once per instantiation)
+  const size_t per_lane = (size_t)C * 4 + 4;
+  int LC = (int)((size_t)98304 / per_lane);
+  if (LC < 1) return BTX_E_UNSUPPORTED;  // a row of > 24 575 classes does not fit a chunk
+  if (LC > lanes) LC = lanes;
+  const size_t lds = (size_t)LC * per_lane;
+  if (act_dtype == BTX_ACT_F32) {
+    static bool attr_f = false;
+    if (!attr_f) { (void)hipFuncSetAttribute((const void*)mc_accumulate_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304 + 64); attr_f = true; }
+    hipLaunchKernelGGL(mc_accumulate_kernel<float>, dim3(bs), dim3(1024), lds, st, (const float*)logits, bs, C, kl, packed,
+                       lanes, LC);
+  } else if (act_dtype == BTX_ACT_BF16) {
+    static bool attr_b = false;
+    if (!attr_b) { (void)hipFuncSetAttribute((const void*)mc_accumulate_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304 + 64); attr_b = true; }
+    hipLaunchKernelGGL(mc_accumulate_kernel<__bf16>, dim3(bs), dim3(1024), lds, st, (const __bf16*)logits, bs, C, kl,
+                       packed, lanes, LC);
+  } else
     return BTX_E_DTYPE;
   return (int)hipGetLastError();
 }

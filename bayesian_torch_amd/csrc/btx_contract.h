@@ -128,6 +128,7 @@ struct ContractParams {
   int pt_nw, pt_astage, pt_lds;
   int pt_mi;      // patch variant: 32-pixel MFMA tiles per wave (2 | 4)
   int pt_tune;    // BTX_PT_TRACE builds: bit 6 = report the per-stage split instead of the phase timers
+  int pt_nopw;    // tuning builds (BTX_NO_DMA_PW=1): the generic LDS-DMA kernel for pointwise shapes too (A/B)
   int pt_kg;      // tap-unrolled kernel: K-groups per workgroup (1 | 2)
   int pt_lds_g;   //                      LDS bytes of one K-group
   int pt_taps;    // 10*KH + KW when the tap-unrolled kernel (btx_contract_taps.h) takes the launch, else 0

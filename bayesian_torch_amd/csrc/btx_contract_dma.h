@@ -92,7 +92,13 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 }
 #undef BTX_VM
 
-template <int PREC, int KIND, int NW>
+// PW: the pointwise form (Linear, 1x1 convolutions at stride 1 without padding, hashed or explicit signs on whole words: the
+// K = 64 / N = 64 convolutions of every ResNet50 bottleneck and the classifier heads).  Output pixel m IS input pixel m and the
+// one tap is always valid, so the geometry decode, the tap masks, the (kd, kh, kw) walk and the transposed gather rule are not
+// even compiled: the generic instantiation keeps ~40 launch parameters alive across its K loop, which hipcc spills into VGPR
+// lanes (733 v_readlane + 180 v_writelane in the bf16 Flipout kernel's ISA); this one reads seven.  Same arithmetic, same
+// order: bit-identical to the generic form (tests/test_gpu_contract.py).
+template <int PREC, int KIND, int NW, bool PW = false>
 __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const ContractParams) {
   BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   using LD = DmaLds<NW>;
@@ -169,23 +175,24 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   // Pointwise contractions (Linear, 1x1 convolutions at stride 1: 37 of the 53 convolutions of a ResNet50): output pixel m
   // IS input pixel m — no (n, d, h, w) decode, every tap (there is one) valid.  The decode below was 3.4k of the 7.3k
   // prologue cycles of a block whose K loop (K = 64) takes 2.3k (phase timers, round 3).
-  const bool pointwise = p.pointwise != 0;  // wave-uniform
+  const bool pointwise = PW || (p.pointwise != 0);  // wave-uniform
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int mq = mtile * TP + wave * 64 + q * 16 + (lane >> 2);
     pb_ok[q] = mq < p.M;
-    if (pointwise) {
+    if (PW || pointwise) {
       pb_d[q] = pb_h[q] = pb_w[q] = pb_n[q] = 0;
       pb_off[q] = (uint32_t)(pb_ok[q] ? mq : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
     } else {
-      decode(pb_ok[q] ? mq : 0, pb_d[q], pb_h[q], pb_w[q], pb_n[q], pb_off[q]);
+      if constexpr (!PW) decode(pb_ok[q] ? mq : 0, pb_d[q], pb_h[q], pb_w[q], pb_n[q], pb_off[q]);
     }
   }
   // tap validity, one bitmask per axis and pixel (bit k: tap k of that axis reads inside the input), computed once per
   // workgroup with KD + KH + KW iterations; a tap is valid iff its three bits are set
-  const bool use_mask = (p.KD <= 32) && (p.KH <= 32) && (p.KW <= 32) && !p.transposed;  // uniform
+  const bool use_mask = !PW && (p.KD <= 32) && (p.KH <= 32) && (p.KW <= 32) && !p.transposed;  // uniform
   uint32_t md[4] = {0u, 0u, 0u, 0u}, mh[4] = {0u, 0u, 0u, 0u}, mw[4] = {0u, 0u, 0u, 0u};
-  if (pointwise) {
+  if constexpr (PW) {
+  } else if (pointwise) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) { md[q] = pb_ok[q] ? 1u : 0u; mh[q] = 1u; mw[q] = 1u; }
   } else if (use_mask) {
@@ -211,13 +218,15 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   {
     const int m = mtile * TP + tid;
     int a_, b_, c_, d_;
-    if (pointwise) sg_off = (uint32_t)(m < p.M ? m : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
-    else decode(m < p.M ? m : 0, a_, b_, c_, d_, sg_off);
+    if (PW || pointwise) sg_off = (uint32_t)(m < p.M ? m : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+    else if constexpr (!PW) decode(m < p.M ? m : 0, a_, b_, c_, d_, sg_off);
   }
 
   // wave-uniform K walk: channel offset inside the tap and the tap itself
   int s_c, s_kd, s_kh, s_kw, s_tap;
-  {
+  if constexpr (PW) {  // one tap: the walk is the channel offset alone
+    s_c = k_begin; s_kd = s_kh = s_kw = s_tap = 0;
+  } else {
     uint32_t tap, c0, t2, kw0, kd0, kh0;
     fdivmod((uint32_t)k_begin, p.fd_Cg, (uint32_t)p.Cg, tap, c0);
     fdivmod(tap, p.fd_KW, (uint32_t)p.KW, t2, kw0);
@@ -231,7 +240,8 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   auto issue_acts = [&]() __attribute__((always_inline)) {  // stages in order: the K walk advances by one stage per call
     // activations: one tap for the whole stage; tap_off is wave-uniform
     uint32_t tap_off = 0;
-    if (!p.transposed)
+    if constexpr (PW) tap_off = (uint32_t)s_c;
+    else if (!p.transposed)
       tap_off = (uint32_t)(((s_kd * p.dd) * p.H + s_kh * p.dh) * p.W + s_kw * p.dw) * (uint32_t)p.C + (uint32_t)s_c;
     const uint32_t tap_boff = tap_off * (uint32_t)sizeof(ACT);
     unsigned char* as = smem + DA_OFF + a_slot_issue * DA_STAGE + wave * 4096;
@@ -239,7 +249,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     for (int q = 0; q < 4; ++q) {
       bool ok;
       uint32_t bo;
-      if (use_mask) {
+      if constexpr (PW) {
+        ok = pb_ok[q];
+        bo = pb_boff[q] + tap_boff;
+      } else if (use_mask) {
         ok = ((md[q] >> s_kd) & (mh[q] >> s_kh) & (mw[q] >> s_kw) & 1u) != 0u;
         bo = pb_boff[q] + tap_boff;
       } else if (!p.transposed) {
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
       // one hashed word covers the 32 (bf16) / 16 (f32) channels of pixel `tid`'s stage.  (In the padding the
       // activations are zero, so the word is irrelevant there.  Transposed: recompute the input offset.)
       uint32_t off = sg_off + tap_off;
-      if (p.transposed) {
+      if (!PW && p.transposed) {
         const int m = mtile * TP + tid;
         int bd_, bh_, bw_, nb_;
         uint32_t o_;
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
       // starts at element offset e0 inside the word needs the word shifted left by e0>>1 within each 16-bit half
       const uint32_t n_in = p.x_bytes / (uint32_t)sizeof(ACT);
       uint32_t w = p.sign_in ? sign_word_explicit(p.sign_in, off, n_in) : btx_sign_word(off >> 5, rl.kin_a, rl.kin_b);
-      if (p.sign_unaligned) {  // uniform: the stage may run into the next word (row-fused stems)
+      if (!PW && p.sign_unaligned) {  // uniform: the stage may run into the next word (row-fused stems)
         const uint32_t w1 = p.sign_in ? sign_word_explicit(p.sign_in, off + 32u, n_in)
                                       : btx_sign_word((off >> 5) + 1u, rl.kin_a, rl.kin_b);
         const uint32_t k = (off & 31u) >> 1;
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     }
     // advance the K walk by one stage
     s_c += BK;
-    if (s_c >= p.Cg) {
+    if (!PW && s_c >= p.Cg) {
       s_c = 0;
       ++s_tap;
       if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; ++s_kd; } }
@@ -415,9 +428,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
 
 template <int PREC>
 static int launch_contract_dma_impl(int kind, const ContractParams& p, int nwg, hipStream_t st) {
-#define BTX_LAUNCH_DMA(KIND, NW)                                                                                        \
+#define BTX_LAUNCH_DMA(KIND, NW, PW)                                                                                    \
   do {                                                                                                                  \
-    auto kfn = contract_dma_kernel<PREC, KIND, NW>;                                                                     \
+    auto kfn = contract_dma_kernel<PREC, KIND, NW, PW>;                                                                 \
     static bool attr_done = false;                                                                                      \
     if (!attr_done) {                                                                                                   \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, DmaLds<NW>::BYTES); \
@@ -428,8 +441,11 @@ static int launch_contract_dma_impl(int kind, const ContractParams& p, int nwg, 
   } while (0)
   int rc = launch_presample_impl<PREC>(kind, p, st);
   if (rc) return rc;
-  if (p.pt_nw == 4) { if (kind == 0) BTX_LAUNCH_DMA(0, 4); else BTX_LAUNCH_DMA(1, 4); }
-  else { if (kind == 0) BTX_LAUNCH_DMA(0, 8); else BTX_LAUNCH_DMA(1, 8); }
+  // the pointwise form where its contract holds (two workgroups per CU: the shapes that are all prologue and store side)
+  const bool pw = p.pointwise && !p.transposed && !p.sign_unaligned && p.pt_nw == 4 && !p.pt_nopw;
+  if (pw) { if (kind == 0) BTX_LAUNCH_DMA(0, 4, true); else BTX_LAUNCH_DMA(1, 4, true); }
+  else if (p.pt_nw == 4) { if (kind == 0) BTX_LAUNCH_DMA(0, 4, false); else BTX_LAUNCH_DMA(1, 4, false); }
+  else { if (kind == 0) BTX_LAUNCH_DMA(0, 8, false); else BTX_LAUNCH_DMA(1, 8, false); }
 #undef BTX_LAUNCH_DMA
   return (int)hipGetLastError();
 }

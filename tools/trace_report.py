@@ -21,6 +21,18 @@ def main():
         lines.append("%-90s %8d %12.1f %10.2f %10.2f %10.2f %6.2f" % (kn[:90], n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3,
                                                                   100.0 * tot / total))
     lines.append("TOTAL kernel time %.3f ms over %d dispatches" % (total / 1e6, sum(r[1] for r in rows)))
+    if "--sequence" in sys.argv:
+        # the last N dispatches in launch order (N = the argument): one steady-state replay, kernel by kernel
+        n_last = int(sys.argv[sys.argv.index("--sequence") + 1])
+        seq = cur.execute(f"""select s.kernel_name, d.start, d.end from '{disp}' d join '{sym}' s on s.id = d.kernel_id
+                               order by d.start desc limit {n_last}""").fetchall()[::-1]
+        lines.append("last %d dispatches in order (us; gap = idle time since the previous kernel ended):" % len(seq))
+        prev = None
+        for kn, st, en in seq:
+            short = kn.split("(")[0][-70:]
+            lines.append("  %-70s %10.2f  gap %8.2f" % (short, (en - st) / 1e3, 0.0 if prev is None else (st - prev) / 1e3))
+            prev = en
+        lines.append("  span %.2f us, busy %.2f us" % ((seq[-1][2] - seq[0][1]) / 1e3, sum(e - s_ for _, s_, e in seq) / 1e3))
     txt = "\n".join(lines)
     print(txt)
     if "--out" in sys.argv:
