@@ -29,7 +29,7 @@
 #include "btx_contract_taps.h"
 #include "btx_contract_taps2.h"
 #if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
-#include "btx_contract_taps3.h"  // persistent form: measurement builds only
+#include "../../tools/experimental/btx_contract_taps3.h"  // persistent form: measured and parked, measurement builds only
 #endif
 
 namespace btx {

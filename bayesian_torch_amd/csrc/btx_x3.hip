@@ -6,7 +6,7 @@
 #include "btx_contract_dma.h"
 #include "btx_contract_gemm8.h"
 #if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
-#include "btx_contract_pw.h"  // measured and parked: see btx_api.hip
+#include "../../tools/experimental/btx_contract_pw.h"  // measured and parked: see btx_api.hip
 #endif
 namespace btx {
 int launch_contract_patch_x3(int kind, const ContractParams& p, int nwg, hipStream_t st) {
