@@ -14,7 +14,7 @@ FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_
 FLAG_REVERSE = 256
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 FLAG_LANES_SHIFT = 16
 SAMPLE_SKIP_MU = 1
 
@@ -64,7 +64,8 @@ class KlItem(ctypes.Structure):
 EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_gauss", "btx_kl_model_workspace_bytes",
            "btx_kl_gauss_model", "btx_kl_gauss_model_bwd", "btx_contract_wgrad",
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_fwd_lanes", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign", "btx_rho_grad",
-           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_mc_accumulate_lanes", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl")
+           "btx_mc_packed_floats", "btx_mc_accumulate", "btx_mc_accumulate_lanes", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl",
+           "btx_bn_workspace_bytes", "btx_bn_train_fwd", "btx_bn_train_bwd")
 
 
 def lib_path():
@@ -140,6 +141,13 @@ def lib():
     L.btx_mc_accumulate.argtypes = [vp, i32, i32, i32, f32, vp, vp]
     L.btx_mc_accumulate_lanes.restype = i32
     L.btx_mc_accumulate_lanes.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
+    i64 = ctypes.c_longlong
+    L.btx_bn_workspace_bytes.restype = sz
+    L.btx_bn_workspace_bytes.argtypes = [i64, i32]
+    L.btx_bn_train_fwd.restype = i32
+    L.btx_bn_train_fwd.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, sz, vp]
+    L.btx_bn_train_bwd.restype = i32
+    L.btx_bn_train_bwd.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32, vp, vp, vp, vp, vp, sz, vp]
     if L.btx_abi_version() != ABI_VERSION:
         raise BtxError("libbtx.so ABI %d != expected %d" % (L.btx_abi_version(), ABI_VERSION))
     _LIB = L

@@ -228,3 +228,100 @@ def kl_of_layers(layers):
     if torch.is_grad_enabled() and any(t.requires_grad for t in params):
         return KlFn.apply(meta, *params)
     return BF.kl_model_hip(_entries(meta, params))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# training-mode BatchNorm on channels-last activations (csrc/btx_bn.hip, btx_bn_train_fwd / _bwd): the step either side of
+# the variational convolutions in the reference's training loop (README.md:114-125 on models/deterministic/resnet_large.py)
+# --------------------------------------------------------------------------------------------------------------------
+def _act_code(dt):
+    return _lib.ACT_BF16 if dt == torch.bfloat16 else _lib.ACT_F32
+
+
+def bn_train_usable(bn, x):
+    """True when nn.BatchNorm{1,2,3}d `bn` in training mode on `x` can take the HIP kernels: CUDA tensor, f32 / bf16,
+    channels-last storage (or 2-D [M, C]), C % 8 == 0, parameters and running estimates of one dtype (f32 or bf16)."""
+    if not (bn.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() in (2, 4, 5)):
+        return False
+    C = x.shape[1]
+    if C % 8 != 0 or C > 2048 or x.numel() == 0 or x.numel() // C < 2:
+        return False
+    if bn.momentum is None and bn.track_running_stats:
+        return False  # cumulative moving average: torch's own path
+    ts = [t for t in (bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                      bn.running_var if bn.track_running_stats else None) if t is not None]
+    if ts and (any(t.dtype != ts[0].dtype for t in ts) or ts[0].dtype not in (torch.float32, torch.bfloat16)):
+        return False
+    if x.dim() == 2 and not x.is_contiguous():
+        return False
+    if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    if x.dim() == 5 and not x.is_contiguous(memory_format=torch.channels_last_3d):
+        return False
+    return True
+
+
+class BatchNormTrainFn(torch.autograd.Function):
+    """y = batch_norm(x) with batch statistics; running_mean / running_var updated in place (as F.batch_norm does)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        L = _lib.lib()
+        C = x.shape[1]
+        M = x.numel() // C
+        dev = x.device
+        y = torch.empty_like(x)  # preserves the channels-last strides
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = BF._workspace(dev, L.btx_bn_workspace_bytes(M, C), stream)
+        ref = next((t for t in (weight, bias, running_mean, running_var) if t is not None), None)
+        pdt = _act_code(ref.dtype) if ref is not None else _lib.ACT_F32
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        w = weight.detach().contiguous() if weight is not None else None
+        b = bias.detach().contiguous() if bias is not None else None
+        _lib.check(L.btx_bn_train_fwd(x.data_ptr(), y.data_ptr(), _act_code(x.dtype), M, C, ptr(w), ptr(b), ptr(running_mean),
+                                      ptr(running_var), pdt, float(momentum if momentum is not None else 0.0), float(eps),
+                                      save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        ctx.save_for_backward(x, w, save_mean, save_invstd)
+        ctx.has_bias = bias is not None
+        ctx.pdt = pdt
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, save_mean, save_invstd = ctx.saved_tensors
+        C = x.shape[1]
+        M = x.numel() // C
+        dev = x.device
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        # the gradient in the layout of x (channels-last storage): a no-op when the consumer produced it that way
+        if x.dim() == 4:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        elif x.dim() == 5:
+            dy = dy.contiguous(memory_format=torch.channels_last_3d)
+        else:
+            dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = BF._workspace(dev, L.btx_bn_workspace_bytes(M, C), stream)
+        _lib.check(L.btx_bn_train_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_code(x.dtype), M, C,
+                                      w.data_ptr() if w is not None else None, ctx.pdt, save_mean.data_ptr(),
+                                      save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      stream))
+        gw = dgamma.to(w.dtype) if (w is not None and ctx.needs_input_grad[1]) else None
+        gb = dbeta.to(w.dtype if w is not None else torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return (dx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None
+
+
+def batch_norm_train(bn, x):
+    """training-mode forward of the nn.BatchNorm module `bn` through libbtx (bn_train_usable(bn, x) must hold)"""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return BatchNormTrainFn.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)

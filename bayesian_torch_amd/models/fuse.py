@@ -140,3 +140,25 @@ def fuse_resnet(model):
         model.forward = types.MethodType(fwd, model)
         n += 1
     return n
+
+
+def hip_batchnorm(model):
+    """Route the TRAINING-mode forward (and backward) of every nn.BatchNorm{1,2,3}d of `model` through libbtx
+    (csrc/btx_bn.hip) whenever the call qualifies — CUDA, f32 / bf16, channels-last storage, C % 8 == 0
+    (autograd.bn_train_usable) — and leave everything else (eval mode, CPU, other layouts) to torch.  The module tree,
+    parameters, buffers and state_dict keys are untouched; results match F.batch_norm to rounding.  The reference's training
+    loop (README.md:114-125) spends a third of a ResNet18 step in ATen's channels-last BatchNorm kernels."""
+    from .. import autograd as _ag
+    n = 0
+    for m in model.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm) and "_btx_bn_orig" not in m.__dict__:
+            orig = m.forward
+
+            def fwd(self, x, _orig=orig):
+                if _ag.bn_train_usable(self, x):
+                    return _ag.batch_norm_train(self, x)
+                return _orig(x)
+            object.__setattr__(m, "_btx_bn_orig", orig)
+            m.forward = types.MethodType(fwd, m)
+            n += 1
+    return n

@@ -698,6 +698,8 @@ def run_train_step(dev, steps=5):
     bt.manual_seed(2024)
     bt.set_precision("bf16")
     model = build_model("Flipout", dev, torch.bfloat16, fuse=False).train()
+    from bayesian_torch_amd.models.fuse import hip_batchnorm
+    hip_batchnorm(model)  # training-mode BatchNorm through libbtx (csrc/btx_bn.hip); the f32 parity reference below keeps torch's
     torch.manual_seed(1234)
     x = torch.randn(64, 3, 224, 224, device=dev).to(torch.bfloat16)
     y = torch.randint(0, 1000, (64,), device=dev)
@@ -752,7 +754,7 @@ def run_train_step(dev, steps=5):
     # each; the stem counted with its own 7x7x3 taps, not the padded row-fused geometry)
     gflop = 464.4 + (464.4 - 30.2) + 464.4
     return {"workload": "training step (README.md:114-125): dnn_to_bnn(ResNet18) Flipout bs64, bf16 activations, forward + "
-                        "CE + KL/B + backward through libbtx (f32-MFMA weight gradients), eager launches",
+                        "CE + KL/B + backward through libbtx (bf16-MFMA weight gradients, HIP BatchNorm), eager launches",
             "ms_per_step": ms, "achieved_tflops": gflop / ms, "loss_finite": bool(torch.isfinite(loss)),
             "parity_vs_f32_mode": parity}
 

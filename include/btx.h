@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BTX_ABI_VERSION 6
+#define BTX_ABI_VERSION 7
 
 /* argument-error codes (negative) */
 #define BTX_E_NULL        (-1)   /* required pointer is NULL */
@@ -321,6 +321,23 @@ int btx_rowfuse_pack(const void* x, int in_dtype, const int64_t* strides_ncHW_ho
  * -> [NB][Ho][Wo][C], C % 8 == 0, 2*pad <= k; identical results to torch (max is exact). */
 int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, int C, int k, int stride, int pad,
                      void* stream);
+
+/* §8(f)-4, the step either side of the path in the reference's TRAINING loop (README.md:114-125 on
+ * models/deterministic/resnet_large.py:46-62: conv -> bn -> relu under model.train()): torch.nn.BatchNorm2d in training mode on
+ * channels-last activations x[M][C] (M = N*H*W), ABI 7.  Forward: batch mean / biased variance per channel (f64 fold of per-block
+ * f32 sums, fixed order), y = (x - mean) * invstd * gamma + beta, running_mean / running_var updated as torch does
+ * (running = (1 - momentum) * running + momentum * batch, unbiased variance), save_mean / save_invstd (f32 [C]) for the backward.
+ * Backward: dgamma = sum(dy * xhat), dbeta = sum(dy) (f32 [C]), dx = gamma * invstd * (dy - dbeta / M - xhat * dgamma / M).
+ * x / y / dy / dx: act_dtype (BTX_ACT_F32 | BTX_ACT_BF16), 16-byte aligned; gamma, beta, running_*: param_dtype (same codes),
+ * each nullable (affine=False / track_running_stats=False); C % 8 == 0, C <= 2048 (else BTX_E_UNSUPPORTED: the caller keeps
+ * torch's own kernels).  Three launches per call on `stream`, workspace btx_bn_workspace_bytes(M, C). */
+size_t btx_bn_workspace_bytes(long long M, int C);
+int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, const void* gamma, const void* beta,
+                     void* running_mean, void* running_var, int param_dtype, float momentum, float eps, float* save_mean,
+                     float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+int btx_bn_train_bwd(const void* x, const void* dy, void* dx, int act_dtype, long long M, int C, const void* gamma,
+                     int param_dtype, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* ws,
+                     size_t ws_bytes, void* stream);
 
 /* Global average pooling in front of the classifier (resnet_large.py: AdaptiveAvgPool2d((1,1))): channels-last
  * [NB][HW][C] -> [NB][C], f32 accumulation in a fixed order, C % 8 == 0. */

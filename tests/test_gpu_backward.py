@@ -351,3 +351,101 @@ def test_backward_at_baseline_size_every_resnet18_layer_shape(prec, act, bar):
         print("backward at size (%s): worst rel-L2 %s" % (prec, {k_: "%.3g" % v for k_, v in worst.items()}))
     finally:
         bt.set_precision("f32")
+
+
+# ---- training-mode BatchNorm through libbtx (csrc/btx_bn.hip): forward, running estimates, backward vs torch's own BatchNorm ----
+BN_CASES = [((8, 64, 56, 56), torch.float32, 2e-5), ((64, 64, 56, 56), torch.bfloat16, 1e-2), ((16, 512, 7, 7), torch.bfloat16, 1e-2),
+            ((4, 24, 9, 11), torch.float32, 2e-5), ((3, 2048, 2, 2), torch.bfloat16, 1e-2), ((300, 128), torch.float32, 2e-5)]
+
+
+@pytest.mark.parametrize("shape,dtype,tol", BN_CASES, ids=["%s-%s" % ("x".join(map(str, c[0])), str(c[1]).split(".")[-1]) for c in BN_CASES])
+def test_hip_batchnorm_training_matches_torch(shape, dtype, tol):
+    """BatchNorm in training mode on channels-last activations: y, running_mean / running_var / num_batches_tracked, dx, dgamma,
+    dbeta against torch.nn.BatchNorm (f32 arithmetic on the SAME, dtype-rounded, inputs).  bf16: outputs are rounded once to bf16
+    (bar 1e-2 rel-L2, measured ~3e-3); f32: 2e-5."""
+    from bayesian_torch_amd.models.fuse import hip_batchnorm
+    from bayesian_torch_amd import autograd as ag
+    dev = _dev()
+    torch.manual_seed(5)
+    C = shape[1]
+    cls = torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d
+    bn = cls(C, momentum=0.1).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(C))
+        bn.bias.copy_(0.2 * torch.randn(C))
+        bn.running_mean.copy_(0.1 * torch.randn(C))
+        bn.running_var.copy_(0.5 + torch.rand(C))
+    ref = cls(C, momentum=0.1).to(dev)
+    ref.load_state_dict(bn.state_dict())
+    if dtype == torch.bfloat16:
+        bn = bn.to(torch.bfloat16)  # parameters and running estimates in bf16, as bench.py's build_model does
+        with torch.no_grad():       # the reference starts from the same (bf16-valued) tensors, in f32
+            for a, b in zip(ref.state_dict().values(), bn.state_dict().values()):
+                a.copy_(b.float())
+    x = (torch.randn(*shape, device=dev) * 1.7 + 0.3).to(dtype)
+    if len(shape) == 4:
+        x = x.contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(*shape, device=dev).to(dtype)
+    if len(shape) == 4:
+        dy = dy.contiguous(memory_format=torch.channels_last)
+    assert hip_batchnorm(bn) == 1
+    bn.train(); ref.train()
+    x1 = x.clone().requires_grad_(True)
+    assert ag.bn_train_usable(bn, x1)
+    y = bn(x1)
+    y.backward(dy)
+    x2 = x.float().clone().requires_grad_(True)
+    yr = ref(x2)
+    yr.backward(dy.float())
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
+    errs = dict(y=rel(y, yr), dx=rel(x1.grad, x2.grad), dgamma=rel(bn.weight.grad, ref.weight.grad), dbeta=rel(bn.bias.grad, ref.bias.grad),
+                rmean=rel(bn.running_mean, ref.running_mean), rvar=rel(bn.running_var, ref.running_var))
+    print("hip batchnorm %s %s: %s" % (shape, dtype, ", ".join("%s %.2e" % kv for kv in errs.items())))
+    assert y.dtype == dtype and y.shape == x.shape and y.stride() == x.stride()
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    for k, v in errs.items():
+        assert v < tol, (k, v)
+    # eval mode, CPU tensors and layouts outside the contract keep torch's own path
+    bn.eval()
+    assert not ag.bn_train_usable(bn, x)
+    bn.train()
+    if len(shape) == 4:
+        assert not ag.bn_train_usable(bn, x.contiguous())  # NCHW storage
+        y2 = bn(x.contiguous())
+        assert torch.isfinite(y2.float()).all()
+
+
+def test_training_step_with_hip_batchnorm_matches_torch_batchnorm():
+    """one training step (README.md:114-125) of a converted ResNet18 at batch 8, f32 parity mode: loss and the gradients of the first
+    and the last variational layer with hip_batchnorm(model) against the same model on torch's BatchNorm kernels"""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models import resnet
+    from bayesian_torch_amd.models.fuse import hip_batchnorm
+    dev = _dev()
+    bt.manual_seed(2024)
+    bt.set_precision("f32")
+    res = []
+    for use_hip in (False, True):
+        torch.manual_seed(0)
+        m = resnet.resnet18()
+        bt.dnn_to_bnn(m, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Flipout",
+                              moped_enable=False, moped_delta=0.5))
+        m = m.to(dev).train()
+        bt.assign_layer_ids(m)
+        if use_hip:
+            assert hip_batchnorm(m) == 20
+        torch.manual_seed(1)
+        x = torch.randn(8, 3, 224, 224, device=dev)
+        t = torch.randint(0, 1000, (8,), device=dev)
+        bt.set_sample_index(m, 3)
+        out = m(x)
+        loss = torch.nn.functional.cross_entropy(out, t) + bt.get_kl_loss(m) / 8
+        loss.backward()
+        res.append((float(loss), m.conv1.mu_kernel.grad.clone(), m.fc.mu_weight.grad.clone(), m.bn1.running_var.clone(),
+                    m.layer4[1].bn2.weight.grad.clone()))
+    (l0, a0, b0, c0, d0), (l1, a1, b1, c1, d1) = res
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    print("training step, hip vs torch BatchNorm: loss %.6f / %.6f, conv1 dmu %.2e, fc dmu %.2e, bn1 running_var %.2e, bn dgamma %.2e" % (
+        l1, l0, rel(a1, a0), rel(b1, b0), rel(c1, c0), rel(d1, d0)))
+    assert abs(l1 - l0) < 1e-4 * abs(l0)
+    assert rel(a1, a0) < 5e-3 and rel(b1, b0) < 1e-3 and rel(c1, c0) < 1e-5 and rel(d1, d0) < 1e-3
