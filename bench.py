@@ -1134,7 +1134,7 @@ def main():
                 extra["cfg4_f32_parity_mode"] = summarise_extra(
                     "cfg4 shard in f32 parity mode (v_mfma_f32_32x32x2_f32, f32 activations)", r, "f32")
                 # north_star's 1e-4 tolerance at throughput: f32 activations, split-bf16 operands, three bf16 MFMAs per product
-                r = run_resnet_config("resnet18", "Flipout", "bf16x3", 64, False, 16, 3, 16, dev, parity=True, prewarm=3)
+                r = run_resnet_config("resnet18", "Flipout", "bf16x3", 64, False, 20, 0, 20, dev, parity=True, prewarm=3)
                 extra["cfg4_bf16x3"] = summarise_extra(
                     "cfg4 shard in split-bf16 mode (f32 activations, 3x v_mfma_f32_32x32x16_bf16 per product; fractions "
                     "against a third of the bf16 peak)", r, "bf16x3", table=True)
