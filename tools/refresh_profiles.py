@@ -26,7 +26,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
 ENV = dict(os.environ, TMPDIR="/tmp")
-PREFIX = "r04"  # file-name prefix of the round being measured
+PREFIX = "r05"  # file-name prefix of the round being measured
 SHAPES = ["64,64,56,1,3", "128,128,28,1,3", "256,256,14,1,3", "512,512,7,1,3"]
 
 
@@ -50,12 +50,16 @@ def variant(name, flags):
 
 def step_bench():
     out = sh("python bench.py --steps 20 --warmup 5", timeout=2400)  # the driver's invocation
-    line = [l for l in out.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]  # the compact line (<= 6 KB), LAST on stdout
+    c = json.loads(line)
     os.makedirs(OUT, exist_ok=True)
-    json.dump(d, open(os.path.join(OUT, PREFIX + "_bench_line.json"), "w"), indent=1)
+    json.dump(c, open(os.path.join(OUT, PREFIX + "_bench_line.json"), "w"), indent=1)
+    d = json.load(open(os.path.join(ROOT, "gpurun_out", "bench_detail.json")))  # the full result of the same run
+    json.dump(d, open(os.path.join(OUT, PREFIX + "_bench_detail.json"), "w"), indent=1)
     r = d["roofline"]
-    body = "value %.1f %s  ms/step %.4f  regions %s\n" % (d["value"], d["unit"], d["ms_per_step"], ["%.3f" % v for v in d["ms_per_step_runs"]])
+    body = "final stdout line: %d bytes\n" % len(line)
+    body += "value %.1f %s  ms/step %.4f  regions %s\n" % (d["value"], d["unit"], d["ms_per_step"], ["%.3f" % v for v in d["ms_per_step_runs"]])
+    body += "sustained (2 s of replays): %s\n" % json.dumps(d.get("sustained"))
     body += "roofline.frac %.4f (contraction only %.4f)  e2e %.4f  sampling %.1f us per %d-lane launch\n" % (
         r["frac"], r["frac_contraction_only"], r["frac_e2e"], r["sampling_us_per_launch"], r["mc_samples_per_launch"])
     body += "traffic (%s): %s\n" % (r["traffic_source"], json.dumps({k: round(v["ratio"], 2) for k, v in (r["traffic_detail"] or {}).get("layers", {}).items()}))
@@ -65,7 +69,8 @@ def step_bench():
     for k, v in d.get("extra", {}).items():
         body += "%s: %s\n" % (k, json.dumps(v)[:600])
     body += "cpu_baseline: %s\n" % json.dumps(d.get("cpu_baseline"))[:400]
-    write(PREFIX + "_bench_summary.txt", "python bench.py --steps 20 --warmup 5   (the driver's invocation; 1 MI355X; the JSON line is profiles/" + PREFIX + "_bench_line.json)", body)
+    write(PREFIX + "_bench_summary.txt", "python bench.py --steps 20 --warmup 5   (the driver's invocation; 1 MI355X; the compact JSON line is profiles/" + PREFIX +
+          "_bench_line.json, the full result profiles/" + PREFIX + "_bench_detail.json)", body)
 
 
 def step_trace():
@@ -74,7 +79,7 @@ def step_trace():
     for tag, extra in (("stats", ""), ("lanes1", " --lanes 1")):
         d = os.path.join(ROOT, "gpurun_out", "r4_kt_" + tag)
         shutil.rmtree(d, ignore_errors=True)
-        cmd = "python %s/bench.py --steps 20 --warmup 20 --no-extras --no-cpu-baseline --no-traffic%s" % (ROOT, extra)
+        cmd = "python %s/bench.py --steps 20 --warmup 20 --no-extras --no-cpu-baseline --no-traffic --no-sustain%s" % (ROOT, extra)
         sh("rocprofv3 --kernel-trace --stats -d %s -o kt -- %s" % (d, cmd), cwd="/tmp", timeout=1200)
         db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
         body = sh("python tools/trace_report.py %s" % db[0]) if db else "(no trace written)\n"
