@@ -1022,6 +1022,24 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   static const bool no_dma = tune_env("BTX_NO_DMA") != nullptr;
   const bool rowfuse = (flags & BTX_FLAG_ROWFUSE) != 0;
   bool dma = !gen && !no_dma && dma_shape_ok(g, act_dtype, prec, pl);
+  // Sample where the weights are used when nothing shares the sampled tile.  A pointwise layer (Linear, 1x1x1 at stride 1) with
+  // at most 256 rows per MC sample reads every weight once per sample: the register-staged kernel — (mu, rho) straight into the
+  // wave's registers, softplus + Philox + Box-Muller there, the sampled tile never exists in HBM (north_star's kernel design) —
+  // does strictly less memory work than a sampling pre-pass plus a tile DMA (measured equal or faster: BASELINE cfg2 10 718 vs
+  // 10 592 MC-samples/s, profiles/r05_experiments.txt E6).  Layers whose tiles are shared by many pixel tiles — every convolution
+  // of a ResNet — keep pre-sampled tiles: there an in-kernel sampler repeats each draw once per pixel tile.
+  // A caller that hands over pre-sampled tiles (BtxNoise.sampled_w) or explicit noise keeps the LDS-DMA family.
+  {
+    const bool pointwise_geom = !(flags & BTX_FLAG_TRANSPOSED) && g->KD == 1 && g->KH == 1 && g->KW == 1 && g->sd == 1 && g->sh == 1 &&
+                                g->sw == 1 && g->pd == 0 && g->ph == 0 && g->pw == 0;
+    // (single-sample launches only: with MC sample lanes the pre-sampled form of the ResNet18 classifier — 20 lanes x 64 rows — runs
+    // in 72 us against 109 us, the tiles of all lanes coming from the one sampling launch of the replay)
+    // BTX_FLAG_CONCURRENT single-sample launches are planned like lanes (a lane is bit-identical to them): same kernel as the lanes.
+    if (dma && !rowfuse && pointwise_geom && lanes == 1 && !(flags & BTX_FLAG_CONCURRENT) && pl.M <= 256 && prec != BTX_PREC_BF16X3 &&
+        !(noise && (noise->sampled_w || noise->eps_w || noise->sign_in || noise->sign_out)) &&
+        !(flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_OUT_BF16)) && !tune_env("BTX_NO_FUSED_LINEAR"))
+      dma = false;
+  }
   if (rowfuse) {
     // one K-stage = one kernel row: the K walk sees KW*C "channels" per tap and a single tap per row
     const int esz = (act_dtype == BTX_ACT_BF16) ? 2 : 4;

@@ -258,6 +258,15 @@ class _VariationalNd(BaseVariationalLayer_):
             tag, op, src = ("plain",), op0, ()
         if src and op0.transposed:
             return None  # the transposed GEMM-major order is not [N][taps][C] of the padded geometry: per-launch sampling
+        # Single-sample launches of Linear layers with at most 256 rows are sampled INSIDE their contraction launch (libbtx routes them to
+        # the register-staged kernel: softplus + Philox in registers, no tile in HBM — btx_api.hip "sample where the weights are
+        # used"): nothing to pre-sample.  (bf16x3 has no register-staged form and keeps its tiles.)
+        if op0.nd == 0 and (self.precision or prec) != "bf16x3" and self._lanes()[0] == 1 and not BF._CONCURRENT:
+            rows = 1
+            for v in shape[:-1]:
+                rows *= int(v)
+            if rows <= 256:
+                return None
         # Only the LDS-DMA kernel family consumes pre-sampled tiles, and it takes a layer only when a K-stage (32 bf16 /
         # 16 f32 channels) lies inside one filter tap; everything else (depthwise / odd grouped convolutions, C/groups
         # not a multiple of the stage) samples in registers and would ignore — or, for K % 4 != 0, could not even

@@ -334,7 +334,9 @@ def test_presample_is_bit_identical_and_one_shot(prec, act):
             bt.presample(m, 9)                         # stale on purpose: the forward below runs sample 4
             bt.set_sample_index(m, 4)
             y4s = m(x)
-        assert n_pre == 21
+        # the 20 convolutions get pre-sampled tiles; the classifier (Linear, 2 rows per sample: one pixel tile) is sampled inside its
+        # contraction launch (register-staged kernel: the sampled tile never exists in HBM) and has nothing to pre-sample
+        assert n_pre == 20
         assert torch.equal(y9, y9p)
         assert torch.equal(y4, y4s)
         assert not torch.equal(y4, y9)
@@ -367,9 +369,10 @@ def test_presample_of_padded_layouts_is_bit_identical():
                 y0 = net(x)
                 bt.set_sample_index(net, 6, presample=True)
                 # only the layers the LDS-DMA kernel family takes are sampled ahead (the register-staged kernel samples in
-                # registers and ignores tiles): the row-fused stem, and in f32 the 720-wide Linear (720 % 16 == 0)
+                # registers and ignores tiles): the row-fused stem.  (The 720-wide Linear would qualify in f32 — 720 % 16 == 0 —
+                # but a single-sample Linear launch of 4 rows is sampled inside its contraction launch: nothing to pre-sample.)
                 n_pre = sum(1 for mod in net.modules() if getattr(mod, "_btx_pre", None) is not None)
-                assert n_pre == (2 if prec == "f32" else 1), (prec, n_pre)
+                assert n_pre == 1, (prec, n_pre)
                 y1 = net(x)
             assert torch.equal(y0, y1), prec
         finally:
@@ -675,3 +678,41 @@ def test_lstm_wrappers_on_the_hip_linear_kernels():
             h = o * torch.tanh(c)
             assert torch.allclose(hs[:, t], h, atol=1e-6) and torch.allclose(cs[:, t], c, atol=1e-6)
         assert abs(float(kl) - 7 * float(layer.kl_loss())) <= 1e-4 * abs(float(kl))
+
+
+def test_single_sample_linear_layers_sample_inside_their_launch():
+    """north_star's kernel for the Linear family: a single-sample launch of a Linear layer with <= 256 rows is routed to the
+    register-staged kernel (softplus + Philox in registers, no sampled tile in HBM) — it has nothing to pre-sample — while the same
+    layer under the throughput plan / with MC sample lanes keeps pre-sampled tiles (a lane must be bit-identical to a
+    single-sample launch of that plan).  Values: against the CPU reference chain with the noise BTX-RNG defines."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    from bayesian_torch_amd import functional as BF
+    from oracle import bt_ref
+    dev = _dev()
+    bt.manual_seed(3)
+    torch.manual_seed(0)
+    layer = L.LinearFlipout(784, 512).to(dev)
+    x = torch.randn(256, 784, device=dev)
+    for prec, act, tol in (("f32", torch.float32, 1e-5), ("bf16", torch.bfloat16, 1e-2)):
+        layer.precision = prec
+        xx = x.to(act)
+        with torch.no_grad():
+            out = layer._forward_hip(xx, sample_idx=5)
+            assert layer.presample_item(5, prec) is None                      # single-sample, 256 rows: sampled in the launch
+            with BF.concurrent_plan():
+                assert layer.presample_item(5, prec) is not None              # planned like a lane: pre-sampled tiles
+            bt.set_sample_lanes(layer, [5, 6], batch=256)
+            assert layer.presample_item(5, prec) is not None
+            bt.set_sample_lanes(layer, None)
+            big = torch.randn(512, 784, device=dev).to(act)
+            layer._forward_hip(big, sample_idx=5)
+            assert layer.presample_item(5, prec) is not None                  # 512 rows: two pixel tiles share a weight tile
+            layer._forward_hip(xx, sample_idx=5)
+        nz = layer.materialize_noise(5, tuple(xx.shape), tuple(out.shape), xx.dtype)
+        c = lambda t: t.detach().float().cpu()  # noqa: E731
+        ref = bt_ref.flipout_forward(c(xx), c(layer.mu_weight), c(layer.rho_weight), c(layer.mu_bias), c(layer.rho_bias), c(nz["eps_w"]),
+                                     c(nz["eps_b"]), c(nz["sign_in"]), c(nz["sign_out"]), dict(kind="linear"))
+        err = float((out.float().cpu() - ref).norm() / ref.norm())
+        print("LinearFlipout 784->512, 256 rows, %s, sampled in the launch: rel-L2 vs the CPU reference chain %.2e" % (prec, err))
+        assert err < tol, (prec, err)
