@@ -65,7 +65,7 @@ EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_
            "btx_kl_gauss_model", "btx_kl_gauss_model_bwd", "btx_contract_wgrad",
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_fwd_lanes", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign", "btx_rho_grad",
            "btx_mc_packed_floats", "btx_mc_accumulate", "btx_mc_accumulate_lanes", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl",
-           "btx_bn_workspace_bytes", "btx_bn_train_fwd", "btx_bn_train_bwd")
+           "btx_bn_workspace_bytes", "btx_bn_train_fwd", "btx_bn_train_bwd", "btx_dgrad_weights")
 
 
 def lib_path():
@@ -148,6 +148,8 @@ def lib():
     L.btx_bn_train_fwd.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, sz, vp]
     L.btx_bn_train_bwd.restype = i32
     L.btx_bn_train_bwd.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32, vp, vp, vp, vp, vp, sz, vp]
+    L.btx_dgrad_weights.restype = i32
+    L.btx_dgrad_weights.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(Rng), vp]
     if L.btx_abi_version() != ABI_VERSION:
         raise BtxError("libbtx.so ABI %d != expected %d" % (L.btx_abi_version(), ABI_VERSION))
     _LIB = L

@@ -21,13 +21,40 @@ from . import functional as BF
 from . import rng as _rng
 
 
+def fast_dgrad_ok(layer):
+    """the data gradient's weight operands in ONE launch (btx_dgrad_weights): Linear layers and stride-1 2-D convolutions on plain
+    layouts (no channel padding, no row-fused stem, groups == 1) whose padding does not exceed the dilated kernel extent"""
+    op = layer._op
+    if layer._btx_cpad is not None or op.transposed or op.groups != 1:
+        return False
+    if op.nd == 0:
+        return True
+    if op.nd == 2 and op.stride == (1, 1, 1) and op.in_channels > 4:
+        return all(d * (k - 1) - p >= 0 for d, k, p in zip(op.dilation[1:], op.kernel[1:], op.padding[1:]))
+    return False
+
+
 def _data_grad_hip(layer, dy, x_shape, nz, sample_idx, hashed_signs, mu, rho):
     """dx through libbtx: the contraction of dy with the (mu, sigma*eps) the FORWARD used (the tensors autograd saved) on
     the transposed geometry"""
     op = layer._op
-    mu, rho, eps = mu.detach(), rho.detach(), nz["eps_w"]
     kind = _lib.KIND_FLIPOUT if layer._family == "flipout" else _lib.KIND_REPARAM
     nd = op.nd
+    if fast_dgrad_ok(layer) and (kind == _lib.KIND_REPARAM or hashed_signs):
+        mu_p, rho_p = BF.gemm_major_view(mu.detach(), op), BF.gemm_major_view(rho.detach(), op)
+        if nd == 0:
+            opT, taps, flip = BF.OpDesc(0, op.out_channels, op.in_channels), 1, False
+        else:
+            pad = tuple(d * (k - 1) - p for d, k, p in zip(op.dilation[1:], op.kernel[1:], op.padding[1:]))
+            opT = BF.OpDesc(2, op.out_channels, op.in_channels, op.kernel[1:], 1, pad, op.dilation[1:], 1)
+            taps, flip = op.kernel[1] * op.kernel[2], True
+        w_mu, w_rho, w_eps = BF.dgrad_weights_hip(mu_p, rho_p, op.out_channels, taps, op.in_channels, flip, _rng.seed(),
+                                                  sample_idx, layer._btx_layer_id)
+        dx = BF.contract_hip(kind, dy, w_mu, w_rho, None, None, opT, _rng.seed(), sample_idx, layer._btx_layer_id,
+                             prec=layer.precision, noise={"eps_w_packed": w_eps},
+                             extra_flags=_lib.FLAG_SWAP_SIGNS if kind == _lib.KIND_FLIPOUT else 0)
+        return dx.reshape(x_shape) if nd == 0 else dx
+    mu, rho, eps = mu.detach(), rho.detach(), nz["eps_w"]
     if nd == 0:
         opT = BF.OpDesc(0, op.out_channels, op.in_channels)
         w_mu, w_rho, w_eps = mu.t(), rho.t(), eps.t()
@@ -94,7 +121,8 @@ class ContractFn(torch.autograd.Function):
             # the noise TENSORS (eps, signs) are only materialised where something still needs them: the data gradient (it
             # contracts with the transposed / flipped sigma*eps), padded / transposed layouts, bias gradients
             plain_w = not op.transposed and not padded
-            need_nz = (ctx.needs_input_grad[2] or not plain_w or need_signs or
+            fast_dx = plain_w and fast_dgrad_ok(layer)  # the data gradient regenerates eps in its own operand pass
+            need_nz = ((ctx.needs_input_grad[2] and not fast_dx) or not plain_w or need_signs or
                        (rho_b is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6])))
             nz = layer.materialize_noise(s, tuple(x.shape), tuple(dy.shape), x.dtype, signs=need_signs) if need_nz else {}
             dx = dmu = drho = dmu_b = drho_b = None

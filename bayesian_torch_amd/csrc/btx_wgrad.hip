@@ -361,7 +361,76 @@ void sign_keys_host(const BtxRng* rng, uint32_t stream, uint32_t* ka, uint32_t* 
   *kb = k.x[1];
 }
 
+// ---- the operands of the DATA gradient in one pass (btx_dgrad_weights) ---------------------------------------------------
+// dx of  y = conv(x, W)  at stride 1 is a convolution of dy with the spatially flipped, channel-transposed kernel; of a Linear
+// layer a product with W^T.  Its three weight operands — mu, rho and the eps the FORWARD drew — in the GEMM-major order of that
+// transposed geometry:  out[c][tp][n] = src[n][flip ? T-1-tp : tp][c],  eps regenerated at the SOURCE index (BTX-RNG v1 is a pure
+// function of it).  32 x 32 (n, c) tiles of one tap through LDS: reads run along c (one Philox call per four consecutive source
+// elements), writes along n.  Replaces, per layer and training step, fill_eps + unpack + three flips + four pack copies (ten ATen /
+// libbtx launches of 3-6 us, ~150 per ResNet18 step).
+__global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
+                                                            float* __restrict__ omu, float* __restrict__ orho,
+                                                            float* __restrict__ oeps, int N, int T, int C, int flip, int ctiles,
+                                                            int ntiles, uint32_t k0, uint32_t k1, uint32_t sample, uint32_t layer) {
+  __shared__ float tm[32][33], tr[32][33], te[32][33];
+  const int b = blockIdx.x;
+  const int ct = b % ctiles, nt = (b / ctiles) % ntiles, t = b / (ctiles * ntiles);
+  const int tp = flip ? T - 1 - t : t;
+  const int tid = threadIdx.x;
+  {  // read: thread = (row r of 32 n, quad q of 8) -> 4 consecutive c
+    const int r = tid >> 3, q = tid & 7;
+    const int n = nt * 32 + r, c0 = ct * 32 + 4 * q;
+    float m4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f}, e4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N && c0 < C) {
+      const size_t e0 = ((size_t)n * T + t) * C + c0;
+      if ((C & 3) == 0) {  // e0 is a multiple of 4: one Philox block, 16-byte loads
+        const f32x4 a = *(const f32x4*)(mu + e0), bq = *(const f32x4*)(rho + e0);
+        m4[0] = a[0]; m4[1] = a[1]; m4[2] = a[2]; m4[3] = a[3];
+        r4[0] = bq[0]; r4[1] = bq[1]; r4[2] = bq[2]; r4[3] = bq[3];
+        btx_normal4((uint32_t)(e0 >> 2), sample, layer, 0u, k0, k1, e4);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + e < C) {
+            m4[e] = mu[e0 + e]; r4[e] = rho[e0 + e];
+            float z[4];
+            btx_normal4((uint32_t)((e0 + e) >> 2), sample, layer, 0u, k0, k1, z);
+            e4[e] = z[(e0 + e) & 3];
+          }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { tm[r][4 * q + e] = m4[e]; tr[r][4 * q + e] = r4[e]; te[r][4 * q + e] = e4[e]; }
+  }
+  __syncthreads();
+  {  // write: thread = (row cc of 32 c, quad q of 8) -> 4 consecutive n
+    const int cc = tid >> 3, q = tid & 7;
+    const int c = ct * 32 + cc, n0 = nt * 32 + 4 * q;
+    if (c < C && n0 < N) {
+      const size_t o0 = ((size_t)c * T + tp) * N + n0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + e < N) { omu[o0 + e] = tm[4 * q + e][cc]; orho[o0 + e] = tr[4 * q + e][cc]; oeps[o0 + e] = te[4 * q + e][cc]; }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int btx_dgrad_weights(const float* mu_w, const float* rho_w, float* out_mu, float* out_rho, float* out_eps, int N, int T,
+                                 int C, int flip, const BtxRng* rng, void* stream) {
+  if (!mu_w || !rho_w || !out_mu || !out_rho || !out_eps || !rng) return BTX_E_NULL;
+  if (N <= 0 || T <= 0 || C <= 0) return BTX_E_SHAPE;
+  if ((unsigned long long)N * T * C > 0xfffffffcULL) return BTX_E_UNSUPPORTED;  // BTX-RNG v1 block index is 32 bits
+  if (((((uintptr_t)mu_w) | ((uintptr_t)rho_w)) & 15) && (C & 3) == 0) return BTX_E_ALIGN;
+  const int ctiles = (C + 31) / 32, ntiles = (N + 31) / 32;
+  const long long nwg = (long long)ctiles * ntiles * T;
+  if (nwg > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
+  hipLaunchKernelGGL(dgrad_weights_kernel, dim3((int)nwg), dim3(256), 0, (hipStream_t)stream, mu_w, rho_w, out_mu, out_rho, out_eps, N,
+                     T, C, flip ? 1 : 0, ctiles, ntiles, (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx,
+                     rng->layer_id);
+  return (int)hipGetLastError();
+}
 
 extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta,
                                   float* db_mu, float* db_delta, const BtxRng* rng, const BtxNoise* noise, int act_dtype,

@@ -382,7 +382,10 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
         keep.append(sampled_w)
     if noise:
         nz = nz or _lib.Noise()
-        if noise.get("eps_w") is not None:
+        if noise.get("eps_w_packed") is not None:  # already in the GEMM-major order of `op` (dgrad_weights_hip)
+            t = noise["eps_w_packed"]
+            keep.append(t); nz.eps_w = t.data_ptr()
+        elif noise.get("eps_w") is not None:
             t = pack_gemm_major(noise["eps_w"].to(device=x.device, dtype=torch.float32), op)
             keep.append(t); nz.eps_w = t.data_ptr()
         if noise.get("eps_b") is not None:
@@ -670,6 +673,19 @@ def rho_grad_hip(dw_flat, rho_flat, seed, sample_idx, layer_id, rng_stream, out=
     _lib.check(L.btx_rho_grad(dw_flat.data_ptr(), rho_flat.data_ptr(), out.data_ptr(), dw_flat.numel(), ctypes.byref(r),
                               rng_stream, torch.cuda.current_stream(dw_flat.device).cuda_stream))
     return out
+
+
+def dgrad_weights_hip(mu_p, rho_p, n, taps, c, flip, seed, sample_idx, layer_id):
+    """btx_dgrad_weights: (mu, rho, eps) of the data gradient's transposed geometry, GEMM-major [c][taps][n] f32, from the layer's
+    own GEMM-major parameters [n][taps][c] in ONE launch (eps = the forward's draw, regenerated)."""
+    L = _lib.lib()
+    dev = mu_p.device
+    outs = [torch.empty(int(c) * int(taps) * int(n), dtype=torch.float32, device=dev) for _ in range(3)]
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    _lib.check(L.btx_dgrad_weights(mu_p.data_ptr(), rho_p.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                   int(n), int(taps), int(c), 1 if flip else 0, ctypes.byref(r),
+                                   torch.cuda.current_stream(dev).cuda_stream))
+    return outs
 
 
 def fill_sign_hip(n, device, seed, sample_idx, layer_id, rng_stream):

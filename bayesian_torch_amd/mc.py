@@ -183,7 +183,7 @@ class GraphedMC:
     replay unless static_input=True (then call set_input() to change it)."""
 
     def __init__(self, model, x, kl=0.0, warmup=2, lanes=1, keep_logits=False, concurrent_hint=None, lane_mode="launch",
-                 static_input=False):
+                 static_input=False, capture_stream=None):
         """lanes > 1: one replay evaluates `lanes` MC samples (independent noise: the same results as one at a time); use
         run_many().  lane_mode "launch" (default): the samples are lanes of ONE launch per layer (rng.set_sample_lanes:
         4x the workgroups per launch fill the 256 CUs where one sample of a 7x7 / 14x14 layer cannot, and one
@@ -198,6 +198,8 @@ class GraphedMC:
             raise ValueError("lane_mode must be 'launch' or 'streams'")
         self.model, self.x, self.kl, self.lanes = model, x, float(kl), int(lanes)
         self.lane_mode = lane_mode
+        self._capture_stream = capture_stream  # graphs that will be replayed concurrently must not share a capture stream:
+        # the contraction workspace (split-K partials) is per stream and its address is baked into the captured launches
         self.static_input = bool(static_input) and self.lanes > 1 and lane_mode == "launch"
         self._static_packs = {}  # this graph's packed stem inputs {id(layer): (key, tensor)}: owned here, freed by close()
         if self.lanes > 1 and lane_mode == "launch":
@@ -268,7 +270,8 @@ class GraphedMC:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        kw = dict(stream=self._capture_stream) if self._capture_stream is not None else {}
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local", **kw):
             self._launch_lanes(skip_mu=True)
         self.packed.zero_()
         # the replays need nothing from the Python-side lane state: a plain `model(x)` between replays is a plain forward

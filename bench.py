@@ -703,9 +703,14 @@ def run_train_step(dev, steps=5):
     torch.manual_seed(1234)
     x = torch.randn(64, 3, 224, 224, device=dev).to(torch.bfloat16)
     y = torch.randint(0, 1000, (64,), device=dev)
+    step_no = [0]
+
     def step():
         for p_ in model.parameters():
             p_.grad = None
+        # one sampling launch for the forward of all 21 layers instead of one small pre-pass per layer
+        bt.set_sample_index(model, step_no[0], presample=True)
+        step_no[0] += 1
         out = model(x)
         loss = torch.nn.functional.cross_entropy(out.float(), y) + bt.get_kl_loss(model) / 64
         loss.backward()

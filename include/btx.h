@@ -299,6 +299,15 @@ size_t btx_sampled_w_bytes_lanes(const BtxGeom* g, int kind, int prec, int lanes
 int btx_sample_weights_lanes(const BtxSampleItem* items_host, int n_items, const BtxRng* rng /* layer_id unused */,
                              int prec, void* stream, int lanes, uint32_t sflags);
 
+/* Training, the step in front of the data gradient (ABI 7).  dx of a stride-1 convolution is the forward's own contraction on the
+ * spatially flipped, channel-transposed kernel, of a Linear layer on W^T (what autograd derives for F.conv*d / F.linear inside
+ * conv_flipout.py:376-417, linear_flipout.py:168-174).  One launch writes its three weight operands in the GEMM-major order of
+ * that geometry — out[c][tp][n] = src[n][flip ? T-1-tp : tp][c] for mu, rho and for the eps the forward drew (regenerated at the
+ * source index: stream BTX_STREAM_EPS_W of rng) — from the layer's own GEMM-major parameters mu_w / rho_w [N][T][C] (groups == 1).
+ * The results go to btx_contract_fwd as (mu_w, rho_w, BtxNoise.eps_w) of the transposed geometry. */
+int btx_dgrad_weights(const float* mu_w, const float* rho_w, float* out_mu, float* out_rho, float* out_eps, int N, int T, int C,
+                      int flip, const BtxRng* rng, void* stream);
+
 /* Training, the step behind btx_contract_wgrad: drho[i] = dw[i] * eps(i) * sigmoid(rho[i]) over the n elements of a weight
  * tensor in the order of mu_w (what autograd derives for `sigma = log1p(exp(rho)); delta = sigma * eps` of
  * conv_flipout.py:372-375 / conv_variational.py:358-366 / linear_flipout.py:150-153).  dw = dw_delta of a Flipout layer,

@@ -449,3 +449,23 @@ def test_training_step_with_hip_batchnorm_matches_torch_batchnorm():
         l1, l0, rel(a1, a0), rel(b1, b0), rel(c1, c0), rel(d1, d0)))
     assert abs(l1 - l0) < 1e-4 * abs(l0)
     assert rel(a1, a0) < 5e-3 and rel(b1, b0) < 1e-3 and rel(c1, c0) < 1e-5 and rel(d1, d0) < 1e-3
+
+
+@pytest.mark.parametrize("N,T,C,flip", [(64, 9, 64, True), (128, 9, 64, True), (40, 9, 24, True), (1000, 1, 512, False), (10, 1, 50, False),
+                                        (33, 25, 7, True)])
+def test_dgrad_weights_one_launch_equals_the_torch_chain(N, T, C, flip):
+    """btx_dgrad_weights: (mu, rho, eps) of the data gradient's transposed geometry in one launch == flip / transpose / pack of the
+    parameters and of btx_fill_eps's eps by torch ops (bit for bit: a permutation of f32 values and the same Philox draws)"""
+    from bayesian_torch_amd import functional as BF
+    from bayesian_torch_amd import _lib
+    dev = _dev()
+    torch.manual_seed(N * 7 + T)
+    mu = torch.randn(N, T, C, device=dev)
+    rho = torch.randn(N, T, C, device=dev) - 3
+    om, orh, oe = BF.dgrad_weights_hip(mu, rho, N, T, C, flip, 77, 5, 13)
+    eps = BF.fill_eps_hip(N * T * C, dev, 77, 5, 13, _lib.STREAM_EPS_W).reshape(N, T, C)
+
+    def tr(t):
+        t = t.flip(1) if flip else t
+        return t.permute(2, 1, 0).contiguous().reshape(-1)
+    assert torch.equal(om, tr(mu)) and torch.equal(orh, tr(rho)) and torch.equal(oe, tr(eps))
