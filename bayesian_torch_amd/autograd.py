@@ -48,10 +48,11 @@ def _data_grad_hip(layer, dy, x_shape, nz, sample_idx, hashed_signs, mu, rho):
             pad = tuple(d * (k - 1) - p for d, k, p in zip(op.dilation[1:], op.kernel[1:], op.padding[1:]))
             opT = BF.OpDesc(2, op.out_channels, op.in_channels, op.kernel[1:], 1, pad, op.dilation[1:], 1)
             taps, flip = op.kernel[1] * op.kernel[2], True
+        sdev = getattr(layer, "_btx_sample_dev", None)  # captured training step: the sample index is a device word
         w_mu, w_rho, w_eps = BF.dgrad_weights_hip(mu_p, rho_p, op.out_channels, taps, op.in_channels, flip, _rng.seed(),
-                                                  sample_idx, layer._btx_layer_id)
+                                                  sample_idx, layer._btx_layer_id, sample_dev=sdev)
         dx = BF.contract_hip(kind, dy, w_mu, w_rho, None, None, opT, _rng.seed(), sample_idx, layer._btx_layer_id,
-                             prec=layer.precision, noise={"eps_w_packed": w_eps},
+                             prec=layer.precision, noise={"eps_w_packed": w_eps}, sample_dev=sdev,
                              extra_flags=_lib.FLAG_SWAP_SIGNS if kind == _lib.KIND_FLIPOUT else 0)
         return dx.reshape(x_shape) if nd == 0 else dx
     mu, rho, eps = mu.detach(), rho.detach(), nz["eps_w"]
@@ -86,7 +87,7 @@ def _data_grad_hip(layer, dy, x_shape, nz, sample_idx, hashed_signs, mu, rho):
             noise["sign_in"], noise["sign_out"] = nz["sign_out"], nz["sign_in"]
     dx = BF.contract_hip(kind, dy, BF.pack_gemm_major(w_mu.float(), opT), BF.pack_gemm_major(w_rho.float(), opT), None, None,
                          opT, _rng.seed(), sample_idx, layer._btx_layer_id, prec=layer.precision, noise=noise,
-                         extra_flags=flags)
+                         extra_flags=flags, sample_dev=getattr(layer, "_btx_sample_dev", None))
     return dx.reshape(x_shape) if nd == 0 else dx
 
 
@@ -124,7 +125,9 @@ class ContractFn(torch.autograd.Function):
             fast_dx = plain_w and fast_dgrad_ok(layer)  # the data gradient regenerates eps in its own operand pass
             need_nz = ((ctx.needs_input_grad[2] and not fast_dx) or not plain_w or need_signs or
                        (rho_b is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6])))
-            nz = layer.materialize_noise(s, tuple(x.shape), tuple(dy.shape), x.dtype, signs=need_signs) if need_nz else {}
+            sdev = getattr(layer, "_btx_sample_dev", None)  # captured step: eps / signs follow the device word, not `s`
+            nz = layer.materialize_noise(s, tuple(x.shape), tuple(dy.shape), x.dtype, signs=need_signs,
+                                         sample_dev=sdev) if need_nz else {}
             dx = dmu = drho = dmu_b = drho_b = None
             kind = _lib.KIND_FLIPOUT if flip else _lib.KIND_REPARAM
             want_w = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
@@ -135,24 +138,24 @@ class ContractFn(torch.autograd.Function):
                     # row-fused stem: the gradient on the geometry the forward ran on (7 kernel rows x 32 elements instead of
                     # 49 taps x 3 channels of a 64-wide tile; the forward's hashed signs instead of sign tensors)
                     dW, dWd, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
-                                                    bias=want_b, rowfuse=plan)
+                                                    bias=want_b, rowfuse=plan, sample_dev=sdev)
                 elif not op.transposed and not padded:
                     # plain layouts: the kernel's GEMM-major buffers ARE the gradients (strided logical views, as the
                     # parameters themselves are stored), and drho = dW_delta * eps * sigmoid(rho) is one launch with eps
                     # regenerated in the kernel (btx_rho_grad) instead of fill_eps + unpack + sigmoid + two products
                     dWf, dWdf, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
-                                                      bias=want_b, raw=True)
+                                                      bias=want_b, raw=True, sample_dev=sdev)
                     if want_w:
                         rho_f = BF.gemm_major_view(rho, op).reshape(-1)
                         src = dWdf if flip else dWf
                         drho_f = BF.rho_grad_hip(src, rho_f, _rng.seed(), s, layer._btx_layer_id, _lib.STREAM_EPS_W,
-                                                 out=src if flip else None)
+                                                 out=src if flip else None, sample_dev=sdev)
                         dmu = BF.gemm_major_logical_view(dWf, w_shape, op)
                         drho = BF.gemm_major_logical_view(drho_f, w_shape, op)
                     fused_w = True
                 elif not op.transposed:
                     dW, dWd, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
-                                                    signs=signs, bias=want_b)
+                                                    signs=signs, bias=want_b, sample_dev=sdev)
                 else:
                     # y = convT(x, W): W is the weight of the plain convolution that maps y-space to x-space, so its
                     # gradient is corr(dy, x) on that geometry — x and dy (and the two sign streams) exchange roles
@@ -161,7 +164,7 @@ class ContractFn(torch.autograd.Function):
                                     op.padding[3 - nd:], op.dilation[3 - nd:], op.groups)
                     sw = (signs[1], signs[0]) if signs is not None else None
                     dW, dWd, _, _ = BF.wgrad_hip(kind, dy, x, opc, _rng.seed(), s, layer._btx_layer_id, w_shape, signs=sw,
-                                                 swap=True)
+                                                 swap=True, sample_dev=sdev)
                     db = dbd = None
                     if want_b:
                         red = tuple(i for i in range(dy.dim()) if i != 1)
@@ -353,3 +356,69 @@ def batch_norm_train(bn, x):
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return BatchNormTrainFn.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+
+
+class GraphedTrainStep:
+    """forward + loss + backward of `model` on a fixed batch, captured ONCE into a hipGraph and replayed per training step
+    (reference README.md:114-125: `output = model(x); kl = get_kl_loss(model); loss = ce(output, y) + kl / batch_size;
+    loss.backward()`).  An eager step of a converted ResNet18 dispatches ~590 kernel launches through Python / ATen at ~16 us
+    each and is bound by the HOST (profiles/r05_experiments.txt E9); a replay has no host work.  What changes between steps — the MC
+    sample index that keys BTX-RNG v1 — lives in one device word that run() rewrites, so every replay draws fresh noise exactly as
+    an eager step with set_sample_index(model, s) would (forward, data / weight / rho gradients all read the word).
+
+        step = GraphedTrainStep(model, x, target)            # grads live in p.grad (static tensors, rewritten by every replay)
+        for it in range(n): loss = step.run(it); optimizer.step()
+
+    In-place parameter updates between replays are seen (the kernels read mu / rho where they live); x / target are read from the
+    tensors given here (copy new batches INTO them).  Layers on padded layouts that need their input gradient (sign tensors keyed
+    on the host) cannot be captured and raise.  Drop every reference to the loss / outputs of earlier EAGER steps of this model
+    before constructing one (torch: a live autograd graph pins its AccumulateGrad nodes to the stream it ran on)."""
+
+    def __init__(self, model, x, target, loss_fn=None, warmup=2):
+        from .models.dnn_to_bnn import get_kl_loss
+        if not x.is_cuda:
+            raise ValueError("GraphedTrainStep needs CUDA (ROCm) tensors")
+        self.model, self.x, self.target = model, x, target
+        bs = x.shape[0]
+        self.loss_fn = loss_fn or (lambda out, tgt: torch.nn.functional.cross_entropy(out.float(), tgt) + get_kl_loss(model) / bs)
+        dev = x.device
+        import gc
+        gc.collect()  # autograd graphs of earlier eager steps still referenced from garbage would pin AccumulateGrad nodes to the
+        torch.cuda.synchronize(dev)  # caller's stream (torch warns that this "may break CUDA graph capture": it does)
+        self._layers = [m for m in model.modules() if hasattr(m, "_btx_layer_id")]
+        self.sample_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        for m in self._layers:
+            m.__dict__["_btx_sample_dev"] = self.sample_dev
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup) + 1):
+                self._step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        for p_ in model.parameters():
+            p_.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.loss = self._step()
+
+    def _step(self):
+        for p_ in self.model.parameters():
+            p_.grad = None
+        _rng.presample(self.model, 0)  # one sampling launch for the forward of every layer (reads the device word)
+        out = self.model(self.x)
+        if isinstance(out, tuple):
+            out = out[0]
+        loss = self.loss_fn(out, self.target)
+        loss.backward()
+        return loss.detach()
+
+    def run(self, sample_idx):
+        self.sample_dev.fill_(int(sample_idx) & 0x7FFFFFFF)
+        self.graph.replay()
+        return self.loss
+
+    def close(self):
+        for m in self._layers:
+            m.__dict__["_btx_sample_dev"] = None
+            m.__dict__["_btx_pre"] = None

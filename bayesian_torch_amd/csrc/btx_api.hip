@@ -162,7 +162,9 @@ __global__ __launch_bounds__(KL_BLOCK) void kl_model_bwd_kernel(const KlBatchDev
 // noise materialisation (BTX-RNG v1)
 // ========================================================================================================
 __global__ __launch_bounds__(256) void fill_eps_kernel(float* __restrict__ out, size_t n, uint32_t k0, uint32_t k1,
-                                                       uint32_t sample, uint32_t layer, uint32_t stream) {
+                                                       uint32_t sample, uint32_t layer, uint32_t stream,
+                                                       const uint32_t* __restrict__ sample_ptr) {
+  if (sample_ptr) sample = __builtin_amdgcn_readfirstlane(*sample_ptr);  // BtxRng.sample_idx_dev (captured steps)
   const size_t nblk = (n + 3) >> 2;
   for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nblk; b += (size_t)gridDim.x * 256) {
     float z[4];
@@ -176,7 +178,9 @@ __global__ __launch_bounds__(256) void fill_eps_kernel(float* __restrict__ out, 
 // drho = dw * eps * sigmoid(rho): the elementwise follow-up of the weight gradient, eps regenerated (never materialised)
 __global__ __launch_bounds__(256) void rho_grad_kernel(const float* __restrict__ dw, const float* __restrict__ rho,
                                                        float* __restrict__ drho, size_t n, uint32_t k0, uint32_t k1,
-                                                       uint32_t sample, uint32_t layer, uint32_t stream) {
+                                                       uint32_t sample, uint32_t layer, uint32_t stream,
+                                                       const uint32_t* __restrict__ sample_ptr) {
+  if (sample_ptr) sample = __builtin_amdgcn_readfirstlane(*sample_ptr);
   const size_t nblk = (n + 3) >> 2;
   for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nblk; b += (size_t)gridDim.x * 256) {
     float z[4];
@@ -1444,7 +1448,8 @@ int btx_fill_eps(float* out, size_t n, const BtxRng* rng, uint32_t rng_stream, v
   size_t blocks = ((n + 3) / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(fill_eps_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, out, n,
-                     (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx, rng->layer_id, rng_stream);
+                     (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx, rng->layer_id, rng_stream,
+                     (const uint32_t*)rng->sample_idx_dev);
   return (int)hipGetLastError();
 }
 
@@ -1456,7 +1461,8 @@ int btx_rho_grad(const float* dw, const float* rho, float* drho, size_t n, const
   size_t blocks = ((n + 3) / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(rho_grad_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dw, rho, drho, n,
-                     (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx, rng->layer_id, rng_stream);
+                     (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx, rng->layer_id, rng_stream,
+                     (const uint32_t*)rng->sample_idx_dev);
   return (int)hipGetLastError();
 }
 

@@ -46,6 +46,9 @@ struct WgradParams {
   int sd, sh, sw, pd, ph, pw, dd, dh, dw;
   int M, K, T, groups, ntiles, ctiles, chunks, chunk_px;
   uint32_t kin_a, kin_b, kout_a, kout_b;
+  const uint32_t* sample_ptr;  // BtxRng.sample_idx_dev: the sign keys are then derived on the device (captured training steps)
+  uint32_t seed_lo, seed_hi, layer;
+  int swap;
   FastDiv fd_Wo, fd_Ho, fd_Do, fd_T, fd_ctiles, fd_ntiles, fd_groups;
 };
 
@@ -65,6 +68,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   unsigned char* t_dys = smem + 2 * WG_TILE;
   unsigned char* t_xs = smem + 3 * WG_TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hk = lane >> 5;
+  // sign keys of this (sample, layer): the host's, or — with a device-resident sample index — derived here, as the forward does
+  uint32_t kin_a = p.kin_a, kin_b = p.kin_b, kout_a = p.kout_a, kout_b = p.kout_b;
+  if (KIND == 1 && p.sample_ptr) {
+    const uint32_t smp = __builtin_amdgcn_readfirstlane(*p.sample_ptr);
+    const uint32_t si = p.swap ? BTX_STREAM_SIGN_OUT : BTX_STREAM_SIGN_IN, so = p.swap ? BTX_STREAM_SIGN_IN : BTX_STREAM_SIGN_OUT;
+    const BtxPhilox4 ki = btx_philox4x32_10(0u, smp, p.layer, si, p.seed_lo, p.seed_hi);
+    const BtxPhilox4 ko = btx_philox4x32_10(0u, smp, p.layer, so, p.seed_lo, p.seed_hi);
+    kin_a = __builtin_amdgcn_readfirstlane(ki.x[0]); kin_b = __builtin_amdgcn_readfirstlane(ki.x[1]);
+    kout_a = __builtin_amdgcn_readfirstlane(ko.x[0]); kout_b = __builtin_amdgcn_readfirstlane(ko.x[1]);
+  }
 
   uint32_t u, u_chunk, u_tap, u_ct, u_nt, u_g;
   fdivmod(blockIdx.x, p.fd_T, (uint32_t)p.T, u, u_tap);
@@ -137,11 +150,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     uint32_t wx = 0, wy = 0;
     if constexpr (KIND == 1) {
       // one hashed word covers an aligned 16-element run; pair j of the word has its signs at bits 15 - j and 31 - j
-      wy = btx_sign_word(r.yi >> 5, p.kout_a, p.kout_b) << ((r.yi & 31u) >> 1);
+      wy = btx_sign_word(r.yi >> 5, kout_a, kout_b) << ((r.yi & 31u) >> 1);
       if (x_al16) {
-        wx = btx_sign_word(r.xi >> 5, p.kin_a, p.kin_b) << ((r.xi & 31u) >> 1);
+        wx = btx_sign_word(r.xi >> 5, kin_a, kin_b) << ((r.xi & 31u) >> 1);
       } else {  // the run may straddle two words: the 32 signs starting at element xi (btx_contract_stem.h)
-        const uint32_t w = btx_sign_word(r.xi >> 5, p.kin_a, p.kin_b), w1 = btx_sign_word((r.xi >> 5) + 1u, p.kin_a, p.kin_b);
+        const uint32_t w = btx_sign_word(r.xi >> 5, kin_a, kin_b), w1 = btx_sign_word((r.xi >> 5) + 1u, kin_a, kin_b);
         const uint32_t k = (r.xi & 31u) >> 1;
         const uint32_t lo = ((w & 0xffffu) << 16) | (w1 & 0xffffu), hi = (w & 0xffff0000u) | (w1 >> 16);
         wx = ((lo << k) >> 16) | ((hi << k) & 0xffff0000u);
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             if (p.sign_in) neg = p.sign_in[i] < 0;
             else {
               const uint32_t wi = (uint32_t)(i >> 5);
-              if (wi != cwi) { cwi = wi; cw = btx_sign_word(wi, p.kin_a, p.kin_b); }
+              if (wi != cwi) { cwi = wi; cw = btx_sign_word(wi, kin_a, kin_b); }
               neg = (cw >> btx_sign_bitpos((uint32_t)i & 31u)) & 1u;
             }
           }
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             if (p.sign_out) neg = p.sign_out[i] < 0;
             else {
               const uint32_t wi = (uint32_t)(i >> 5);
-              if (wi != cwi) { cwi = wi; cw = btx_sign_word(wi, p.kout_a, p.kout_b); }
+              if (wi != cwi) { cwi = wi; cw = btx_sign_word(wi, kout_a, kout_b); }
               neg = (cw >> btx_sign_bitpos((uint32_t)i & 31u)) & 1u;
             }
           }
@@ -371,8 +384,10 @@ void sign_keys_host(const BtxRng* rng, uint32_t stream, uint32_t* ka, uint32_t* 
 __global__ __launch_bounds__(256) void dgrad_weights_kernel(const float* __restrict__ mu, const float* __restrict__ rho,
                                                             float* __restrict__ omu, float* __restrict__ orho,
                                                             float* __restrict__ oeps, int N, int T, int C, int flip, int ctiles,
-                                                            int ntiles, uint32_t k0, uint32_t k1, uint32_t sample, uint32_t layer) {
+                                                            int ntiles, uint32_t k0, uint32_t k1, uint32_t sample, uint32_t layer,
+                                                            const uint32_t* __restrict__ sample_ptr) {
   __shared__ float tm[32][33], tr[32][33], te[32][33];
+  if (sample_ptr) sample = __builtin_amdgcn_readfirstlane(*sample_ptr);
   const int b = blockIdx.x;
   const int ct = b % ctiles, nt = (b / ctiles) % ntiles, t = b / (ctiles * ntiles);
   const int tp = flip ? T - 1 - t : t;
@@ -428,7 +443,7 @@ extern "C" int btx_dgrad_weights(const float* mu_w, const float* rho_w, float* o
   if (nwg > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
   hipLaunchKernelGGL(dgrad_weights_kernel, dim3((int)nwg), dim3(256), 0, (hipStream_t)stream, mu_w, rho_w, out_mu, out_rho, out_eps, N,
                      T, C, flip ? 1 : 0, ctiles, ntiles, (uint32_t)rng->seed, (uint32_t)(rng->seed >> 32), rng->sample_idx,
-                     rng->layer_id);
+                     rng->layer_id, rng->sample_idx_dev);
   return (int)hipGetLastError();
 }
 
@@ -446,7 +461,6 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
   // 7x7x3 stem: 7 x 32 of a 64-wide tile instead of 49 x 3 of 64) — and the signs are the forward's hashed ones
   const bool rowfuse = (flags & BTX_FLAG_ROWFUSE) != 0;
   if (rowfuse && (g->groups != 1 || g->D != 1 || g->KD != 1 || g->pw != 0 || g->dw != 1)) return BTX_E_UNSUPPORTED;
-  if (rng->sample_idx_dev) return BTX_E_UNSUPPORTED;
   int32_t Do, Ho, Wo;
   int rc = btx_out_shape(g, 0, &Do, &Ho, &Wo);
   if (rc) return rc;
@@ -476,6 +490,8 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
   const bool swap = (flags & BTX_FLAG_SWAP_SIGNS) != 0;  // transposed layers: the roles of x and dy are exchanged
   sign_keys_host(rng, swap ? BTX_STREAM_SIGN_OUT : BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
   sign_keys_host(rng, swap ? BTX_STREAM_SIGN_IN : BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
+  p.sample_ptr = rng->sample_idx_dev; p.seed_lo = (uint32_t)rng->seed; p.seed_hi = (uint32_t)(rng->seed >> 32); p.layer = rng->layer_id;
+  p.swap = swap ? 1 : 0;
   p.fd_Wo = make_fastdiv((uint32_t)Wo); p.fd_Ho = make_fastdiv((uint32_t)Ho); p.fd_Do = make_fastdiv((uint32_t)Do);
   p.fd_T = make_fastdiv((uint32_t)p.T); p.fd_ctiles = make_fastdiv((uint32_t)p.ctiles);
   p.fd_ntiles = make_fastdiv((uint32_t)p.ntiles); p.fd_groups = make_fastdiv((uint32_t)p.groups);

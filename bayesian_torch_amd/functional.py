@@ -455,7 +455,7 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
 
 
 def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, swap=False, bias=False, rowfuse=None,
-              _flags=0, raw=False):
+              _flags=0, raw=False, sample_dev=None):
     """btx_contract_wgrad: (dW_mu, dW_delta | None, db_mu | None, db_delta | None) in the layer's LOGICAL weight layout
     (f32).  `op` is a plain (non-transposed) contraction; `signs` = (sign_in, sign_out) logical +/-1 tensors for layers
     whose forward ran on padded layouts, else the forward's hashed signs are regenerated.  `rowfuse` = the layer's
@@ -472,7 +472,7 @@ def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, 
             dy = F.pad(dy, (0, fo[2] - dy.shape[3], 0, fo[1] - dy.shape[2]))
         kh, kwp, cp, kw, cin = fop.kernel[1], plan["kwp"], plan["cp"], plan["kw"], plan["cin"]
         dwm, dwd, dbm, dbd = wgrad_hip(kind, xin, dy, fop, seed, sample_idx, layer_id, (fop.out_channels, cp, kh, kwp),
-                                       bias=bias, _flags=_lib.FLAG_ROWFUSE)
+                                       bias=bias, _flags=_lib.FLAG_ROWFUSE, sample_dev=sample_dev)
         un = lambda t: t[:, :cin, :, :kw].contiguous() if t is not None else None  # noqa: E731
         return un(dwm), un(dwd), dbm, dbd
     xp, nb, spatial, _ = _to_channels_last(x, op)
@@ -505,7 +505,8 @@ def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, 
         so = _sign_to_int8_cl(signs[1].reshape(dy2.shape), yop)
         keep += [si, so]
         nz.sign_in, nz.sign_out = si.data_ptr(), so.data_ptr()
-    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF, None)
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF,
+                 sample_dev.data_ptr() if sample_dev is not None else None)
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     _lib.check(L.btx_contract_wgrad(kind, ctypes.byref(g), xp.data_ptr(), dyp.data_ptr(), dwm.data_ptr(), ptr(dwd), ptr(dbm),
                                     ptr(dbd), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None, act,
@@ -653,35 +654,39 @@ def pad_channels(x, op, extra):
     return xp.permute((0, nd + 1) + tuple(range(1, nd + 1)))
 
 
-def fill_eps_hip(n, device, seed, sample_idx, layer_id, rng_stream):
-    """BTX-RNG v1 eps for a flat index space of n elements, as a flat f32 CUDA tensor."""
+def fill_eps_hip(n, device, seed, sample_idx, layer_id, rng_stream, sample_dev=None):
+    """BTX-RNG v1 eps for a flat index space of n elements, as a flat f32 CUDA tensor.  sample_dev: the sample index lives in
+    that device word (captured steps) and sample_idx is ignored."""
     L = _lib.lib()
     out = torch.empty(int(n), dtype=torch.float32, device=device)
-    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF,
+                 sample_dev.data_ptr() if sample_dev is not None else None)
     _lib.check(L.btx_fill_eps(out.data_ptr(), out.numel(), ctypes.byref(r), rng_stream,
                               torch.cuda.current_stream(out.device).cuda_stream))
     return out
 
 
-def rho_grad_hip(dw_flat, rho_flat, seed, sample_idx, layer_id, rng_stream, out=None):
+def rho_grad_hip(dw_flat, rho_flat, seed, sample_idx, layer_id, rng_stream, out=None, sample_dev=None):
     """btx_rho_grad: drho = dw * eps * sigmoid(rho) over flat f32 tensors in the same (GEMM-major) element order, eps
     regenerated inside the kernel.  `out` may be dw_flat itself."""
     L = _lib.lib()
     if out is None:
         out = torch.empty_like(dw_flat)
-    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF,
+                 sample_dev.data_ptr() if sample_dev is not None else None)
     _lib.check(L.btx_rho_grad(dw_flat.data_ptr(), rho_flat.data_ptr(), out.data_ptr(), dw_flat.numel(), ctypes.byref(r),
                               rng_stream, torch.cuda.current_stream(dw_flat.device).cuda_stream))
     return out
 
 
-def dgrad_weights_hip(mu_p, rho_p, n, taps, c, flip, seed, sample_idx, layer_id):
+def dgrad_weights_hip(mu_p, rho_p, n, taps, c, flip, seed, sample_idx, layer_id, sample_dev=None):
     """btx_dgrad_weights: (mu, rho, eps) of the data gradient's transposed geometry, GEMM-major [c][taps][n] f32, from the layer's
     own GEMM-major parameters [n][taps][c] in ONE launch (eps = the forward's draw, regenerated)."""
     L = _lib.lib()
     dev = mu_p.device
     outs = [torch.empty(int(c) * int(taps) * int(n), dtype=torch.float32, device=dev) for _ in range(3)]
-    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF)
+    r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF,
+                 sample_dev.data_ptr() if sample_dev is not None else None)
     _lib.check(L.btx_dgrad_weights(mu_p.data_ptr(), rho_p.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
                                    int(n), int(taps), int(c), 1 if flip else 0, ctypes.byref(r),
                                    torch.cuda.current_stream(dev).cuda_stream))

@@ -424,7 +424,7 @@ class _VariationalNd(BaseVariationalLayer_):
             cache[key] = BF.rowfuse_plan(self._op, key)
         return cache[key]
 
-    def materialize_noise(self, sample_idx, x_shape=None, out_shape=None, x_dtype=None, signs=True):
+    def materialize_noise(self, sample_idx, x_shape=None, out_shape=None, x_dtype=None, signs=True, sample_dev=None):
         """The noise BTX-RNG v1 defines for MC sample `sample_idx` of this layer, in the reference's logical
         layouts: dict(eps_w, eps_b[, sign_in, sign_out]).  Also refreshes the eps_* buffers (the reference's
         observable side effect, conv_variational.py:362).  signs=False: skip the Flipout sign tensors (the backward
@@ -432,17 +432,24 @@ class _VariationalNd(BaseVariationalLayer_):
         mu, _ = self._w()
         op, seed, lid = self._op, _rng.seed(), self._btx_layer_id
         cin, cpad = op.in_channels, self._btx_cpad
+        # sample_dev (captured training steps): the index lives in a device word; eps follows it, the sign TENSORS (padded
+        # layouts only) are keyed on the host and cannot
+        if sample_dev is not None and signs and self._family == "flipout" and x_shape is not None:
+            raise _lib.BtxError("sign tensors of padded layouts need a host-side sample index: this layer cannot run in a captured step")
+        _fill_eps = BF.fill_eps_hip
+        if sample_dev is not None:
+            _fill_eps = lambda n, dev, sd, si, li, st: BF.fill_eps_hip(n, dev, sd, si, li, st, sample_dev=sample_dev)  # noqa: E731
         plan = None
         if x_shape is not None and op.nd == 2 and cin <= 4:
             plan = BF.rowfuse_plan(op, tuple(x_shape))
         if plan is not None:  # indices run over the row-fused layouts: weights [Cout][KH][kwp][cp], input [N][Hp][Wp][cp]
             kh, kw, kwp, cp = op.kernel[1], plan["kw"], plan["kwp"], plan["cp"]
-            flat = BF.fill_eps_hip(mu.shape[0] * kh * kwp * cp, mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+            flat = _fill_eps(mu.shape[0] * kh * kwp * cp, mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
             e = flat.reshape(mu.shape[0], kh, kwp, cp)[:, :, :kw, :cin].permute(0, 3, 1, 2).contiguous()
             d = {"eps_w": e}
             getattr(self, "eps_" + self._wn).copy_(e)
             if self.mu_bias is not None:
-                d["eps_b"] = BF.fill_eps_hip(self.mu_bias.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_B)
+                d["eps_b"] = _fill_eps(self.mu_bias.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_B)
                 self.eps_bias.copy_(d["eps_b"])
             if self._family == "flipout" and signs:
                 n, _, h, w = x_shape
@@ -456,14 +463,14 @@ class _VariationalNd(BaseVariationalLayer_):
                 d["sign_out"] = so[:, :plan["Ho"], :plan["Wo"], :].permute(0, 3, 1, 2)
             return d
         if cpad is None:
-            flat = BF.fill_eps_hip(mu.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+            flat = _fill_eps(mu.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
         else:  # indices run over the zero-padded [N][tap][cpad] layout
-            flat = BF.fill_eps_hip(mu.numel() // cin * cpad, mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
+            flat = _fill_eps(mu.numel() // cin * cpad, mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_W)
             flat = flat.reshape(-1, cpad)[:, :cin].reshape(-1)
         d = {"eps_w": BF.unpack_gemm_major(flat, tuple(mu.shape), op)}
         getattr(self, "eps_" + self._wn).copy_(d["eps_w"])
         if self.mu_bias is not None:
-            d["eps_b"] = BF.fill_eps_hip(self.mu_bias.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_B)
+            d["eps_b"] = _fill_eps(self.mu_bias.numel(), mu.device, seed, sample_idx, lid, _lib.STREAM_EPS_B)
             self.eps_bias.copy_(d["eps_b"])
         if self._family == "flipout" and x_shape is not None and signs:
             def cl_to_logical(flat8, shape):

@@ -722,7 +722,30 @@ def run_train_step(dev, steps=5):
     for _ in range(steps):
         loss = step()
     torch.cuda.synchronize(dev)
-    ms = 1e3 * (time.perf_counter() - t0) / steps
+    ms_eager = 1e3 * (time.perf_counter() - t0) / steps
+    loss_finite = bool(torch.isfinite(loss))
+    del loss  # the eager step's autograd graph must be gone before the capture (its AccumulateGrad nodes live on this stream)
+    for p_ in model.parameters():
+        p_.grad = None
+    # the same step captured once into a hipGraph (autograd.GraphedTrainStep: the MC sample index lives in a device word): an eager
+    # step is ~590 launches dispatched by Python / ATen and bound by the host
+    ms, graphed = ms_eager, None
+    try:
+        from bayesian_torch_amd.autograd import GraphedTrainStep
+        gs = GraphedTrainStep(model, x, y)
+        for i in range(2):
+            gs.run(100 + i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(max(steps, 10)):
+            gl = gs.run(200 + i)
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.perf_counter() - t0) / max(steps, 10)
+        loss_finite = loss_finite and bool(torch.isfinite(gl))
+        graphed = True
+        gs.close()
+    except Exception as e:  # noqa — a runtime that cannot capture: the eager figure stands
+        graphed = "capture failed: %s: %s" % (type(e).__name__, e)
     # parity figure: the same step (same parameters, same MC sample index => same BTX-RNG noise) in f32 parity mode —
     # loss and the weight gradients of the first convolution, a layer3 convolution and the classifier
     def grads(m, xin):
@@ -759,9 +782,22 @@ def run_train_step(dev, steps=5):
     # each; the stem counted with its own 7x7x3 taps, not the padded row-fused geometry)
     gflop = 464.4 + (464.4 - 30.2) + 464.4
     return {"workload": "training step (README.md:114-125): dnn_to_bnn(ResNet18) Flipout bs64, bf16 activations, forward + "
-                        "CE + KL/B + backward through libbtx (bf16-MFMA weight gradients, HIP BatchNorm), eager launches",
-            "ms_per_step": ms, "achieved_tflops": gflop / ms, "loss_finite": bool(torch.isfinite(loss)),
+                        "CE + KL/B + backward through libbtx (bf16-MFMA weight gradients, HIP BatchNorm), one hipGraph replay per step (ms_per_step_eager: launched from Python)",
+            "ms_per_step": ms, "ms_per_step_eager": ms_eager, "hipgraph": graphed, "achieved_tflops": gflop / ms,
+            "loss_finite": loss_finite,
             "parity_vs_f32_mode": parity}
+
+
+def run_train_step_isolated(timeout_s=420):
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-step-only"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": "train-step subprocess rc %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+    except Exception as e:  # noqa
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def summarise_extra(name, r, prec, table=False):
@@ -871,7 +907,7 @@ def compact_line(out):
             short = {"cfg4_strong_shape_4_per_rank": "strong_shape", "cfg4_f32_parity_mode": "cfg4_f32"}.get(k, k)
             e2[short] = _pick(v, ("value", "ms_per_step", "frac_e2e", "dominant_kernel_frac", "kl_rel_err",
                                   "logits_rel_l2_vs_unfused_f32", "logits_rel_l2_vs_f32_mode", "vs_weak_region",
-                                  "achieved_tflops", "hbm_rows_min_frac", "lanes"))
+                                  "achieved_tflops", "hbm_rows_min_frac", "lanes", "ms_per_step_eager"))
         line["extra"] = e2
     line["detail"] = "gpurun_out/bench_detail.json"
     line = _sig(line)
@@ -1004,8 +1040,12 @@ def main():
     ap.add_argument("--no-stem-pool", action="store_true", help="A/B: the stem's max-pool as its own kernel instead of folded "
                     "into the stem launch (BtxEpilogue.pool)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank protocol (no GPU)")
+    ap.add_argument("--train-step-only", action="store_true", help="print the extra.train_step result (JSON) and exit")
     args = ap.parse_args()
 
+    if args.train_step_only:
+        print(json.dumps(run_train_step(torch.device("cuda", 0))))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:], args.dry_run))
 
@@ -1159,7 +1199,9 @@ def main():
                     "ms_per_step": r["ms_per_step"], "ms_per_region": r["ms_per_step"] * 4, "value": r["value"],
                     "unit": "MC-samples/s", "ms_per_step_runs": r.get("ms_per_step_runs"),
                     "vs_weak_region": r["value"] / head["value"]}
-                extra["train_step"] = run_train_step(dev)
+                # in a process of its own: the step captures autograd into a hipGraph, and nothing that could go wrong there
+                # (a runtime that aborts instead of raising) may cost the run its JSON line
+                extra["train_step"] = run_train_step_isolated()
             except Exception as e:  # noqa — the headline must survive a failing extra
                 extra["error"] = "%s: %s" % (type(e).__name__, e)
             out["extra"] = extra

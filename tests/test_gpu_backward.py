@@ -469,3 +469,56 @@ def test_dgrad_weights_one_launch_equals_the_torch_chain(N, T, C, flip):
         t = t.flip(1) if flip else t
         return t.permute(2, 1, 0).contiguous().reshape(-1)
     assert torch.equal(om, tr(mu)) and torch.equal(orh, tr(rho)) and torch.equal(oe, tr(eps))
+
+
+def test_captured_training_step_equals_the_eager_step():
+    """autograd.GraphedTrainStep: forward + CE + KL / B + backward of a converted ResNet18 captured into one hipGraph; a replay with
+    the sample word set to s must give the loss and the gradients of the eager step with set_sample_index(model, s) (same kernels,
+    same noise; the weight gradient's f32 atomics may reorder sums: 1e-5), and two replays with different words must differ."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models import resnet
+    from bayesian_torch_amd.models.fuse import hip_batchnorm
+    from bayesian_torch_amd.autograd import GraphedTrainStep
+    dev = _dev()
+    bt.manual_seed(2024)
+    bt.set_precision("f32")
+    torch.manual_seed(0)
+    m = resnet.resnet18()
+    bt.dnn_to_bnn(m, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Flipout",
+                          moped_enable=False, moped_delta=0.5))
+    m = m.to(dev).train()
+    bt.assign_layer_ids(m)
+    hip_batchnorm(m)
+    for mod in m.modules():  # BatchNorm in eval-like frozen-statistics mode would differ between the two runs: keep momentum 0
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 0.0
+    torch.manual_seed(1)
+    x = torch.randn(4, 3, 224, 224, device=dev)
+    t = torch.randint(0, 1000, (4,), device=dev)
+
+    def eager(s):
+        for p_ in m.parameters():
+            p_.grad = None
+        bt.set_sample_index(m, s)
+        out = m(x)
+        loss = torch.nn.functional.cross_entropy(out.float(), t) + bt.get_kl_loss(m) / 4
+        loss.backward()
+        return float(loss), [p_.grad.detach().clone() for p_ in (m.conv1.mu_kernel, m.conv1.rho_kernel, m.layer2[0].conv1.rho_kernel,
+                                                                 m.layer4[1].conv2.mu_kernel, m.fc.rho_weight, m.fc.rho_bias, m.bn1.weight)]
+    l7, g7 = eager(7)
+    gs = GraphedTrainStep(m, x, t)
+    la = float(gs.run(7))
+    ga = [p_.grad.detach().clone() for p_ in (m.conv1.mu_kernel, m.conv1.rho_kernel, m.layer2[0].conv1.rho_kernel,
+                                              m.layer4[1].conv2.mu_kernel, m.fc.rho_weight, m.fc.rho_bias, m.bn1.weight)]
+    lb = float(gs.run(8))
+    gb = m.layer2[0].conv1.rho_kernel.grad.detach().clone()
+    gs.close()
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    errs = [rel(a, b) for a, b in zip(ga, g7)]
+    print("captured vs eager training step (sample 7): loss %.6f / %.6f, gradient rel-L2 %s; sample 8 loss %.6f" % (
+        la, l7, ", ".join("%.1e" % e for e in errs), lb))
+    assert abs(la - l7) < 1e-5 * abs(l7)
+    assert max(errs) < 1e-5, errs
+    assert abs(lb - la) > 0 and rel(gb, ga[2]) > 1e-3  # another sample index: other noise
+    l7b, _ = eager(7)  # the model is back to host-side sample indices
+    assert abs(l7b - l7) < 1e-5 * abs(l7)
