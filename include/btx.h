@@ -126,7 +126,9 @@ typedef struct BtxRng {
   const uint32_t* sample_idx_dev; /* optional DEVICE pointer: when non-NULL the kernels read the sample index from it
                                      when they run and sample_idx is ignored.  This is what lets one captured hipGraph
                                      of a whole MC forward be replayed for successive samples (update the word, replay):
-                                     no per-launch host work in the Monte-Carlo loop. */
+                                     no per-launch host work in the Monte-Carlo loop.  Honoured by every entry point that
+                                     takes a BtxRng except btx_fill_sign (ABI 7: also btx_contract_wgrad, btx_rho_grad,
+                                     btx_fill_eps, btx_dgrad_weights — a whole TRAINING step can be captured). */
 } BtxRng;
 
 /* Optional explicit noise (parity mode).  Any member may be NULL => generated by BTX-RNG v1.
