@@ -692,8 +692,8 @@ def test_single_sample_linear_layers_sample_inside_their_launch():
     dev = _dev()
     bt.manual_seed(3)
     torch.manual_seed(0)
-    layer = L.LinearFlipout(784, 512).to(dev)
-    x = torch.randn(256, 784, device=dev)
+    layer = L.LinearFlipout(768, 512).to(dev)
+    x = torch.randn(256, 768, device=dev)
     for prec, act, tol in (("f32", torch.float32, 1e-5), ("bf16", torch.bfloat16, 1e-2)):
         layer.precision = prec
         xx = x.to(act)
@@ -705,7 +705,7 @@ def test_single_sample_linear_layers_sample_inside_their_launch():
             bt.set_sample_lanes(layer, [5, 6], batch=256)
             assert layer.presample_item(5, prec) is not None
             bt.set_sample_lanes(layer, None)
-            big = torch.randn(512, 784, device=dev).to(act)
+            big = torch.randn(512, 768, device=dev).to(act)
             layer._forward_hip(big, sample_idx=5)
             assert layer.presample_item(5, prec) is not None                  # 512 rows: two pixel tiles share a weight tile
             layer._forward_hip(xx, sample_idx=5)
@@ -714,5 +714,5 @@ def test_single_sample_linear_layers_sample_inside_their_launch():
         ref = bt_ref.flipout_forward(c(xx), c(layer.mu_weight), c(layer.rho_weight), c(layer.mu_bias), c(layer.rho_bias), c(nz["eps_w"]),
                                      c(nz["eps_b"]), c(nz["sign_in"]), c(nz["sign_out"]), dict(kind="linear"))
         err = float((out.float().cpu() - ref).norm() / ref.norm())
-        print("LinearFlipout 784->512, 256 rows, %s, sampled in the launch: rel-L2 vs the CPU reference chain %.2e" % (prec, err))
+        print("LinearFlipout 768->512, 256 rows, %s, sampled in the launch: rel-L2 vs the CPU reference chain %.2e" % (prec, err))
         assert err < tol, (prec, err)
