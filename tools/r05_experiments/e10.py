@@ -1,6 +1,6 @@
 """E10: two hipGraphs of L/2 lanes replayed concurrently on two streams vs one graph of L lanes (fills the launch tails?)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 import bayesian_torch_amd as bt
 from bayesian_torch_amd import mc

@@ -1,5 +1,5 @@
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 import bayesian_torch_amd as bt
 from bayesian_torch_amd import rng as _rng, mc
