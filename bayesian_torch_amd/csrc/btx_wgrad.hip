@@ -141,11 +141,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     r.y[0] = out_ok ? y0 : z; r.y[1] = out_ok ? y1 : z;
     r.xi = (uint32_t)xo; r.yi = (uint32_t)yo;
   };
-  // Fast path: the tiles go to LDS TRANSPOSED and stay bf16 — T[channel][pixel], 144-byte rows — so that an MFMA fragment
-  // (8 consecutive pixels of one channel) is one 16-byte read and the product runs on v_mfma_f32_32x32x16_bf16 (bf16 x bf16
-  // products are exact in f32, the accumulation stays f32: the same gradient as the f32 MFMA, 16x the matrix rate).
-  // dword d of half hf of a run holds elements 8 hf + 2d (low half) and + 1 (high half).
-  constexpr int TR_ROW = 64 * 2 + 16;
+  // Fast path (round 5): the tiles stay bf16 and PIXEL-MAJOR in LDS — four blocks of 16 channels, each [64 pixels][16 channels] with
+  // 32-byte rows — written with 16-byte stores (two per operand per thread; round 2-4 wrote the transpose with sixteen 2-byte
+  // stores per operand: the kernel was bound by that staging).  The MFMA fragments — 8 consecutive pixels of one channel — come out
+  // of gfx950's transpose read instead: ds_read_b64_tr_b16 hands lane c of a 16-lane group column c of the 4 x 16 block the group's
+  // lanes address (lane i: row i/4, columns 4(i%4)..; probed on hardware: tools/ubench/tr_probe.hip), i.e. 4 pixels of channel c.
+  // Block bases are skewed by {0, 16, 64, 80} bytes so that the eight lanes of a 16-byte store group hit eight distinct slots.
+  // bf16 x bf16 products are exact in f32 and the accumulation stays f32: the same gradient as before.
+  constexpr int TB_BLK = 64 * 32 + 128;  // bytes per 16-channel block (+ room for the skew)
+  auto blk_base = [](int q) __attribute__((always_inline)) { return q * TB_BLK + ((q & 1) + 4 * (q >> 1)) * 16; };
   auto stash = [&](const Raw& r) __attribute__((always_inline)) {
     uint32_t wx = 0, wy = 0;
     if constexpr (KIND == 1) {
@@ -160,30 +164,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         wx = ((lo << k) >> 16) | ((hi << k) & 0xffff0000u);
       }
     }
-    // rows 16 apart are a multiple of 64 dwords apart whatever the (16-byte aligned) pitch: the four channel groups of a
-    // wave's write would hit the same banks (measured: 158 -> 122 us per ResNet18 layer).  Rotate the pixel axis by 16 per
-    // channel group instead.  (Packing two neighbouring pixels into 4-byte writes through DPP: measured slower, 143 us —
-    // the extra VALU outweighs the saved LDS cycles.)
-    const int col = ((s_px + 16 * s_q) & 63) * 2;
+    const int off = blk_base(s_q) + s_px * 32;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+    for (int hf = 0; hf < 2; ++hf) {
+      *(u32x4*)(t_x + off + 16 * hf) = r.x[hf];
+      *(u32x4*)(t_dy + off + 16 * hf) = r.y[hf];
+      if constexpr (KIND == 1) {
+        u32x4 xs_, ys_;
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int row = (16 * s_q + 8 * hf + 2 * d) * TR_ROW + col;  // channel of the dword's low half; the high half: next row
-        const uint32_t xv_ = r.x[hf][d], yv_ = r.y[hf][d];
-        *(uint16_t*)(t_x + row) = (uint16_t)xv_;
-        *(uint16_t*)(t_x + row + TR_ROW) = (uint16_t)(xv_ >> 16);
-        *(uint16_t*)(t_dy + row) = (uint16_t)yv_;
-        *(uint16_t*)(t_dy + row + TR_ROW) = (uint16_t)(yv_ >> 16);
-        if constexpr (KIND == 1) {
+        for (int d = 0; d < 4; ++d) {
           const int j = 4 * hf + d;  // pair index of the dword inside the run
-          const uint32_t xs_ = xv_ ^ ((wx << j) & 0x80008000u), ys_ = yv_ ^ ((wy << j) & 0x80008000u);
-          *(uint16_t*)(t_xs + row) = (uint16_t)xs_;
-          *(uint16_t*)(t_xs + row + TR_ROW) = (uint16_t)(xs_ >> 16);
-          *(uint16_t*)(t_dys + row) = (uint16_t)ys_;
-          *(uint16_t*)(t_dys + row + TR_ROW) = (uint16_t)(ys_ >> 16);
+          xs_[d] = r.x[hf][d] ^ ((wx << j) & 0x80008000u);
+          ys_[d] = r.y[hf][d] ^ ((wy << j) & 0x80008000u);
         }
+        *(u32x4*)(t_xs + off + 16 * hf) = xs_;
+        *(u32x4*)(t_dys + off + 16 * hf) = ys_;
       }
+    }
   };
   Raw raw;
   if constexpr (fast) { if (m_begin < m_end) fetch(m_begin, raw); }
@@ -266,18 +263,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     __syncthreads();
     if constexpr (fast) { if (m0 + WG_PX < m_end) fetch(m0 + WG_PX, raw); }  // in flight during the MFMAs below
     if constexpr (fast) {
-      // ---- multiply (bf16 MFMA): wave w takes pixels 16w..16w+15 of the step = one k-step of 16
+      // ---- multiply (bf16 MFMA): wave w takes pixels 16w..16w+15 of the step = one k-step of 16.  Fragment of lane (l31, hk) for
+      // channel half i: channel 32 i + l31, pixels 16w + 8hk + 0..7 = two transpose reads of 4 pixels each; within the lane's
+      // 16-lane group (channel block 2i + (l31 >> 4)) lane c addresses row (c >> 2), columns 4 (c & 3).. of the 4-pixel x 16-channel block
       bf16x8 a[2], b[2], as_[2], bs_[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rn = 32 * i + l31;
-        const int ko = ((16 * wave + 8 * hk + 16 * ((rn >> 4) & 3)) & 63) * 2;  // the row's rotation of the pixel axis
-        a[i] = *(const bf16x8*)(t_dy + rn * TR_ROW + ko);
-        b[i] = *(const bf16x8*)(t_x + rn * TR_ROW + ko);
+      {
+        const int c16 = lane & 15, g16 = (lane >> 4) & 1;
+        const int lane_off = (16 * wave + 8 * hk + (c16 >> 2)) * 32 + (c16 & 3) * 8;
+        auto lds_addr = [&](const unsigned char* tile, int blk) __attribute__((always_inline)) -> uint32_t {
+          return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(tile + blk_base(blk) + lane_off);
+        };
+        // all transpose reads of the step in flight together, one wait (inline asm: the compiler does not track these reads)
+        const uint32_t ad0 = lds_addr(t_dy, g16), ad1 = lds_addr(t_dy, 2 + g16), bd0 = lds_addr(t_x, g16), bd1 = lds_addr(t_x, 2 + g16);
+        u32x2 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h;
         if constexpr (KIND == 1) {
-          as_[i] = *(const bf16x8*)(t_dys + rn * TR_ROW + ko);
-          bs_[i] = *(const bf16x8*)(t_xs + rn * TR_ROW + ko);
+          const uint32_t as0 = lds_addr(t_dys, g16), as1 = lds_addr(t_dys, 2 + g16), bs0 = lds_addr(t_xs, g16), bs1 = lds_addr(t_xs, 2 + g16);
+          u32x2 c0l, c0h, c1l, c1h, d0l, d0h, d1l, d1h;
+          asm volatile(
+              "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:128\n\t"
+              "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:128\n\t"
+              "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:128\n\t"
+              "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:128\n\t"
+              "ds_read_b64_tr_b16 %8, %20\n\tds_read_b64_tr_b16 %9, %20 offset:128\n\t"
+              "ds_read_b64_tr_b16 %10, %21\n\tds_read_b64_tr_b16 %11, %21 offset:128\n\t"
+              "ds_read_b64_tr_b16 %12, %22\n\tds_read_b64_tr_b16 %13, %22 offset:128\n\t"
+              "ds_read_b64_tr_b16 %14, %23\n\tds_read_b64_tr_b16 %15, %23 offset:128\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h), "=&v"(c0l), "=&v"(c0h),
+                "=&v"(c1l), "=&v"(c1h), "=&v"(d0l), "=&v"(d0h), "=&v"(d1l), "=&v"(d1h)
+              : "v"(ad0), "v"(ad1), "v"(bd0), "v"(bd1), "v"(as0), "v"(as1), "v"(bs0), "v"(bs1)
+              : "memory");
+          as_[0] = __builtin_bit_cast(bf16x8, (u32x4){c0l[0], c0l[1], c0h[0], c0h[1]});
+          as_[1] = __builtin_bit_cast(bf16x8, (u32x4){c1l[0], c1l[1], c1h[0], c1h[1]});
+          bs_[0] = __builtin_bit_cast(bf16x8, (u32x4){d0l[0], d0l[1], d0h[0], d0h[1]});
+          bs_[1] = __builtin_bit_cast(bf16x8, (u32x4){d1l[0], d1l[1], d1h[0], d1h[1]});
+        } else {
+          asm volatile(
+              "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:128\n\t"
+              "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:128\n\t"
+              "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:128\n\t"
+              "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:128\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(a0l), "=&v"(a0h), "=&v"(a1l), "=&v"(a1h), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h)
+              : "v"(ad0), "v"(ad1), "v"(bd0), "v"(bd1)
+              : "memory");
         }
+        a[0] = __builtin_bit_cast(bf16x8, (u32x4){a0l[0], a0l[1], a0h[0], a0h[1]});
+        a[1] = __builtin_bit_cast(bf16x8, (u32x4){a1l[0], a1l[1], a1h[0], a1h[1]});
+        b[0] = __builtin_bit_cast(bf16x8, (u32x4){b0l[0], b0l[1], b0h[0], b0h[1]});
+        b[1] = __builtin_bit_cast(bf16x8, (u32x4){b1l[0], b1l[1], b1h[0], b1h[1]});
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -288,17 +322,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             if constexpr (KIND == 1) acc_d[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_[i], bs_[j], acc_d[i][j], 0, 0, 0);
           }
         }
-      if (do_bias && tid < 64) {  // column n = tid of dy: its 64 pixels are one row of the transposed tile
-#pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) {
-          const u32x4 v = *(const u32x4*)(t_dy + tid * TR_ROW + q8 * 16);
-#pragma unroll
-          for (int d = 0; d < 4; ++d) bsum_m += u2f(v[d] << 16) + u2f(v[d] & 0xffff0000u);
-          if constexpr (KIND == 1) {
-            const u32x4 vs = *(const u32x4*)(t_dys + tid * TR_ROW + q8 * 16);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) bsum_d += u2f(vs[d] << 16) + u2f(vs[d] & 0xffff0000u);
-          }
+      if (do_bias && tid < 64) {  // column n = tid of dy: one 2-byte element per pixel row of its 16-channel block
+        const unsigned char* cb = t_dy + blk_base(tid >> 4) + (tid & 15) * 2;
+        const unsigned char* cbs = t_dys + blk_base(tid >> 4) + (tid & 15) * 2;
+        for (int q = 0; q < WG_PX; ++q) {
+          bsum_m += u2f((uint32_t)(*(const uint16_t*)(cb + q * 32)) << 16);
+          if constexpr (KIND == 1) bsum_d += u2f((uint32_t)(*(const uint16_t*)(cbs + q * 32)) << 16);
         }
       }
     } else {
