@@ -7,7 +7,7 @@
 // ATen kernels (batch_norm_collect_statistics / _backward_reduce / _backward_elemt / _transform_input, channels-last bf16) took
 // 3.65 ms of a 10.6 ms step for 2.5 GB of traffic (0.7 TB/s).  These are plain HBM-bound passes:
 //
-//   forward   stats: one pass over x  -> per-block (sum, sum of squares) per channel in f32 -> fixed-order f64 fold: mean, 1/sqrt(var + eps),
+//   forward   stats: one pass over x  -> per-block sums of (x - pivot), (x - pivot)^2 per channel in f32 (pivot = row 0) -> fixed-order f64 fold: mean, 1/sqrt(var + eps),
 //             the running estimates, and the per-channel (scale, shift) of the apply pass
 //             apply: y = x * scale[c] + shift[c]                                  (one read, one write)
 //   backward  reduce: one pass over (x, dy) -> sum(dy), sum(dy * xhat) per channel -> dgamma, dbeta and the three coefficients of
@@ -90,6 +90,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const ACT* __restrict__
 #pragma unroll
     for (int i = 0; i < 8; ++i) { mu[i] = mean[g * 8 + i]; is[i] = invstd[g * 8 + i]; }
   }
+  // MODE 0: sums of (x - pivot) and (x - pivot)^2 with pivot = the channel's value in row 0: E[x^2] - E[x]^2 on raw f32 sums loses
+  // the variance of a channel whose mean is large against its spread; shifted by any value of the channel it does not
+  if (MODE == 0 && act) load8<ACT>(x + g * 8, mu);
   if (act) {
     // four rows in flight per thread (the pass is bound by how many 16-byte loads a CU keeps outstanding), summed in row order
     const long long stride = (long long)gridDim.x * rpb;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const ACT* __restrict__
         if (!ok[u]) continue;
         if (MODE == 0) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { s0[i] += v[u][i]; s1[i] = __builtin_fmaf(v[u][i], v[u][i], s1[i]); }
+          for (int i = 0; i < 8; ++i) { const float dlt = v[u][i] - mu[i]; s0[i] += dlt; s1[i] = __builtin_fmaf(dlt, dlt, s1[i]); }
         } else {
 #pragma unroll
           for (int i = 0; i < 8; ++i) { s0[i] += d[u][i]; s1[i] = __builtin_fmaf(d[u][i], (v[u][i] - mu[i]) * is[i], s1[i]); }
@@ -170,6 +173,7 @@ __device__ __forceinline__ bool bn_fold(const float* __restrict__ partial, int n
 
 // forward: fold the partials, statistics, running estimates, (scale, shift) of the apply pass
 __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const float* __restrict__ partial, int nblk, long long M, int C,
+                                                           const void* x_row0, int act_dtype,
                                                            const void* gamma, const void* beta, void* running_mean,
                                                            void* running_var, int pdt, float momentum, float eps,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
@@ -177,8 +181,10 @@ __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const float* __restr
   int c;
   double s, q;
   if (!bn_fold(partial, nblk, C, c, s, q)) return;
-  const double m = s / (double)M;
-  double var = q / (double)M - m * m;
+  const double pivot = (double)param_load(x_row0, act_dtype, c);  // the sums are those of x - pivot (bn_partial_kernel)
+  const double ms = s / (double)M;
+  const double m = pivot + ms;
+  double var = q / (double)M - ms * ms;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   save_mean[c] = (float)m;
@@ -289,7 +295,7 @@ int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, 
     hipLaunchKernelGGL((bn_partial_kernel<float, 0>), dim3(nblk), dim3(256), lds, st, (const float*)x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, M, C, partial);
   }
-  hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, nblk, M, C, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, nblk, M, C, x, act_dtype, gamma, beta, running_mean,
                      running_var, param_dtype, momentum, eps, save_mean, save_invstd, scale, shift);
   if (act_dtype == BTX_ACT_BF16)
     hipLaunchKernelGGL((bn_apply_kernel<__bf16, false>), dim3((unsigned)nap), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)nullptr,
