@@ -450,7 +450,12 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
                                                      "bf16" if act == _lib.ACT_BF16 else "f32", op.kernel[0],
                                                      op.kernel[1], op.kernel[2], op.in_channels, op.out_channels, m_rows)
         _LAUNCH_LOG.append((tag, flops, ev0, ev1))
-    res = restore(out, out_sp)
+    if op.nd == 0 and x_shared:
+        # a Linear layer that reads ONE input for all lanes (the first layer of an MLP): the output stacks the lanes along the
+        # leading axis — [lanes * d0, *d1.., N] — where `restore` would fold it back into the input's own leading shape
+        res = out.reshape((lanes * x.shape[0],) + tuple(x.shape[1:-1]) + (op.out_channels,))
+    else:
+        res = restore(out, out_sp)
     return res.contiguous() if (_OUT_LAYOUT == "contiguous" and op.nd > 0) else res
 
 

@@ -312,3 +312,49 @@ def test_lstm_refuses_device_resident_sample_index():
             lstm(X)
         bt.set_sample_lanes(lstm, None)
         lstm(X)
+
+
+@pytest.mark.parametrize("prec,act", [("bf16", torch.bfloat16), ("f32", torch.float32)])
+def test_mlp_lanes_share_the_input_of_the_first_linear_layer(prec, act):
+    """BASELINE cfg2 as bench.py runs it: the MC samples of a LinearFlipout MLP as lanes of one launch per layer.  The FIRST layer
+    reads one input for all lanes (a Linear layer with a shared input: its output stacks the lanes along the leading axis — this used
+    to fold back into the input's shape and raise); every lane's logits equal a single-sample forward of the throughput plan bit for
+    bit, and the graphed replay's statistics equal the sum over those forwards."""
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import mc
+    from bayesian_torch_amd import functional as BF
+    dev = _dev()
+    bt.manual_seed(2024)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(784, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                              torch.nn.Linear(512, 10))
+    bt.dnn_to_bnn(net, dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Flipout",
+                            moped_enable=False, moped_delta=0.5))
+    net = net.to(dev).eval()
+    bt.assign_layer_ids(net)
+    bt.set_precision(prec)
+    try:
+        x = torch.randn(256, 784, device=dev).to(act)
+        idx = [3, 9, 10, 77]
+        with torch.no_grad():
+            singles = []
+            with BF.concurrent_plan():
+                for s in idx:
+                    bt.set_sample_index(net, s)
+                    singles.append(net(x).float().clone())
+            bt.set_sample_lanes(net, idx, batch=256)
+            y = net(x).float()
+            bt.set_sample_lanes(net, None)
+            assert y.shape == (4 * 256, 10)
+            for l in range(4):
+                assert torch.equal(y[l * 256:(l + 1) * 256], singles[l]), l
+            want = torch.zeros(mc.packed_numel(256, 10), dtype=torch.float32, device=dev)
+            for t in singles:
+                mc.accumulate(want, t.to(act), 0.25)
+            g = mc.GraphedMC(net, x, kl=0.25, lanes=4)
+            g.run_many(idx)
+            torch.cuda.synchronize()
+            assert torch.allclose(g.packed, want, rtol=1e-6, atol=1e-6)
+            g.close()
+    finally:
+        bt.set_precision("f32")
