@@ -1196,7 +1196,7 @@ def main():
                 r = run_resnet_config("resnet50", "Flipout", "bf16", 128, True, 16, 2, 16, dev, parity=True, prewarm=3)
                 extra["cfg5"] = summarise_extra("cfg5 shard: dnn_to_bnn(ResNet50) Flipout + MOPED(0.5) bs128 bf16", r, "bf16",
                                                 table=True)
-                r = run_resnet_config("resnet50", "Flipout", "bf16x3", 128, True, 8, 2, 8, dev, parity=True, prewarm=2,
+                r = run_resnet_config("resnet50", "Flipout", "bf16x3", 128, True, 16, 0, 16, dev, parity=True, prewarm=2,
                                       per_launch=False)
                 extra["cfg5_bf16x3"] = summarise_extra("cfg5 shard in split-bf16 mode (f32 activations)", r, "bf16x3")
                 # the strong-scaling shape of cfg4 (32 samples over 8 GPUs): 4 MC samples on this rank, one replay — the
