@@ -525,3 +525,60 @@ def test_captured_training_step_equals_the_eager_step():
     assert abs(lb - la) > 0 and rel(gb, ga[2]) > 1e-3  # another sample index: other noise
     l7b, _ = eager(7)  # the model is back to host-side sample indices
     assert abs(l7b - l7) < 1e-5 * abs(l7)
+
+
+# gradients at the BASELINE batch against autograd through the reference chain evaluated ON THE CPU (ATen f32 conv backward):
+# no GPU library between the HIP gradients and the reference arithmetic (the forward has the same check in test_gpu_at_size.py)
+CPU_BWD_CASES = [
+    ("taps_56", "Conv2dFlipout", dict(in_channels=64, out_channels=64, kernel_size=3, padding=1, bias=False), (64, 64, 56, 56)),
+    ("taps2_s2", "Conv2dFlipout", dict(in_channels=128, out_channels=256, kernel_size=3, stride=2, padding=1, bias=False), (64, 128, 28, 28)),
+    ("pw_s2", "Conv2dFlipout", dict(in_channels=256, out_channels=512, kernel_size=1, stride=2, bias=False), (64, 256, 14, 14)),
+    ("fc", "LinearFlipout", dict(in_features=512, out_features=1000), (64, 512)),
+    ("reparam_14", "Conv2dReparameterization", dict(in_channels=256, out_channels=256, kernel_size=3, padding=1, bias=False), (64, 256, 14, 14)),
+]
+
+
+@pytest.mark.parametrize("case", CPU_BWD_CASES, ids=[c[0] for c in CPU_BWD_CASES])
+def test_backward_at_baseline_batch_vs_cpu_autograd(case):
+    import os
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd import layers as L
+    from oracle import bt_ref
+    name, cls, kw, xshape = case
+    dev = _dev()
+    bt.manual_seed(2024)
+    bt.set_precision("f32")
+    torch.manual_seed(3)
+    layer = getattr(L, cls)(**kw).to(dev)
+    torch.manual_seed(1234)
+    x = torch.randn(*xshape, device=dev)
+    if len(xshape) == 4:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    bt.set_sample_index(layer, 9)
+    out = layer(x, return_kl=False)
+    torch.manual_seed(5)
+    dy = torch.randn(out.shape, device=dev)
+    out.backward(dy)
+    mu, rho = layer._w()
+    got = [x.grad, mu.grad, rho.grad] + ([layer.mu_bias.grad, layer.rho_bias.grad] if layer.mu_bias is not None else [])
+    # the same function on the CPU: reference op chain + torch autograd, fed with the noise BTX-RNG defines for (layer, sample 9)
+    nz = layer.materialize_noise(9, tuple(x.shape), tuple(out.shape), x.dtype)
+    c = lambda t: None if t is None else t.detach().float().cpu().contiguous()  # noqa: E731
+    xc = c(x).requires_grad_(True)
+    muc, rhoc = c(mu).requires_grad_(True), c(rho).requires_grad_(True)
+    mbc = c(layer.mu_bias).requires_grad_(True) if layer.mu_bias is not None else None
+    rbc = c(layer.rho_bias).requires_grad_(True) if layer.rho_bias is not None else None
+    op = dict(kind="linear") if layer._op.nd == 0 else dict(kind="conv", nd=2, stride=layer._op.stride[1:], padding=layer._op.padding[1:],
+                                                           dilation=layer._op.dilation[1:], groups=layer._op.groups)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    if "Flipout" in cls:
+        ref = bt_ref.flipout_forward(xc, muc, rhoc, mbc, rbc, c(nz["eps_w"]), c(nz.get("eps_b")), c(nz["sign_in"]), c(nz["sign_out"]), op)
+    else:
+        ref = bt_ref.reparam_forward(xc, muc, rhoc, mbc, rbc, c(nz["eps_w"]), c(nz.get("eps_b")), op)
+    ref.backward(c(dy))
+    want = [xc.grad, muc.grad, rhoc.grad] + ([mbc.grad, rbc.grad] if mbc is not None else [])
+    errs = [float((g.detach().float().cpu() - w).norm() / w.norm()) for g, w in zip(got, want)]
+    print("%s batch %d: dx, dmu, drho%s vs CPU autograd through the reference chain: %s" % (
+        name, xshape[0], ", dmu_b, drho_b" if mbc is not None else "", ", ".join("%.2e" % e for e in errs)))
+    assert max(errs) < 1e-4, (name, errs)
