@@ -14,7 +14,7 @@ FLAG_TRANSPOSED, FLAG_KL_ACCUM, FLAG_ROWFUSE, FLAG_OUT_F32, FLAG_OUT_BF16, FLAG_
 FLAG_REVERSE = 256
 E_UNSUPPORTED = -3
 STREAM_EPS_W, STREAM_EPS_B, STREAM_SIGN_IN, STREAM_SIGN_OUT = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 FLAG_LANES_SHIFT = 16
 SAMPLE_SKIP_MU = 1
 
@@ -65,7 +65,8 @@ EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_
            "btx_kl_gauss_model", "btx_kl_gauss_model_bwd", "btx_contract_wgrad",
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_fwd_lanes", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign", "btx_rho_grad",
            "btx_mc_packed_floats", "btx_mc_accumulate", "btx_mc_accumulate_lanes", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl",
-           "btx_bn_workspace_bytes", "btx_bn_train_fwd", "btx_bn_train_bwd", "btx_dgrad_weights")
+           "btx_bn_workspace_bytes", "btx_bn_train_fwd", "btx_bn_train_bwd", "btx_dgrad_weights",
+           "btx_wgrad_workspace_bytes", "btx_contract_wgrad_ws")
 
 
 def lib_path():
@@ -101,6 +102,11 @@ def lib():
     L.btx_contract_wgrad.restype = i32
     L.btx_contract_wgrad.argtypes = [i32, ctypes.POINTER(Geom), vp, vp, vp, vp, vp, vp, ctypes.POINTER(Rng),
                                      ctypes.POINTER(Noise), i32, u32, vp]
+    L.btx_contract_wgrad_ws.restype = i32
+    L.btx_contract_wgrad_ws.argtypes = [i32, ctypes.POINTER(Geom), vp, vp, vp, vp, vp, vp, ctypes.POINTER(Rng),
+                                        ctypes.POINTER(Noise), i32, u32, vp, sz, vp, vp, vp]
+    L.btx_wgrad_workspace_bytes.restype = sz
+    L.btx_wgrad_workspace_bytes.argtypes = [i32, ctypes.POINTER(Geom), i32, u32]
     L.btx_contract_workspace_bytes.restype = sz
     L.btx_contract_workspace_bytes.argtypes = [ctypes.POINTER(Geom), i32, i32, i32, u32]
     L.btx_contract_fwd.restype = i32

@@ -143,13 +143,14 @@ class ContractFn(torch.autograd.Function):
                     # plain layouts: the kernel's GEMM-major buffers ARE the gradients (strided logical views, as the
                     # parameters themselves are stored), and drho = dW_delta * eps * sigmoid(rho) is one launch with eps
                     # regenerated in the kernel (btx_rho_grad) instead of fill_eps + unpack + sigmoid + two products
-                    dWf, dWdf, db, dbd = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape,
-                                                      bias=want_b, raw=True, sample_dev=sdev)
+                    rho_f = BF.gemm_major_view(rho, op).reshape(-1) if want_w else None
+                    if rho_f is not None and not rho_f.is_contiguous():
+                        rho_f = rho_f.contiguous()
+                    res = BF.wgrad_hip(kind, x, dy, op, _rng.seed(), s, layer._btx_layer_id, w_shape, bias=want_b, raw=True,
+                                       sample_dev=sdev, rho_flat=rho_f)
+                    dWf, dWdf, db, dbd = res[:4]
                     if want_w:
-                        rho_f = BF.gemm_major_view(rho, op).reshape(-1)
-                        src = dWdf if flip else dWf
-                        drho_f = BF.rho_grad_hip(src, rho_f, _rng.seed(), s, layer._btx_layer_id, _lib.STREAM_EPS_W,
-                                                 out=src if flip else None, sample_dev=sdev)
+                        drho_f = res[4]  # formed by the weight gradient's own reduction launch (btx_contract_wgrad_ws)
                         dmu = BF.gemm_major_logical_view(dWf, w_shape, op)
                         drho = BF.gemm_major_logical_view(drho_f, w_shape, op)
                     fused_w = True
@@ -336,16 +337,17 @@ class BatchNormTrainFn(torch.autograd.Function):
         else:
             dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        pd = w.dtype if w is not None else torch.float32  # the kernel writes the two [C] gradients in the parameters' dtype
+        dgamma = torch.empty(C, dtype=pd, device=dev)
+        dbeta = torch.empty(C, dtype=pd, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         ws = BF._workspace(dev, L.btx_bn_workspace_bytes(M, C), stream)
         _lib.check(L.btx_bn_train_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_code(x.dtype), M, C,
                                       w.data_ptr() if w is not None else None, ctx.pdt, save_mean.data_ptr(),
                                       save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
                                       stream))
-        gw = dgamma.to(w.dtype) if (w is not None and ctx.needs_input_grad[1]) else None
-        gb = dbeta.to(w.dtype if w is not None else torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gw = dgamma if (w is not None and ctx.needs_input_grad[1]) else None
+        gb = dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return (dx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None
 
 

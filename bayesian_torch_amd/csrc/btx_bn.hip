@@ -207,14 +207,14 @@ __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const float* __restr
 // backward: dgamma, dbeta and the coefficients of dx = A*dy + B*x + D
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, long long M, int C,
                                                            const void* gamma, int pdt, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, float* __restrict__ cA,
+                                                           const float* __restrict__ invstd, void* __restrict__ dgamma,
+                                                           void* __restrict__ dbeta, float* __restrict__ cA,
                                                            float* __restrict__ cB, float* __restrict__ cD) {
   int c;
   double s, q;
   if (!bn_fold(partial, nblk, C, c, s, q)) return;
-  if (dbeta) dbeta[c] = (float)s;
-  if (dgamma) dgamma[c] = (float)q;
+  if (dbeta) param_store(dbeta, pdt, c, (float)s);   // in the parameters' dtype: what autograd hands the optimizer
+  if (dgamma) param_store(dgamma, pdt, c, (float)q);
   const float g = gamma ? param_load(gamma, pdt, c) : 1.f;
   const double is = (double)invstd[c], mu = (double)mean[c], invM = 1.0 / (double)M;
   const double A = (double)g * is;
@@ -307,7 +307,7 @@ int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, 
 }
 
 int btx_bn_train_bwd(const void* x, const void* dy, void* dx, int act_dtype, long long M, int C, const void* gamma,
-                     int param_dtype, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* ws,
+                     int param_dtype, const float* save_mean, const float* save_invstd, void* dgamma, void* dbeta, void* ws,
                      size_t ws_bytes, void* stream) {
   if (!x || !dy || !dx || !save_mean || !save_invstd || !ws) return BTX_E_NULL;
   if (!bn_ok(M, C)) return (M > 0 && C > 0) ? BTX_E_UNSUPPORTED : BTX_E_SHAPE;

@@ -24,6 +24,7 @@
 // block 0.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/btx.h"
 #include "btx_contract.h"
@@ -49,8 +50,13 @@ struct WgradParams {
   const uint32_t* sample_ptr;  // BtxRng.sample_idx_dev: the sign keys are then derived on the device (captured training steps)
   uint32_t seed_lo, seed_hi, layer;
   int swap;
+  int tune;     // measurement builds (BTX_WGRAD_T3_ABL): 1 = no slab stores, 2 = no MFMA section (results wrong: time only)
+  int direct;   // slab mode with ONE chunk: its sums are the result — plain stores straight into dW, no reduction launch
+  float* slab;  // btx_contract_wgrad_ws: [chunk][mean | delta][N*K] partial sums, plain stores (nullptr: f32 atomics into dW)
   FastDiv fd_Wo, fd_Ho, fd_Do, fd_T, fd_ctiles, fd_ntiles, fd_groups;
 };
+
+#include "btx_wgrad_taps.h"
 
 constexpr int WG_PX = 64;          // pixels per step
 constexpr int WG_ROW = 64 * 4 + 16;  // bytes per pixel row of a staged tile: 64 f32 + pad (conflict-free 16-B writes)
@@ -368,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   // ---- reduce the four waves' partial tiles through LDS and add them to dW.
   // C/D layout of 32x32 MFMAs: reg r of lane (l31, hk) = D[row = (r&3) + 8*(r>>2) + 4*hk][col = l31]; row = n, col = c.
   float* red = (float*)smem;  // [wave][64 n][64 c]
-  auto reduce_store = [&](const f32x16 (&acc)[2][2], float* dst) {
+  const size_t slab_e = (size_t)p.N * p.T * p.Cg;  // elements of one dW tensor (N = groups * Ng)
+  auto reduce_store = [&](const f32x16 (&acc)[2][2], float* dst, int which) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -384,12 +391,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       const int n = e >> 6, c = e & 63;
       const float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
       const int ng = nt * 64 + n, cg = ct * 64 + c;
-      if (ng < p.Ng && cg < p.Cg)
-        atomicAdd(dst + ((size_t)(grp * p.Ng + ng) * p.T + tap) * p.Cg + cg, v);
+      if (ng < p.Ng && cg < p.Cg) {
+        const size_t e = ((size_t)(grp * p.Ng + ng) * p.T + tap) * p.Cg + cg;
+        if (p.direct) dst[e] = v;
+        else if (p.slab) p.slab[((size_t)chunk * (KIND == 1 ? 2 : 1) + which) * slab_e + e] = v;  // this chunk's slab: a plain store
+        else atomicAdd(dst + e, v);
+      }
     }
   };
-  reduce_store(acc_m, p.dwm);
-  if constexpr (KIND == 1) reduce_store(acc_d, p.dwd);
+  reduce_store(acc_m, p.dwm, 0);
+  if constexpr (KIND == 1) reduce_store(acc_d, p.dwd, 1);
   if (do_bias && tid < 64 && nt * 64 + tid < p.Ng) {
     atomicAdd(p.dbm + grp * p.Ng + nt * 64 + tid, bsum_m);
     if constexpr (KIND == 1) atomicAdd(p.dbd + grp * p.Ng + nt * 64 + tid, bsum_d);
@@ -476,14 +487,127 @@ extern "C" int btx_dgrad_weights(const float* mu_w, const float* rho_w, float* o
   return (int)hipGetLastError();
 }
 
-extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta,
-                                  float* db_mu, float* db_delta, const BtxRng* rng, const BtxNoise* noise, int act_dtype,
-                                  uint32_t flags, void* stream) {
-  if (!g || !x || !dy || !dw_mu || !rng) return BTX_E_NULL;
-  if (kind != BTX_KIND_REPARAM && kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
-  if (kind == BTX_KIND_FLIPOUT && !dw_delta) return BTX_E_NULL;
-  if ((db_mu != nullptr) && kind == BTX_KIND_FLIPOUT && !db_delta) return BTX_E_NULL;
-  if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
+namespace {
+
+// out[e] = the chunks' partial sums added in chunk order (fixed: the result does not depend on the launch's timing).  256 threads =
+// QL element groups x CL chunk lanes; lane cl adds chunks cl, cl + CL, ..., the CL sums are added in order through LDS.
+// With `rho`: the tensor that feeds the rho gradient (dW_delta of a Flipout layer, dW_mu of a Reparameterization layer) also leaves
+// as drho = dW * eps * sigmoid(rho), eps regenerated (what btx_rho_grad computes from the finished dW; drho may alias that dW).
+struct RhoFuse {
+  const float* rho;
+  float* drho;
+  const uint32_t* sample_ptr;
+  uint32_t k0, k1, sample, layer;
+  int which;  // the slab half drho is formed from
+};
+
+__device__ __forceinline__ float rho_factor(float z, float rho) { return z * (1.0f / (1.0f + expf(-rho))); }
+
+template <int VEC>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ out_m,
+                                                           float* __restrict__ out_d, size_t E, int chunks, int nk, int cl_log2,
+                                                           const RhoFuse rf) {
+  __shared__ float red[256 * VEC];
+  const int CL = 1 << cl_log2, QL = 256 >> cl_log2;
+  const int tid = threadIdx.x, ql = tid & (QL - 1), cl = tid >> (8 - cl_log2);
+  const int which = blockIdx.y;
+  const size_t e0 = ((size_t)blockIdx.x * QL + ql) * VEC;
+  const size_t cstride = (size_t)nk * E;
+  float s[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s[v] = 0.f;
+  if (e0 < E) {
+    const float* src = slab + (size_t)which * E + e0;
+#pragma unroll 8
+    for (int c = cl; c < chunks; c += CL) {
+      if constexpr (VEC == 4) {
+        const f32x4 t = *(const f32x4*)(src + (size_t)c * cstride);
+        s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+      } else {
+        s[0] += src[(size_t)c * cstride];
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) red[tid * VEC + v] = s[v];
+  __syncthreads();
+  if (cl == 0 && e0 < E) {
+    float* out = which ? out_d : out_m;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float t = red[ql * VEC + v];
+      for (int k = 1; k < CL; ++k) t += red[(k * QL + ql) * VEC + v];
+      s[v] = t;
+    }
+    const bool fuse = rf.rho != nullptr && which == rf.which;
+    if (!fuse || rf.drho != out) {
+      if constexpr (VEC == 4) *(f32x4*)(out + e0) = (f32x4){s[0], s[1], s[2], s[3]};
+      else out[e0] = s[0];
+    }
+    if (fuse) {
+      const uint32_t smp = rf.sample_ptr ? *rf.sample_ptr : rf.sample;
+      float z[4];
+      btx_normal4((uint32_t)(e0 >> 2), smp, rf.layer, BTX_STREAM_EPS_W, rf.k0, rf.k1, z);
+      if constexpr (VEC == 4) {
+        const f32x4 r = *(const f32x4*)(rf.rho + e0);
+        *(f32x4*)(rf.drho + e0) = (f32x4){s[0] * rho_factor(z[0], r[0]), s[1] * rho_factor(z[1], r[1]), s[2] * rho_factor(z[2], r[2]),
+                                          s[3] * rho_factor(z[3], r[3])};
+      } else {
+        const uint32_t l = (uint32_t)e0 & 3u;
+        const float zz = l == 0 ? z[0] : (l == 1 ? z[1] : (l == 2 ? z[2] : z[3]));
+        rf.drho[e0] = s[0] * rho_factor(zz, rf.rho[e0]);
+      }
+    }
+  }
+}
+
+// drho = dW * eps * sigmoid(rho) on a finished dW (one-chunk launches store straight into dW: no reduction launch to fuse into)
+__global__ __launch_bounds__(256) void wgrad_rho_kernel(const float* dw, size_t n, const RhoFuse rf) {
+  const uint32_t smp = rf.sample_ptr ? __builtin_amdgcn_readfirstlane(*rf.sample_ptr) : rf.sample;
+  const size_t nblk = (n + 3) >> 2;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nblk; b += (size_t)gridDim.x * 256) {
+    float z[4];
+    btx_normal4((uint32_t)b, smp, rf.layer, BTX_STREAM_EPS_W, rf.k0, rf.k1, z);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const size_t i = (b << 2) + e;
+      if (i < n) rf.drho[i] = dw[i] * rho_factor(z[e], rf.rho[i]);
+    }
+  }
+}
+
+static inline const char* wg_tune_env(const char* name) {
+#if defined(BTX_TUNING) || defined(BTX_PT_TRACE)
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
+// the pixel chunking of the two kernels (shared by btx_wgrad_workspace_bytes and the launch).  Atomics path (rounds 2-5): about
+// `target_wgs` workgroups.  Slab paths: at most `target_wgs` = the workgroups the chip holds at once (one round: a second, partly
+// filled round costs a whole round's prologue, epilogue and slab; profiles/r05_experiments.txt E13), a single chunk when one
+// chunk's tiles already exceed that.
+void wgrad_chunks(long long base, long long M, long long target_wgs, bool round_down, long long* chunks_out, long long* cpx_out) {
+  long long chunks = round_down ? target_wgs / base : (target_wgs + base - 1) / base;
+  const long long max_chunks = (M + WG_PX - 1) / WG_PX;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  const long long cpx = ((M + chunks - 1) / chunks + WG_PX - 1) / WG_PX * WG_PX;
+  *chunks_out = (M + cpx - 1) / cpx;
+  *cpx_out = cpx;
+}
+long long wgrad_target_wgs(bool slab) {
+  const char* e = wg_tune_env(slab ? "BTX_WGRAD_SLAB_WGS" : "BTX_WGRAD_WGS");
+  return e ? atoll(e) : (slab ? 512 : 2048);  // slabs: two 4-wave workgroups per CU
+}
+long long wgrad_taps3_target_wgs() {
+  const char* e = wg_tune_env("BTX_WGRAD_T3_WGS");
+  return e ? atoll(e) : 256;  // one 12-wave workgroup per CU
+}
+
+int wgrad_fill_params(int kind, const BtxGeom* g, const void* x, const void* dy, const BtxNoise* noise, uint32_t flags, WgradParams& p) {
   if (flags & BTX_FLAG_TRANSPOSED) return BTX_E_UNSUPPORTED;  // transposed layers: swap x and dy (host)
   // BTX_FLAG_ROWFUSE (small-C stems on the row-fused geometry of the forward, include/btx.h): a kernel row = KW*C contiguous
   // elements of x plays the part of the channel axis — KH "taps" of KW*C "channels" instead of KH*KW taps of C channels (a
@@ -493,9 +617,8 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
   int32_t Do, Ho, Wo;
   int rc = btx_out_shape(g, 0, &Do, &Ho, &Wo);
   if (rc) return rc;
-  WgradParams p;
   memset(&p, 0, sizeof(p));
-  p.x = x; p.dy = dy; p.dwm = dw_mu; p.dwd = dw_delta; p.dbm = db_mu; p.dbd = db_delta;
+  p.x = x; p.dy = dy;
   p.sign_in = noise ? noise->sign_in : nullptr;
   p.sign_out = noise ? noise->sign_out : nullptr;
   p.NB = g->NB; p.D = g->D; p.H = g->H; p.W = g->W; p.C = g->C; p.Cg = g->C / g->groups;
@@ -507,34 +630,82 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
   p.M = (int)M; p.T = g->KD * g->KH * g->KW; p.K = p.T * p.Cg; p.groups = g->groups;
   if (rowfuse) { p.Cg = g->KW * g->C; p.KW = 1; p.T = g->KD * g->KH; }  // K = T * Cg unchanged; the pixel stride p.C stays C
   p.ntiles = (p.Ng + 63) / 64; p.ctiles = (p.Cg + 63) / 64;
-  const long long base = (long long)p.groups * p.ntiles * p.ctiles * p.T;
-  long long chunks = (2048 + base - 1) / base;  // ~2048 workgroups in flight
-  const long long max_chunks = (M + WG_PX - 1) / WG_PX;
-  if (chunks > max_chunks) chunks = max_chunks;
-  if (chunks < 1) chunks = 1;
-  long long cpx = ((M + chunks - 1) / chunks + WG_PX - 1) / WG_PX * WG_PX;
-  chunks = (M + cpx - 1) / cpx;
+  return 0;
+}
+
+// geometry test of the all-taps kernel that needs no pointers (workspace sizing)
+bool wgrad_taps3_geom(const WgradParams& p, int act_dtype) {
+  return act_dtype == BTX_ACT_BF16 && p.groups == 1 && p.D == 1 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.sh == 1 && p.sw == 1 &&
+         p.ph == 1 && p.pw == 1 && p.dh == 1 && p.dw == 1 && p.Ho == p.H && p.Wo == p.W && p.W >= 2 && p.W <= 63 && p.H >= 2 &&
+         (p.C % 64) == 0 && (p.N % 64) == 0 && !wg_tune_env("BTX_WGRAD_NO_TAPS3");
+}
+
+int wgrad_impl(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta, float* db_mu, float* db_delta,
+               const BtxRng* rng, const BtxNoise* noise, int act_dtype, uint32_t flags, void* ws, size_t ws_bytes, const float* rho_w,
+               float* drho, void* stream) {
+  if (!g || !x || !dy || !dw_mu || !rng) return BTX_E_NULL;
+  if ((rho_w != nullptr) != (drho != nullptr)) return BTX_E_NULL;
+  if (rho_w && kind == BTX_KIND_REPARAM && drho == dw_mu) return BTX_E_UNSUPPORTED;  // dmu IS dw_mu: drho needs its own buffer
+  if (kind != BTX_KIND_REPARAM && kind != BTX_KIND_FLIPOUT) return BTX_E_UNSUPPORTED;
+  if (kind == BTX_KIND_FLIPOUT && !dw_delta) return BTX_E_NULL;
+  if ((db_mu != nullptr) && kind == BTX_KIND_FLIPOUT && !db_delta) return BTX_E_NULL;
+  if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
+  WgradParams p;
+  int rc = wgrad_fill_params(kind, g, x, dy, noise, flags, p);
+  if (rc) return rc;
+  p.dwm = dw_mu; p.dwd = dw_delta; p.dbm = db_mu; p.dbd = db_delta;
+  const long long M = p.M;
+  const int nk = kind == BTX_KIND_FLIPOUT ? 2 : 1;
+  const size_t E = (size_t)g->N * p.K;
+  const bool slab = ws != nullptr && ws_bytes > 0;
+  if (slab && (((uintptr_t)ws) & 15)) return BTX_E_ALIGN;
+  p.slab = slab ? (float*)ws : nullptr;
+  const bool taps3 = slab && wgrad_taps3_geom(p, act_dtype) && wgrad_taps3_ok(p, act_dtype, db_mu != nullptr);
+  const long long base = taps3 ? (long long)p.ntiles * p.ctiles : (long long)p.groups * p.ntiles * p.ctiles * p.T;
+  long long chunks, cpx;
+  wgrad_chunks(base, M, taps3 ? wgrad_taps3_target_wgs() : wgrad_target_wgs(slab), slab, &chunks, &cpx);
   p.chunks = (int)chunks; p.chunk_px = (int)cpx;
   if (base * chunks > 0x7fffffffLL) return BTX_E_UNSUPPORTED;
+  if (slab && (size_t)chunks * nk * E * sizeof(float) > ws_bytes) return BTX_E_WORKSPACE;
+  p.direct = (slab && chunks == 1) ? 1 : 0;
   const bool swap = (flags & BTX_FLAG_SWAP_SIGNS) != 0;  // transposed layers: the roles of x and dy are exchanged
   sign_keys_host(rng, swap ? BTX_STREAM_SIGN_OUT : BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);
   sign_keys_host(rng, swap ? BTX_STREAM_SIGN_IN : BTX_STREAM_SIGN_OUT, &p.kout_a, &p.kout_b);
   p.sample_ptr = rng->sample_idx_dev; p.seed_lo = (uint32_t)rng->seed; p.seed_hi = (uint32_t)(rng->seed >> 32); p.layer = rng->layer_id;
   p.swap = swap ? 1 : 0;
-  p.fd_Wo = make_fastdiv((uint32_t)Wo); p.fd_Ho = make_fastdiv((uint32_t)Ho); p.fd_Do = make_fastdiv((uint32_t)Do);
+  { const char* tn = wg_tune_env("BTX_WGRAD_T3_ABL"); p.tune = tn ? atoi(tn) : 0; }
+  p.fd_Wo = make_fastdiv((uint32_t)p.Wo); p.fd_Ho = make_fastdiv((uint32_t)p.Ho); p.fd_Do = make_fastdiv((uint32_t)p.Do);
   p.fd_T = make_fastdiv((uint32_t)p.T); p.fd_ctiles = make_fastdiv((uint32_t)p.ctiles);
   p.fd_ntiles = make_fastdiv((uint32_t)p.ntiles); p.fd_groups = make_fastdiv((uint32_t)p.groups);
   hipStream_t st = (hipStream_t)stream;
-  const size_t wbytes = (size_t)g->N * p.K * sizeof(float);
-  hipError_t e = hipMemsetAsync(dw_mu, 0, wbytes, st);
-  if (e != hipSuccess) return (int)e;
-  if (kind == BTX_KIND_FLIPOUT) { e = hipMemsetAsync(dw_delta, 0, wbytes, st); if (e != hipSuccess) return (int)e; }
+  const size_t wbytes = E * sizeof(float);
+  hipError_t e;
+  if (!slab) {  // the atomics accumulate into dW: it must be zero on entry
+    e = hipMemsetAsync(dw_mu, 0, wbytes, st);
+    if (e != hipSuccess) return (int)e;
+    if (kind == BTX_KIND_FLIPOUT) { e = hipMemsetAsync(dw_delta, 0, wbytes, st); if (e != hipSuccess) return (int)e; }
+  }
   if (db_mu) {
     e = hipMemsetAsync(db_mu, 0, (size_t)g->N * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     if (kind == BTX_KIND_FLIPOUT) { e = hipMemsetAsync(db_delta, 0, (size_t)g->N * sizeof(float), st); if (e != hipSuccess) return (int)e; }
   }
   const int nwg = (int)(base * chunks);
+  if (taps3) {
+#define BTX_LAUNCH_T3(KIND)                                                                                       \
+  do {                                                                                                            \
+    auto kfn = wgrad_taps3_kernel<KIND>;                                                                           \
+    static bool attr_done = false;                                                                                \
+    if (!attr_done) {                                                                                             \
+      hipError_t e2 = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);  \
+      if (e2 != hipSuccess) return (int)e2;                                                                       \
+      attr_done = true;                                                                                           \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kfn, dim3(nwg), dim3(KIND == 1 ? 768 : 384), T3Lds<KIND>::total, st, p);                    \
+  } while (0)
+    if (kind == 0) BTX_LAUNCH_T3(0); else BTX_LAUNCH_T3(1);
+#undef BTX_LAUNCH_T3
+  } else {
   const int lds = (kind == BTX_KIND_FLIPOUT ? 4 : 2) * WG_TILE;
   const int lds_need = lds > 65536 ? lds : 65536;  // the cross-wave reduction uses 64 KiB
   // bf16 fast path (the shapes of a ResNet body and its row-fused stem): whole 16-channel runs, x runs at multiples of 4
@@ -556,5 +727,63 @@ extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, con
   else if (fast_ok) { if (kind == 0) BTX_LAUNCH_WG(__bf16, 0, true); else BTX_LAUNCH_WG(__bf16, 1, true); }
   else { if (kind == 0) BTX_LAUNCH_WG(__bf16, 0, false); else BTX_LAUNCH_WG(__bf16, 1, false); }
 #undef BTX_LAUNCH_WG
-  return (int)hipGetLastError();
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  RhoFuse rf;
+  memset(&rf, 0, sizeof(rf));
+  if (rho_w) {
+    if (E > 0xfffffffcULL) return BTX_E_UNSUPPORTED;  // BTX-RNG v1 block index is 32 bits
+    rf.rho = rho_w; rf.drho = drho; rf.sample_ptr = rng->sample_idx_dev; rf.k0 = (uint32_t)rng->seed; rf.k1 = (uint32_t)(rng->seed >> 32);
+    rf.sample = rng->sample_idx; rf.layer = rng->layer_id; rf.which = nk - 1;
+  }
+  if (slab && !p.direct) {
+    const bool vec = (E % 4 == 0) && ((((uintptr_t)dw_mu) | ((uintptr_t)dw_delta) | ((uintptr_t)rho_w) | ((uintptr_t)drho)) % 16 == 0);
+    int cl_log2 = 0;
+    while (cl_log2 < 4 && (2 << cl_log2) <= chunks) ++cl_log2;  // up to 16 chunk lanes
+    const int QL = 256 >> cl_log2;
+    const size_t groups_e = vec ? (E + 3) / 4 : E;
+    const size_t gx = (groups_e + QL - 1) / QL;
+    if (gx > 0x7fffffffULL) return BTX_E_UNSUPPORTED;
+    if (vec) hipLaunchKernelGGL(wgrad_finish_kernel<4>, dim3((unsigned)gx, nk), dim3(256), 0, st, (const float*)ws, dw_mu, dw_delta, E, (int)chunks, nk, cl_log2, rf);
+    else hipLaunchKernelGGL(wgrad_finish_kernel<1>, dim3((unsigned)gx, nk), dim3(256), 0, st, (const float*)ws, dw_mu, dw_delta, E, (int)chunks, nk, cl_log2, rf);
+    e = hipGetLastError();
+  } else if (rho_w) {
+    size_t blocks = ((E + 3) / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_rho_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)(nk == 2 ? dw_delta : dw_mu), E, rf);
+    e = hipGetLastError();
+  }
+  return (int)e;
+}
+
+}  // namespace
+
+extern "C" int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta,
+                                  float* db_mu, float* db_delta, const BtxRng* rng, const BtxNoise* noise, int act_dtype,
+                                  uint32_t flags, void* stream) {
+  return wgrad_impl(kind, g, x, dy, dw_mu, dw_delta, db_mu, db_delta, rng, noise, act_dtype, flags, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int btx_contract_wgrad_ws(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta,
+                                     float* db_mu, float* db_delta, const BtxRng* rng, const BtxNoise* noise, int act_dtype,
+                                     uint32_t flags, void* ws, size_t ws_bytes, const float* rho_w, float* drho, void* stream) {
+  if (!ws || ws_bytes == 0) return BTX_E_WORKSPACE;
+  return wgrad_impl(kind, g, x, dy, dw_mu, dw_delta, db_mu, db_delta, rng, noise, act_dtype, flags, ws, ws_bytes, rho_w, drho, stream);
+}
+
+// the slabs of either kernel (the choice between them also depends on pointers and on the bias: the size covers both)
+extern "C" size_t btx_wgrad_workspace_bytes(int kind, const BtxGeom* g, int act_dtype, uint32_t flags) {
+  if (!g || (kind != BTX_KIND_REPARAM && kind != BTX_KIND_FLIPOUT)) return 0;
+  WgradParams p;
+  if (wgrad_fill_params(kind, g, nullptr, nullptr, nullptr, flags, p)) return 0;
+  const size_t nk = kind == BTX_KIND_FLIPOUT ? 2 : 1, E = (size_t)g->N * p.K;
+  long long chunks, cpx;
+  wgrad_chunks((long long)p.groups * p.ntiles * p.ctiles * p.T, p.M, wgrad_target_wgs(true), true, &chunks, &cpx);
+  long long most = chunks;
+  if (wgrad_taps3_geom(p, act_dtype)) {
+    wgrad_chunks((long long)p.ntiles * p.ctiles, p.M, wgrad_taps3_target_wgs(), true, &chunks, &cpx);
+    if (chunks > most) most = chunks;
+  }
+  return (size_t)most * nk * E * sizeof(float);
 }

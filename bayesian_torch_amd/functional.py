@@ -459,13 +459,18 @@ def contract_hip(kind, x, mu_p, rho_p, mu_b, rho_b, op, seed, sample_idx, layer_
     return res.contiguous() if (_OUT_LAYOUT == "contiguous" and op.nd > 0) else res
 
 
+WGRAD_ATOMICS = False  # A/B and tests: accumulate the weight gradient with f32 atomics instead of chunk slabs
+
+
 def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, swap=False, bias=False, rowfuse=None,
-              _flags=0, raw=False, sample_dev=None):
+              _flags=0, raw=False, sample_dev=None, rho_flat=None):
     """btx_contract_wgrad: (dW_mu, dW_delta | None, db_mu | None, db_delta | None) in the layer's LOGICAL weight layout
     (f32).  `op` is a plain (non-transposed) contraction; `signs` = (sign_in, sign_out) logical +/-1 tensors for layers
     whose forward ran on padded layouts, else the forward's hashed signs are regenerated.  `rowfuse` = the layer's
     rowfuse_plan(): the gradient is taken on the row-fused geometry the forward ran on (hashed signs, a kernel row as the
-    channel axis) and un-padded here."""
+    channel axis) and un-padded here.  `rho_flat` (with raw=True): the layer's rho in GEMM-major order — a fifth result, drho =
+    dW * eps * sigmoid(rho) (dW = dW_delta, whose buffer then HOLDS drho, for Flipout; dW_mu for Reparameterization), formed by the
+    slab reduction launch itself (btx_contract_wgrad_ws) or, on the atomics path, by btx_rho_grad."""
     L = _lib.lib()
     if op.transposed:
         raise _lib.BtxError("wgrad_hip wants the plain-convolution geometry (exchange x and dy for transposed layers)")
@@ -513,11 +518,31 @@ def wgrad_hip(kind, x, dy, op, seed, sample_idx, layer_id, w_shape, signs=None, 
     r = _lib.Rng(int(seed), int(sample_idx) & 0xFFFFFFFF, int(layer_id) & 0xFFFFFFFF,
                  sample_dev.data_ptr() if sample_dev is not None else None)
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    _lib.check(L.btx_contract_wgrad(kind, ctypes.byref(g), xp.data_ptr(), dyp.data_ptr(), dwm.data_ptr(), ptr(dwd), ptr(dbm),
-                                    ptr(dbd), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None, act,
-                                    (_lib.FLAG_SWAP_SIGNS if swap else 0) | _flags, torch.cuda.current_stream(dev).cuda_stream))
+    flags = (_lib.FLAG_SWAP_SIGNS if swap else 0) | _flags
+    # the pixel chunks' partial sums go to slabs that a second launch adds in chunk order (deterministic; f32 atomics from 2048
+    # workgroups cost more than the slab round trip — profiles/r05_experiments.txt E13).  WGRAD_ATOMICS: the round 2-5 path.
+    wsb = 0 if WGRAD_ATOMICS else int(L.btx_wgrad_workspace_bytes(kind, ctypes.byref(g), act, flags))
+    drho = None
+    if rho_flat is not None:
+        if not raw:
+            raise _lib.BtxError("wgrad_hip: rho_flat goes with raw=True (GEMM-major buffers)")
+        if rho_flat.dtype != torch.float32 or not rho_flat.is_contiguous() or rho_flat.numel() != n * kred:
+            raise _lib.BtxError("wgrad_hip: rho_flat must be the contiguous f32 GEMM-major rho of the layer")
+        drho = dwd if flip else torch.empty_like(dwm)
+    if wsb > 0:
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.check(L.btx_contract_wgrad_ws(kind, ctypes.byref(g), xp.data_ptr(), dyp.data_ptr(), dwm.data_ptr(), ptr(dwd),
+                                           ptr(dbm), ptr(dbd), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None,
+                                           act, flags, ws.data_ptr(), wsb, ptr(rho_flat), ptr(drho),
+                                           torch.cuda.current_stream(dev).cuda_stream))
+    else:
+        _lib.check(L.btx_contract_wgrad(kind, ctypes.byref(g), xp.data_ptr(), dyp.data_ptr(), dwm.data_ptr(), ptr(dwd),
+                                        ptr(dbm), ptr(dbd), ctypes.byref(r), ctypes.byref(nz) if nz is not None else None,
+                                        act, flags, torch.cuda.current_stream(dev).cuda_stream))
+        if rho_flat is not None:
+            rho_grad_hip(dwd if flip else dwm, rho_flat, seed, sample_idx, layer_id, _lib.STREAM_EPS_W, out=drho, sample_dev=sample_dev)
     if raw:  # the flat GEMM-major buffers as the kernel wrote them (autograd: strided logical views, no unpack copies)
-        return dwm, dwd, dbm, dbd
+        return (dwm, dwd, dbm, dbd) if rho_flat is None else (dwm, dwd, dbm, dbd, drho)
     un = lambda t: unpack_gemm_major(t, w_shape, op) if t is not None else None  # noqa: E731
     return un(dwm), un(dwd), dbm, dbd
 

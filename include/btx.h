@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BTX_ABI_VERSION 7
+#define BTX_ABI_VERSION 8
 
 /* argument-error codes (negative) */
 #define BTX_E_NULL        (-1)   /* required pointer is NULL */
@@ -266,6 +266,23 @@ int btx_contract_fwd_lanes(int kind, const BtxGeom* g,
 int btx_contract_wgrad(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta,
                        float* db_mu, float* db_delta, const BtxRng* rng, const BtxNoise* noise /* nullable */,
                        int act_dtype, uint32_t flags, void* stream);
+/* The same with a workspace (ABI 8): the partial sums of the pixel chunks leave as plain stores into per-chunk slabs in `ws`
+ * and a second launch adds them in chunk order — the result no longer depends on the order in which workgroups retire, and
+ * no f32 atomic crosses the fabric (db_* still uses them: N values).  With a workspace the weight gradient of a stride-1
+ * 3x3 "same" convolution on bf16 activations (C % 64 == 0, N % 64 == 0, W <= 63, hashed signs, no bias: the body of a
+ * ResNet) takes a kernel that holds all nine taps of a 64 x 64 tile in one workgroup (csrc/btx_wgrad_taps.h): x is staged
+ * once per pixel instead of once per tap.  ws: 16-byte aligned, btx_wgrad_workspace_bytes(kind, g, act_dtype, flags) bytes
+ * (BTX_E_WORKSPACE if smaller); the outputs need not be cleared and are fully overwritten.  A launch whose pixels fit one
+ * chunk stores straight into dw_* (no second launch).
+ * rho_w / drho (both or neither): the reduction launch also writes what btx_rho_grad would compute from the finished
+ * gradient, drho[i] = dw[i] * eps(i) * sigmoid(rho_w[i]) with dw = dw_delta (Flipout) or dw_mu (Reparameterization), eps of
+ * stream BTX_STREAM_EPS_W of rng; rho_w in the order of mu_w.  drho may alias dw_delta (which then holds drho only); for a
+ * Reparameterization layer it must be a buffer of its own (dw_mu is dmu). */
+size_t btx_wgrad_workspace_bytes(int kind, const BtxGeom* g, int act_dtype, uint32_t flags);
+int btx_contract_wgrad_ws(int kind, const BtxGeom* g, const void* x, const void* dy, float* dw_mu, float* dw_delta,
+                          float* db_mu, float* db_delta, const BtxRng* rng, const BtxNoise* noise /* nullable */,
+                          int act_dtype, uint32_t flags, void* ws, size_t ws_bytes, const float* rho_w /* nullable */,
+                          float* drho /* nullable */, void* stream);
 
 /* Sampling pre-pass, hoisted.  The LDS-DMA / patch kernels of btx_contract_fwd* first sample the layer's weights ONCE
  * into MFMA-ready tiles (W = mu + sigma*eps for Reparameterization; mu and sigma*eps for Flipout; reference:
@@ -338,7 +355,7 @@ int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, 
  * channels-last activations x[M][C] (M = N*H*W), ABI 7.  Forward: batch mean / biased variance per channel (f64 fold of per-block
  * f32 sums, fixed order), y = (x - mean) * invstd * gamma + beta, running_mean / running_var updated as torch does
  * (running = (1 - momentum) * running + momentum * batch, unbiased variance), save_mean / save_invstd (f32 [C]) for the backward.
- * Backward: dgamma = sum(dy * xhat), dbeta = sum(dy) (f32 [C]), dx = gamma * invstd * (dy - dbeta / M - xhat * dgamma / M).
+ * Backward: dgamma = sum(dy * xhat), dbeta = sum(dy) ([C] in param_dtype since ABI 8, f32 before; each nullable), dx = gamma * invstd * (dy - dbeta / M - xhat * dgamma / M).
  * x / y / dy / dx: act_dtype (BTX_ACT_F32 | BTX_ACT_BF16), 16-byte aligned; gamma, beta, running_*: param_dtype (same codes),
  * each nullable (affine=False / track_running_stats=False); C % 8 == 0, C <= 2048 (else BTX_E_UNSUPPORTED: the caller keeps
  * torch's own kernels).  Three launches per call on `stream`, workspace btx_bn_workspace_bytes(M, C). */
@@ -347,7 +364,7 @@ int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, 
                      void* running_mean, void* running_var, int param_dtype, float momentum, float eps, float* save_mean,
                      float* save_invstd, void* ws, size_t ws_bytes, void* stream);
 int btx_bn_train_bwd(const void* x, const void* dy, void* dx, int act_dtype, long long M, int C, const void* gamma,
-                     int param_dtype, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* ws,
+                     int param_dtype, const float* save_mean, const float* save_invstd, void* dgamma, void* dbeta, void* ws,
                      size_t ws_bytes, void* stream);
 
 /* Global average pooling in front of the classifier (resnet_large.py: AdaptiveAvgPool2d((1,1))): channels-last

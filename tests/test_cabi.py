@@ -28,7 +28,7 @@ def test_abi_version_and_argument_errors_without_gpu():
     """pure host-side calls: version, strerror, shape arithmetic, argument validation (no kernel is launched)"""
     from bayesian_torch_amd import _lib
     L = _lib.lib()
-    assert L.btx_abi_version() == 7
+    assert L.btx_abi_version() == 8
     assert b"NULL" in L.btx_strerror(-1)
     g = _lib.Geom()
     g.NB, g.D, g.H, g.W, g.C, g.N = 64, 1, 56, 56, 64, 128
@@ -67,6 +67,12 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert L.btx_sampled_w_bytes(ctypes.byref(g), 1, 2) == L.btx_sampled_w_bytes(ctypes.byref(g), 1, 0) > 0
     assert L.btx_contract_workspace_bytes(ctypes.byref(g), 1, 0, 3, 0) == 0  # unknown precision code
     assert L.btx_mc_accumulate_lanes(None, 2, 4, 10, 0, 0.0, None, None) == -1
+    # weight-gradient slabs (ABI 8), ResNet18 layer1 at batch 64: the all-taps kernel splits the 3136 64-pixel steps of its one
+    # 64 x 64 tile into 242 chunks of 13 (one workgroup per CU), the tap-per-workgroup kernel into 56 for its 9 taps (504 workgroups: one round); mean + delta
+    assert L.btx_wgrad_workspace_bytes(1, ctypes.byref(g), 1, 0) == 242 * 2 * 64 * 576 * 4
+    assert L.btx_wgrad_workspace_bytes(1, ctypes.byref(g), 0, 0) == 56 * 2 * 64 * 576 * 4   # f32 activations: no all-taps kernel
+    assert L.btx_wgrad_workspace_bytes(0, ctypes.byref(g), 0, 0) == 56 * 64 * 576 * 4
+    assert L.btx_contract_wgrad_ws(1, ctypes.byref(g), None, None, None, None, None, None, None, None, 1, 0, None, 0, None, None, None) == -4
 
 
 def test_argument_errors_of_the_sampling_and_format_entry_points():

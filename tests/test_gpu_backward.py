@@ -582,3 +582,77 @@ def test_backward_at_baseline_batch_vs_cpu_autograd(case):
     print("%s batch %d: dx, dmu, drho%s vs CPU autograd through the reference chain: %s" % (
         name, xshape[0], ", dmu_b, drho_b" if mbc is not None else "", ", ".join("%.2e" % e for e in errs)))
     assert max(errs) < 1e-4, (name, errs)
+
+
+# ---- the weight gradient's two accumulation paths and its all-taps kernel (csrc/btx_wgrad_taps.h) against the definition ----
+WGRAD_TAPS3_CASES = [(3, 64, 128, 7, 9), (2, 128, 64, 5, 63), (4, 64, 64, 14, 14), (16, 256, 256, 14, 14), (5, 64, 64, 2, 2)]
+
+
+@pytest.mark.parametrize("kind", ["flipout", "reparam"])
+def test_wgrad_all_taps_kernel_and_chunk_slabs_equal_the_definition(kind):
+    """btx_contract_wgrad_ws on stride-1 3x3 'same' convolutions with bf16 activations (the all-taps kernel: ragged pixel counts,
+    the widest supported row, several chunks per tile, a 2x2 image whose every tap touches the border) and btx_contract_wgrad
+    (f32 atomics, the tap-per-workgroup kernel) against dW_mu = sum_p dy[p] x[p @ tap], dW_delta = the same on the sign-flipped
+    operands, evaluated in float64 on the CPU with the sign tensors btx_fill_sign writes.  bf16 x bf16 products are exact in f32:
+    what is left is the f32 accumulation order (<= 2e-6)."""
+    from bayesian_torch_amd import _lib
+    from bayesian_torch_amd import functional as BF
+    dev = _dev()
+    K = _lib.KIND_FLIPOUT if kind == "flipout" else _lib.KIND_REPARAM
+    seed, smp, lid = 991, 3, 11
+    try:
+        for (nb, cin, cout, h, w) in WGRAD_TAPS3_CASES:
+            torch.manual_seed(nb + cin + w)
+            op = BF.OpDesc(2, cin, cout, 3, 1, 1)
+            x = torch.randn(nb, cin, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dy = torch.randn(nb, cout, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            w_shape = (cout, cin, 3, 3)
+            xd, dyd = x.double().cpu(), dy.double().cpu()
+            want = [torch.nn.grad.conv2d_weight(xd, w_shape, dyd, stride=1, padding=1)]
+            if kind == "flipout":
+                si = BF.fill_sign_hip(x.numel(), dev, seed, smp, lid, _lib.STREAM_SIGN_IN).reshape(nb, h, w, cin).permute(0, 3, 1, 2)
+                so = BF.fill_sign_hip(dy.numel(), dev, seed, smp, lid, _lib.STREAM_SIGN_OUT).reshape(nb, h, w, cout).permute(0, 3, 1, 2)
+                want.append(torch.nn.grad.conv2d_weight(xd * si.double().cpu(), w_shape, dyd * so.double().cpu(), stride=1, padding=1))
+            for atomics in (False, True):
+                BF.WGRAD_ATOMICS = atomics
+                got = BF.wgrad_hip(K, x, dy, op, seed, smp, lid, w_shape)
+                for g_, w_ in zip(got[:len(want)], want):
+                    err = _rel(g_.cpu(), w_)
+                    assert err < 2e-6, ((nb, cin, cout, h, w), kind, "atomics" if atomics else "slabs", err)
+            # the slab path adds the chunks in a fixed order: two calls agree bit for bit (the atomics path does not promise that)
+            BF.WGRAD_ATOMICS = False
+            a = BF.wgrad_hip(K, x, dy, op, seed, smp, lid, w_shape)
+            b = BF.wgrad_hip(K, x, dy, op, seed, smp, lid, w_shape)
+            assert torch.equal(a[0], b[0]) and (a[1] is None or torch.equal(a[1], b[1]))
+    finally:
+        BF.WGRAD_ATOMICS = False
+
+
+def test_wgrad_workspace_too_small_is_refused():
+    import ctypes
+    from bayesian_torch_amd import _lib
+    L = _lib.lib()
+    dev = _dev()
+    g = _lib.Geom()
+    g.NB, g.D, g.H, g.W, g.C, g.N = 2, 1, 8, 8, 64, 64
+    g.KD, g.KH, g.KW = 1, 3, 3
+    g.sd = g.sh = g.sw = 1
+    g.pd, g.ph, g.pw = 0, 1, 1
+    g.dd = g.dh = g.dw = 1
+    g.groups = 1
+    need = L.btx_wgrad_workspace_bytes(_lib.KIND_FLIPOUT, ctypes.byref(g), _lib.ACT_BF16, 0)
+    assert need == 2 * 2 * 64 * 576 * 4  # 128 pixels = two 64-pixel chunks, mean + delta
+    x = torch.zeros(2 * 8 * 8 * 64, dtype=torch.bfloat16, device=dev)
+    dw = torch.zeros(2, 64 * 576, device=dev)
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    r = _lib.Rng(1, 0, 0, None)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    args = (_lib.KIND_FLIPOUT, ctypes.byref(g), x.data_ptr(), x.data_ptr(), dw[0].data_ptr(), dw[1].data_ptr(), None, None,
+            ctypes.byref(r), None, _lib.ACT_BF16, 0)
+    assert L.btx_contract_wgrad_ws(*args, ws.data_ptr(), need - 4, None, None, st) == -4
+    assert L.btx_contract_wgrad_ws(*args, ws.data_ptr() + 4, need, None, None, st) == -6
+    assert L.btx_contract_wgrad_ws(*args, ws.data_ptr(), need, dw[0].data_ptr(), None, st) == -1  # rho_w without drho
+    dw.fill_(7.0)
+    assert L.btx_contract_wgrad_ws(*args, ws.data_ptr(), need, None, None, st) == 0
+    torch.cuda.synchronize()
+    assert float(dw.abs().max()) == 0.0  # fully overwritten (x = dy = 0), no clearing needed
