@@ -151,7 +151,7 @@ def lib():
     L.btx_bn_workspace_bytes.restype = sz
     L.btx_bn_workspace_bytes.argtypes = [i64, i32]
     L.btx_bn_train_fwd.restype = i32
-    L.btx_bn_train_fwd.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, sz, vp]
+    L.btx_bn_train_fwd.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, sz, vp]
     L.btx_bn_train_bwd.restype = i32
     L.btx_bn_train_bwd.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32, vp, vp, vp, vp, vp, sz, vp]
     L.btx_dgrad_weights.restype = i32

@@ -297,7 +297,7 @@ class BatchNormTrainFn(torch.autograd.Function):
     """y = batch_norm(x) with batch statistics; running_mean / running_var updated in place (as F.batch_norm does)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, batches_tracked=None):
         L = _lib.lib()
         C = x.shape[1]
         M = x.numel() // C
@@ -314,7 +314,8 @@ class BatchNormTrainFn(torch.autograd.Function):
         b = bias.detach().contiguous() if bias is not None else None
         _lib.check(L.btx_bn_train_fwd(x.data_ptr(), y.data_ptr(), _act_code(x.dtype), M, C, ptr(w), ptr(b), ptr(running_mean),
                                       ptr(running_var), pdt, float(momentum if momentum is not None else 0.0), float(eps),
-                                      save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+                                      save_mean.data_ptr(), save_invstd.data_ptr(), ptr(batches_tracked), ws.data_ptr(), ws.numel(),
+                                      stream))
         ctx.save_for_backward(x, w, save_mean, save_invstd)
         ctx.has_bias = bias is not None
         ctx.pdt = pdt
@@ -348,16 +349,18 @@ class BatchNormTrainFn(torch.autograd.Function):
                                       stream))
         gw = dgamma if (w is not None and ctx.needs_input_grad[1]) else None
         gb = dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return (dx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None, None
 
 
 def batch_norm_train(bn, x):
     """training-mode forward of the nn.BatchNorm module `bn` through libbtx (bn_train_usable(bn, x) must hold)"""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    nbt = bn.num_batches_tracked if bn.track_running_stats else None
+    if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1):
+        nbt.add_(1)   # not a device int64 word: torch's own increment
+        nbt = None
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return BatchNormTrainFn.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+    return BatchNormTrainFn.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, nbt)  # nbt += 1 inside the statistics launch
 
 
 class GraphedTrainStep:

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const float* __restr
                                                            const void* gamma, const void* beta, void* running_mean,
                                                            void* running_var, int pdt, float momentum, float eps,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                           float* __restrict__ scale, float* __restrict__ shift) {
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           long long* __restrict__ batches_tracked) {
+  if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;  // nn.BatchNorm's num_batches_tracked
   int c;
   double s, q;
   if (!bn_fold(partial, nblk, C, c, s, q)) return;
@@ -273,7 +275,7 @@ size_t btx_bn_workspace_bytes(long long M, int C) {
 
 int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, const void* gamma, const void* beta,
                      void* running_mean, void* running_var, int param_dtype, float momentum, float eps, float* save_mean,
-                     float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+                     float* save_invstd, long long* num_batches_tracked, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !y || !save_mean || !save_invstd || !ws) return BTX_E_NULL;
   if (!bn_ok(M, C)) return (M > 0 && C > 0) ? BTX_E_UNSUPPORTED : BTX_E_SHAPE;
   if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
@@ -296,7 +298,7 @@ int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, 
                        (const float*)nullptr, (const float*)nullptr, M, C, partial);
   }
   hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, nblk, M, C, x, act_dtype, gamma, beta, running_mean,
-                     running_var, param_dtype, momentum, eps, save_mean, save_invstd, scale, shift);
+                     running_var, param_dtype, momentum, eps, save_mean, save_invstd, scale, shift, num_batches_tracked);
   if (act_dtype == BTX_ACT_BF16)
     hipLaunchKernelGGL((bn_apply_kernel<__bf16, false>), dim3((unsigned)nap), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)nullptr,
                        (__bf16*)y, scale, (const float*)nullptr, shift, M, C);

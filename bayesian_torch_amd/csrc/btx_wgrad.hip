@@ -188,10 +188,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       }
     }
   };
-  Raw raw;
-  if constexpr (fast) { if (m_begin < m_end) fetch(m_begin, raw); }
+  // two register sets, fetched TWO steps ahead: a step of this kernel is short (8 MFMAs per wave; 4 on a row-fused stem) and one
+  // step of run-ahead left the L2 / HBM round trip exposed (profiles/r05_experiments.txt E13)
+  Raw raw_a, raw_b;
+  if constexpr (fast) {
+    if (m_begin < m_end) fetch(m_begin, raw_a);
+    if (m_begin + WG_PX < m_end) fetch(m_begin + WG_PX, raw_b);
+  }
 
-  for (int m0 = m_begin; m0 < m_end; m0 += WG_PX) {
+  auto body = [&](int m0, Raw& raw) __attribute__((always_inline)) {
     if constexpr (fast) {
       stash(raw);
     } else {
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
     }
     __syncthreads();
-    if constexpr (fast) { if (m0 + WG_PX < m_end) fetch(m0 + WG_PX, raw); }  // in flight during the MFMAs below
+    if constexpr (fast) { if (m0 + 2 * WG_PX < m_end) fetch(m0 + 2 * WG_PX, raw); }  // in flight during this step's and the next step's MFMAs
     if constexpr (fast) {
       // ---- multiply (bf16 MFMA): wave w takes pixels 16w..16w+15 of the step = one k-step of 16.  Fragment of lane (l31, hk) for
       // channel half i: channel 32 i + l31, pixels 16w + 8hk + 0..7 = two transpose reads of 4 pixels each; within the lane's
@@ -369,6 +374,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
     }
     __syncthreads();
+  };
+  for (int m0 = m_begin; m0 < m_end; m0 += 2 * WG_PX) {
+    body(m0, raw_a);
+    if (m0 + WG_PX < m_end) body(m0 + WG_PX, raw_b);
   }
 
   // ---- reduce the four waves' partial tiles through LDS and add them to dW.

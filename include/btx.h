@@ -362,7 +362,8 @@ int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, 
 size_t btx_bn_workspace_bytes(long long M, int C);
 int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, const void* gamma, const void* beta,
                      void* running_mean, void* running_var, int param_dtype, float momentum, float eps, float* save_mean,
-                     float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+                     float* save_invstd, long long* num_batches_tracked /* nullable, int64 device word: += 1 (ABI 8) */,
+                     void* ws, size_t ws_bytes, void* stream);
 int btx_bn_train_bwd(const void* x, const void* dy, void* dx, int act_dtype, long long M, int C, const void* gamma,
                      int param_dtype, const float* save_mean, const float* save_invstd, void* dgamma, void* dbeta, void* ws,
                      size_t ws_bytes, void* stream);
