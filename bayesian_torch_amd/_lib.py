@@ -34,6 +34,10 @@ class Rng(ctypes.Structure):
                 ("sample_idx_dev", ctypes.c_void_p)]
 
 
+class BnFuse(ctypes.Structure):
+    _fields_ = [("residual", ctypes.c_void_p), ("relu", ctypes.c_int32), ("mask", ctypes.c_void_p), ("dres", ctypes.c_void_p)]
+
+
 class Epilogue(ctypes.Structure):
     _fields_ = [("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("residual", ctypes.c_void_p),
                 ("relu", ctypes.c_int32), ("pool", ctypes.c_int32)]
@@ -151,9 +155,9 @@ def lib():
     L.btx_bn_workspace_bytes.restype = sz
     L.btx_bn_workspace_bytes.argtypes = [i64, i32]
     L.btx_bn_train_fwd.restype = i32
-    L.btx_bn_train_fwd.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, sz, vp]
+    L.btx_bn_train_fwd.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, ctypes.POINTER(BnFuse), vp, sz, vp]
     L.btx_bn_train_bwd.restype = i32
-    L.btx_bn_train_bwd.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32, vp, vp, vp, vp, vp, sz, vp]
+    L.btx_bn_train_bwd.argtypes = [vp, vp, vp, i32, i64, i32, vp, i32, vp, vp, vp, vp, ctypes.POINTER(BnFuse), vp, sz, vp]
     L.btx_dgrad_weights.restype = i32
     L.btx_dgrad_weights.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(Rng), vp]
     if L.btx_abi_version() != ABI_VERSION:

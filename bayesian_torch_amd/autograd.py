@@ -14,6 +14,8 @@ the backward: eps and the Flipout signs are regenerated.
                  reduction axis is the pixel axis, on the exact-f32 MFMA (csrc/btx_wgrad.hip); dmu = dW_mu and
                  drho = dW_delta * eps * sigmoid(rho) are elementwise follow-ups here.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -294,10 +296,12 @@ def bn_train_usable(bn, x):
 
 
 class BatchNormTrainFn(torch.autograd.Function):
-    """y = batch_norm(x) with batch statistics; running_mean / running_var updated in place (as F.batch_norm does)"""
+    """y = [relu](batch_norm(x) [+ residual]) with batch statistics; running_mean / running_var / num_batches_tracked updated in
+    place (as F.batch_norm / nn.BatchNorm do).  The ReLU and the residual add of the reference's blocks
+    (models/deterministic/resnet_large.py:46-62) ride in the normalisation's own launches (csrc/btx_bn.hip)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, batches_tracked=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, batches_tracked=None, residual=None, relu=False):
         L = _lib.lib()
         C = x.shape[1]
         M = x.numel() // C
@@ -312,19 +316,25 @@ class BatchNormTrainFn(torch.autograd.Function):
         ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         w = weight.detach().contiguous() if weight is not None else None
         b = bias.detach().contiguous() if bias is not None else None
+        mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=dev) if relu else None  # one bit per element: y > 0
+        fuse = None
+        if relu or residual is not None:
+            fuse = _lib.BnFuse(ptr(residual), 1 if relu else 0, ptr(mask), None)
         _lib.check(L.btx_bn_train_fwd(x.data_ptr(), y.data_ptr(), _act_code(x.dtype), M, C, ptr(w), ptr(b), ptr(running_mean),
                                       ptr(running_var), pdt, float(momentum if momentum is not None else 0.0), float(eps),
-                                      save_mean.data_ptr(), save_invstd.data_ptr(), ptr(batches_tracked), ws.data_ptr(), ws.numel(),
-                                      stream))
-        ctx.save_for_backward(x, w, save_mean, save_invstd)
+                                      save_mean.data_ptr(), save_invstd.data_ptr(), ptr(batches_tracked),
+                                      ctypes.byref(fuse) if fuse is not None else None, ws.data_ptr(), ws.numel(), stream))
+        ctx.save_for_backward(x, w, save_mean, save_invstd, mask)
         ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.relu = bool(relu)
         ctx.pdt = pdt
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        x, w, save_mean, save_invstd = ctx.saved_tensors
+        x, w, save_mean, save_invstd, mask = ctx.saved_tensors
         C = x.shape[1]
         M = x.numel() // C
         dev = x.device
@@ -343,24 +353,46 @@ class BatchNormTrainFn(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=pd, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         ws = BF._workspace(dev, L.btx_bn_workspace_bytes(M, C), stream)
+        want_res = ctx.has_res and ctx.needs_input_grad[8]
+        dres = None
+        fuse = None
+        if ctx.relu:
+            dres = torch.empty_like(x) if want_res else None  # g = dy where y > 0: the gradient of the residual branch
+            fuse = _lib.BnFuse(None, 1, mask.data_ptr(), dres.data_ptr() if dres is not None else None)
+        elif want_res:
+            dres = dy  # no ReLU behind the add: the residual branch receives dy itself
         _lib.check(L.btx_bn_train_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _act_code(x.dtype), M, C,
                                       w.data_ptr() if w is not None else None, ctx.pdt, save_mean.data_ptr(),
-                                      save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
-                                      stream))
+                                      save_invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                      ctypes.byref(fuse) if fuse is not None else None, ws.data_ptr(), ws.numel(), stream))
         gw = dgamma if (w is not None and ctx.needs_input_grad[1]) else None
         gb = dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return (dx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None, None, dres, None
 
 
-def batch_norm_train(bn, x):
-    """training-mode forward of the nn.BatchNorm module `bn` through libbtx (bn_train_usable(bn, x) must hold)"""
+def batch_norm_train(bn, x, residual=None, relu=False):
+    """training-mode forward of the nn.BatchNorm module `bn` through libbtx (bn_train_usable(bn, x) must hold), optionally with the
+    block's residual add and ReLU inside the same launches: y = [relu](bn(x) [+ residual])"""
     nbt = bn.num_batches_tracked if bn.track_running_stats else None
     if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1):
         nbt.add_(1)   # not a device int64 word: torch's own increment
         nbt = None
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return BatchNormTrainFn.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, nbt)  # nbt += 1 inside the statistics launch
+    # nbt += 1 happens inside the statistics launch
+    return BatchNormTrainFn.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, nbt, residual, relu)
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """[relu](bn(x) [+ residual]) as the reference's blocks spell it (resnet_large.py:46-62) — through the fused launches when the
+    call qualifies (bn_train_usable, residual of x's shape / dtype / storage layout), else with torch's own ops"""
+    if bn_train_usable(bn, x) and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype and
+                                                        residual.stride() == x.stride() and residual.is_cuda)):
+        return batch_norm_train(bn, x, residual=residual, relu=relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y
 
 
 class GraphedTrainStep:

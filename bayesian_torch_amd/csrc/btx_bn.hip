@@ -73,10 +73,13 @@ __device__ __forceinline__ void param_store(void* p, int dtype, int c, float v) 
 
 // Per-channel partial sums of two quantities over the rows of this block:  MODE 0: (x, x*x)   MODE 1: (dy, dy * (x - mean) * invstd)
 // partial[blk][2][C] (f32).  Block = 256 threads = RPB rows x (C/8) channel groups per pass; rows of a block: blk, blk + nblk, ...
-template <typename ACT, int MODE>
+// MASK (MODE 1, a fused ReLU behind the normalisation): dy counts only where the forward's output was positive — one bit per element,
+// the byte of this thread's 8 channels, written by the forward's apply pass.
+template <typename ACT, int MODE, bool MASK = false>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const ACT* __restrict__ x, const ACT* __restrict__ dy,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         long long M, int C, float* __restrict__ partial) {
+                                                         long long M, int C, float* __restrict__ partial,
+                                                         const uint8_t* __restrict__ mask = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [256 threads][16 partial sums] = 16 KiB
   const int cg = C >> 3;              // channel groups per row
   const int rpb = 256 / cg > 0 ? 256 / cg : 1;  // rows per pass (cg <= 256)
@@ -99,6 +102,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const ACT* __restrict__
     for (long long row = (long long)blockIdx.x * rpb + r; row < M; row += 4 * stride) {
       float v[4][8], d[4][8];
       bool ok[4];
+      uint32_t mk[4] = {0xffu, 0xffu, 0xffu, 0xffu};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long rw = row + u * stride;
@@ -106,7 +110,14 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const ACT* __restrict__
         if (ok[u]) {
           load8<ACT>(x + rw * C + g * 8, v[u]);
           if (MODE == 1) load8<ACT>(dy + rw * C + g * 8, d[u]);
+          if (MASK) mk[u] = mask[rw * cg + g];
         }
+      }
+      if (MASK) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) d[u][i] = ((mk[u] >> i) & 1u) ? d[u][i] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -226,11 +237,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restr
   cD[c] = (float)(-A * s * invM - B * mu);
 }
 
-// y = a[c] * x + d[c]   or   dx = a[c] * dy + b[c] * x + d[c]
-template <typename ACT, bool TWO>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const ACT* __restrict__ x, const ACT* __restrict__ dy, ACT* __restrict__ out,
-                                                       const float* __restrict__ ca, const float* __restrict__ cb,
-                                                       const float* __restrict__ cd, long long M, int C) {
+// forward apply: y = a[c] * x + d[c]  [+ residual]  [ReLU, and the byte of positive outputs of these 8 channels for the backward]
+template <typename ACT, bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const ACT* __restrict__ x, const ACT* __restrict__ res, ACT* __restrict__ out,
+                                                           const float* __restrict__ ca, const float* __restrict__ cd,
+                                                           uint8_t* __restrict__ mask, long long M, int C) {
   const int cg = C >> 3;
   const long long total = M * cg;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
@@ -239,16 +250,52 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const ACT* __restrict__ x
     load8<ACT>(x + t * 8, v);
     load8<float>(ca + g * 8, a);
     load8<float>(cd + g * 8, d);
-    if (TWO) {
-      float w[8], b[8];
-      load8<ACT>(dy + t * 8, w);
-      load8<float>(cb + g * 8, b);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(a[i], w[i], __builtin_fmaf(b[i], v[i], d[i]));
-    } else {
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(a[i], v[i], d[i]);
+    if (RES) {
+      float r[8];
+      load8<ACT>(res + t * 8, r);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(a[i], v[i], d[i]);
+      for (int i = 0; i < 8; ++i) o[i] += r[i];
     }
+    if (RELU) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        o[i] = o[i] < 0.f ? 0.f : o[i];       // NaN stays NaN, as torch.relu
+        m |= (o[i] > 0.f ? 1u : 0u) << i;     // torch's threshold_backward: the gradient passes where the output is > 0
+      }
+      mask[t] = (uint8_t)m;
+    }
+    store8<ACT>(out + t * 8, o);
+  }
+}
+
+// backward apply: dx = a[c] * g + b[c] * x + d[c],  g = dy [where the forward's output was positive]; GOUT: g leaves too (the
+// gradient of the residual branch)
+template <typename ACT, bool MASK, bool GOUT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const ACT* __restrict__ x, const ACT* __restrict__ dy, ACT* __restrict__ out,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           const float* __restrict__ cd, const uint8_t* __restrict__ mask,
+                                                           ACT* __restrict__ gout, long long M, int C) {
+  const int cg = C >> 3;
+  const long long total = M * cg;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int g = (int)(t % cg);
+    float v[8], o[8], a[8], d[8], w[8], b[8];
+    load8<ACT>(x + t * 8, v);
+    load8<ACT>(dy + t * 8, w);
+    load8<float>(ca + g * 8, a);
+    load8<float>(cb + g * 8, b);
+    load8<float>(cd + g * 8, d);
+    if (MASK) {
+      const uint32_t m = mask[t];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = ((m >> i) & 1u) ? w[i] : 0.f;
+      if (GOUT) store8<ACT>(gout + t * 8, w);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_fmaf(a[i], w[i], __builtin_fmaf(b[i], v[i], d[i]));
     store8<ACT>(out + t * 8, o);
   }
 }
@@ -275,13 +322,18 @@ size_t btx_bn_workspace_bytes(long long M, int C) {
 
 int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, const void* gamma, const void* beta,
                      void* running_mean, void* running_var, int param_dtype, float momentum, float eps, float* save_mean,
-                     float* save_invstd, long long* num_batches_tracked, void* ws, size_t ws_bytes, void* stream) {
+                     float* save_invstd, long long* num_batches_tracked, const BtxBnFuse* fuse, void* ws, size_t ws_bytes,
+                     void* stream) {
   if (!x || !y || !save_mean || !save_invstd || !ws) return BTX_E_NULL;
   if (!bn_ok(M, C)) return (M > 0 && C > 0) ? BTX_E_UNSUPPORTED : BTX_E_SHAPE;
   if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
   if (param_dtype != BTX_ACT_F32 && param_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
   if (ws_bytes < btx_bn_workspace_bytes(M, C)) return BTX_E_WORKSPACE;
-  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)ws)) & 15) return BTX_E_ALIGN;
+  const void* res = fuse ? fuse->residual : nullptr;
+  const bool relu = fuse && fuse->relu;
+  uint8_t* mask = fuse ? (uint8_t*)fuse->mask : nullptr;
+  if (relu && !mask) return BTX_E_NULL;
+  if ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)ws) | ((uintptr_t)res)) & 15) return BTX_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = bn_blocks(M, C);
   float* partial = (float*)ws;
@@ -292,31 +344,43 @@ int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, 
   if (nap > 8192) nap = 8192;
   if (act_dtype == BTX_ACT_BF16) {
     hipLaunchKernelGGL((bn_partial_kernel<__bf16, 0>), dim3(nblk), dim3(256), lds, st, (const __bf16*)x, (const __bf16*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, M, C, partial);
+                       (const float*)nullptr, (const float*)nullptr, M, C, partial, (const uint8_t*)nullptr);
   } else {
     hipLaunchKernelGGL((bn_partial_kernel<float, 0>), dim3(nblk), dim3(256), lds, st, (const float*)x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, M, C, partial);
+                       (const float*)nullptr, (const float*)nullptr, M, C, partial, (const uint8_t*)nullptr);
   }
   hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, nblk, M, C, x, act_dtype, gamma, beta, running_mean,
                      running_var, param_dtype, momentum, eps, save_mean, save_invstd, scale, shift, num_batches_tracked);
-  if (act_dtype == BTX_ACT_BF16)
-    hipLaunchKernelGGL((bn_apply_kernel<__bf16, false>), dim3((unsigned)nap), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)nullptr,
-                       (__bf16*)y, scale, (const float*)nullptr, shift, M, C);
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<float, false>), dim3((unsigned)nap), dim3(256), 0, st, (const float*)x, (const float*)nullptr,
-                       (float*)y, scale, (const float*)nullptr, shift, M, C);
+#define BTX_BN_FWD_APPLY(ACT, RES, RELU)                                                                                       \
+  hipLaunchKernelGGL((bn_fwd_apply_kernel<ACT, RES, RELU>), dim3((unsigned)nap), dim3(256), 0, st, (const ACT*)x, (const ACT*)res, \
+                     (ACT*)y, scale, shift, mask, M, C)
+#define BTX_BN_FWD_PICK(ACT)                                               \
+  do {                                                                     \
+    if (res && relu) BTX_BN_FWD_APPLY(ACT, true, true);                    \
+    else if (res) BTX_BN_FWD_APPLY(ACT, true, false);                      \
+    else if (relu) BTX_BN_FWD_APPLY(ACT, false, true);                     \
+    else BTX_BN_FWD_APPLY(ACT, false, false);                              \
+  } while (0)
+  if (act_dtype == BTX_ACT_BF16) BTX_BN_FWD_PICK(__bf16); else BTX_BN_FWD_PICK(float);
+#undef BTX_BN_FWD_PICK
+#undef BTX_BN_FWD_APPLY
   return (int)hipGetLastError();
 }
 
 int btx_bn_train_bwd(const void* x, const void* dy, void* dx, int act_dtype, long long M, int C, const void* gamma,
-                     int param_dtype, const float* save_mean, const float* save_invstd, void* dgamma, void* dbeta, void* ws,
-                     size_t ws_bytes, void* stream) {
+                     int param_dtype, const float* save_mean, const float* save_invstd, void* dgamma, void* dbeta,
+                     const BtxBnFuse* fuse, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !dx || !save_mean || !save_invstd || !ws) return BTX_E_NULL;
   if (!bn_ok(M, C)) return (M > 0 && C > 0) ? BTX_E_UNSUPPORTED : BTX_E_SHAPE;
   if (act_dtype != BTX_ACT_F32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
   if (param_dtype != BTX_ACT_F32 && param_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
   if (ws_bytes < btx_bn_workspace_bytes(M, C)) return BTX_E_WORKSPACE;
-  if ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)ws)) & 15) return BTX_E_ALIGN;
+  const bool relu = fuse && fuse->relu;
+  const uint8_t* mask = fuse ? (const uint8_t*)fuse->mask : nullptr;
+  void* dres = fuse ? fuse->dres : nullptr;
+  if (relu && !mask) return BTX_E_NULL;
+  if (dres && !relu) return BTX_E_UNSUPPORTED;  // without a ReLU the residual branch's gradient IS dy: nothing to write
+  if ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)ws) | ((uintptr_t)dres)) & 15) return BTX_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = bn_blocks(M, C);
   float* partial = (float*)ws;
@@ -326,20 +390,26 @@ int btx_bn_train_bwd(const void* x, const void* dy, void* dx, int act_dtype, lon
   const size_t lds = 256 * 16 * sizeof(float);
   long long nap = (M * (C / 8) + 255) / 256;
   if (nap > 8192) nap = 8192;
-  if (act_dtype == BTX_ACT_BF16)
-    hipLaunchKernelGGL((bn_partial_kernel<__bf16, 1>), dim3(nblk), dim3(256), lds, st, (const __bf16*)x, (const __bf16*)dy, save_mean,
-                       save_invstd, M, C, partial);
-  else
-    hipLaunchKernelGGL((bn_partial_kernel<float, 1>), dim3(nblk), dim3(256), lds, st, (const float*)x, (const float*)dy, save_mean,
-                       save_invstd, M, C, partial);
+#define BTX_BN_PARTIAL(ACT, MASK)                                                                                               \
+  hipLaunchKernelGGL((bn_partial_kernel<ACT, 1, MASK>), dim3(nblk), dim3(256), lds, st, (const ACT*)x, (const ACT*)dy, save_mean, \
+                     save_invstd, M, C, partial, mask)
+  if (act_dtype == BTX_ACT_BF16) { if (relu) BTX_BN_PARTIAL(__bf16, true); else BTX_BN_PARTIAL(__bf16, false); }
+  else { if (relu) BTX_BN_PARTIAL(float, true); else BTX_BN_PARTIAL(float, false); }
+#undef BTX_BN_PARTIAL
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, partial, nblk, M, C, gamma, param_dtype, save_mean,
                      save_invstd, dgamma, dbeta, cA, cB, cD);
-  if (act_dtype == BTX_ACT_BF16)
-    hipLaunchKernelGGL((bn_apply_kernel<__bf16, true>), dim3((unsigned)nap), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)dy,
-                       (__bf16*)dx, cA, cB, cD, M, C);
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3((unsigned)nap), dim3(256), 0, st, (const float*)x, (const float*)dy,
-                       (float*)dx, cA, cB, cD, M, C);
+#define BTX_BN_BWD_APPLY(ACT, MASK, GOUT)                                                                                      \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT, MASK, GOUT>), dim3((unsigned)nap), dim3(256), 0, st, (const ACT*)x, (const ACT*)dy, \
+                     (ACT*)dx, cA, cB, cD, mask, (ACT*)dres, M, C)
+#define BTX_BN_BWD_PICK(ACT)                                               \
+  do {                                                                     \
+    if (relu && dres) BTX_BN_BWD_APPLY(ACT, true, true);                   \
+    else if (relu) BTX_BN_BWD_APPLY(ACT, true, false);                     \
+    else BTX_BN_BWD_APPLY(ACT, false, false);                              \
+  } while (0)
+  if (act_dtype == BTX_ACT_BF16) BTX_BN_BWD_PICK(__bf16); else BTX_BN_BWD_PICK(float);
+#undef BTX_BN_BWD_PICK
+#undef BTX_BN_BWD_APPLY
   return (int)hipGetLastError();
 }
 

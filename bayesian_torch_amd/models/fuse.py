@@ -142,12 +142,48 @@ def fuse_resnet(model):
     return n
 
 
-def hip_batchnorm(model):
+def _basic_forward_train(self, x):
+    if not (self.training and x.is_cuda):
+        return self._btx_fwd_eval(x)
+    from .. import autograd as _ag
+    idt = x if self.downsample is None else self.downsample(x)
+    y = _ag.bn_act(self.bn1, self.conv1(x))
+    return _ag.bn_act(self.bn2, self.conv2(y), residual=idt)
+
+
+def _bottleneck_forward_train(self, x):
+    if not (self.training and x.is_cuda):
+        return self._btx_fwd_eval(x)
+    from .. import autograd as _ag
+    idt = x if self.downsample is None else self.downsample(x)
+    y = _ag.bn_act(self.bn1, self.conv1(x))
+    y = _ag.bn_act(self.bn2, self.conv2(y))
+    return _ag.bn_act(self.bn3, self.conv3(y), residual=idt)
+
+
+_KNOWN = ("bayesian_torch_amd.models.resnet", "torchvision.models.resnet")
+
+
+def _plain_block(m):
+    """a block whose forward is KNOWN to be the textbook one — conv/bn pairs, one shared ReLU, `downsample` — i.e. the classes of
+    models/resnet.py and torchvision.models.resnet (same attribute names on a user's own block prove nothing about its forward)"""
+    t = type(m)
+    return (t.__module__ in _KNOWN and t.__name__ in ("BasicBlock", "Bottleneck") and isinstance(getattr(m, "relu", None), nn.ReLU)
+            and all(isinstance(getattr(m, k, None), nn.modules.batchnorm._BatchNorm) for k in ("bn1", "bn2")))
+
+
+def hip_batchnorm(model, fuse_act=True):
     """Route the TRAINING-mode forward (and backward) of every nn.BatchNorm{1,2,3}d of `model` through libbtx
     (csrc/btx_bn.hip) whenever the call qualifies — CUDA, f32 / bf16, channels-last storage, C % 8 == 0
     (autograd.bn_train_usable) — and leave everything else (eval mode, CPU, other layouts) to torch.  The module tree,
     parameters, buffers and state_dict keys are untouched; results match F.batch_norm to rounding.  The reference's training
-    loop (README.md:114-125) spends a third of a ResNet18 step in ATen's channels-last BatchNorm kernels."""
+    loop (README.md:114-125) spends a third of a ResNet18 step in ATen's channels-last BatchNorm kernels.
+
+    fuse_act: the blocks and the stem of models/resnet.py / torchvision.models.resnet (the architecture of the reference's
+    models/deterministic/resnet_large.py:46-62, 85-105) also get their `relu(bn(.))` and
+    `relu(bn(.) + identity)` inside the normalisation's launches while training on the GPU (one rounding instead of two or three;
+    the ReLU's backward mask is a bit per element written by the forward).  Eval mode and CPU tensors keep the forward the block
+    had (the eval-mode folding of fuse_resnet included).  Returns the number of BatchNorm modules routed."""
     from .. import autograd as _ag
     n = 0
     for m in model.modules():
@@ -161,4 +197,21 @@ def hip_batchnorm(model):
             object.__setattr__(m, "_btx_bn_orig", orig)
             m.forward = types.MethodType(fwd, m)
             n += 1
+    if fuse_act:
+        for m in model.modules():
+            if _plain_block(m) and "_btx_fwd_eval" not in m.__dict__:
+                object.__setattr__(m, "_btx_fwd_eval", m.forward)
+                three = hasattr(m, "conv3") and hasattr(m, "bn3")
+                m.forward = types.MethodType(_bottleneck_forward_train if three else _basic_forward_train, m)
+        if (type(model).__module__ in _KNOWN and type(model).__name__ == "ResNet" and isinstance(getattr(model, "relu", None), nn.ReLU)
+                and "_btx_fwd_eval" not in model.__dict__):
+            object.__setattr__(model, "_btx_fwd_eval", model.forward)
+
+            def stem_fwd(self, x):
+                if not (self.training and x.is_cuda):
+                    return self._btx_fwd_eval(x)
+                x = self.maxpool(_ag.bn_act(self.bn1, self.conv1(x)))
+                x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+                return self.fc(self.avgpool(x).flatten(1))
+            model.forward = types.MethodType(stem_fwd, model)
     return n

@@ -360,13 +360,24 @@ int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, 
  * each nullable (affine=False / track_running_stats=False); C % 8 == 0, C <= 2048 (else BTX_E_UNSUPPORTED: the caller keeps
  * torch's own kernels).  Three launches per call on `stream`, workspace btx_bn_workspace_bytes(M, C). */
 size_t btx_bn_workspace_bytes(long long M, int C);
+/* ABI 8: what the reference's blocks do right behind the normalisation (models/deterministic/resnet_large.py:46-62: `relu(bn1(..))`,
+ * `relu(bn2(..) + identity)`), inside the same launches.  Forward: y = [relu](bn(x) [+ residual]) in ONE rounding; with relu the
+ * apply pass also writes one bit per element (y > 0; byte t = the 8 channels of 16-byte group t, M*C/8 bytes) into `mask`.
+ * Backward: the incoming gradient is first masked with those bits (torch's threshold_backward), g = dy where y > 0 else 0; all
+ * sums and dx are formed from g, and `dres` (nullable) receives g itself — the gradient of the residual branch. */
+typedef struct BtxBnFuse {
+  const void* residual;  /* forward: act_dtype, shape and layout of x, 16-byte aligned; nullable */
+  int32_t     relu;
+  void*       mask;      /* forward: written; backward: read.  Required when relu. */
+  void*       dres;      /* backward: act_dtype [M][C], 16-byte aligned; nullable; needs relu */
+} BtxBnFuse;
 int btx_bn_train_fwd(const void* x, void* y, int act_dtype, long long M, int C, const void* gamma, const void* beta,
                      void* running_mean, void* running_var, int param_dtype, float momentum, float eps, float* save_mean,
                      float* save_invstd, long long* num_batches_tracked /* nullable, int64 device word: += 1 (ABI 8) */,
-                     void* ws, size_t ws_bytes, void* stream);
+                     const BtxBnFuse* fuse /* nullable */, void* ws, size_t ws_bytes, void* stream);
 int btx_bn_train_bwd(const void* x, const void* dy, void* dx, int act_dtype, long long M, int C, const void* gamma,
-                     int param_dtype, const float* save_mean, const float* save_invstd, void* dgamma, void* dbeta, void* ws,
-                     size_t ws_bytes, void* stream);
+                     int param_dtype, const float* save_mean, const float* save_invstd, void* dgamma, void* dbeta,
+                     const BtxBnFuse* fuse /* nullable */, void* ws, size_t ws_bytes, void* stream);
 
 /* Global average pooling in front of the classifier (resnet_large.py: AdaptiveAvgPool2d((1,1))): channels-last
  * [NB][HW][C] -> [NB][C], f32 accumulation in a fixed order, C % 8 == 0. */

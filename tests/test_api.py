@@ -228,6 +228,32 @@ def test_fuse_resnet_keeps_the_checkpoint_format():
     assert not torch.allclose(b(x), yb)
 
 
+def test_hip_batchnorm_patch_leaves_cpu_and_eval_forwards_alone():
+    """hip_batchnorm(model): the training-mode fusion (BatchNorm + residual + ReLU in libbtx launches) applies to CUDA tensors of a
+    model in train(); on the CPU and in eval() the patched blocks run the forward they had; state_dict keys do not change; a
+    user's block that merely has the same attribute names is not touched"""
+    from bayesian_torch_amd.models.resnet import resnet18, BasicBlock
+    from bayesian_torch_amd.models.fuse import hip_batchnorm
+    torch.manual_seed(0)
+    a = resnet18(num_classes=10)
+    torch.manual_seed(0)
+    b = resnet18(num_classes=10)
+    keys = list(b.state_dict().keys())
+    assert hip_batchnorm(b) == 20 and hip_batchnorm(b) == 0   # idempotent
+    assert list(b.state_dict().keys()) == keys
+    x = torch.randn(2, 3, 224, 224)
+    a.train(); b.train()
+    assert torch.equal(a(x), b(x)) and torch.equal(a.bn1.running_var, b.bn1.running_var)
+    a.eval(); b.eval()
+    assert torch.equal(a(x), b(x))
+
+    class Mine(BasicBlock):   # same attributes, another forward (pre-activation): must keep its own forward
+        def forward(self, x):
+            return self.conv2(self.relu(self.bn2(self.conv1(self.relu(self.bn1(x)))))) + x
+    m = torch.nn.Sequential(Mine(8, 8))
+    assert hip_batchnorm(m) == 2 and "_btx_fwd_eval" not in m[0].__dict__
+
+
 def test_deepcopy_gets_its_own_noise_identity_and_prior_detection():
     import copy
     from bayesian_torch_amd import layers as L

@@ -51,7 +51,7 @@ def test_abi_version_and_argument_errors_without_gpu():
     assert L.btx_mc_packed_floats(64, 1000) == 2 * 64 * 1000 + 64 + 2
     # training-mode BatchNorm (ABI 7): workspace arithmetic and argument validation
     assert L.btx_bn_workspace_bytes(802816, 64) == (512 * 2 * 64 + 5 * 64) * 4 and L.btx_bn_workspace_bytes(100, 12) == 0
-    assert L.btx_bn_train_fwd(None, None, 1, 100, 64, None, None, None, None, 0, 0.1, 1e-5, None, None, None, None, 0, None) == -1
+    assert L.btx_bn_train_fwd(None, None, 1, 100, 64, None, None, None, None, 0, 0.1, 1e-5, None, None, None, None, None, 0, None) == -1
     # workspace = split-K partials (small-M ResNet18 layer4 shape) + the weight tiles sampled once per launch:
     # the big-M layer1 shape needs only the latter, 2 arrays (mu, delta) x 64 channels x K=576 x 2 bytes
     g.H = g.W = 7

@@ -418,6 +418,63 @@ def test_hip_batchnorm_training_matches_torch(shape, dtype, tol):
         assert torch.isfinite(y2.float()).all()
 
 
+@pytest.mark.parametrize("shape,dtype,tol", [((8, 64, 56, 56), torch.float32, 2e-5), ((16, 128, 28, 28), torch.bfloat16, 1e-2),
+                                             ((4, 24, 9, 11), torch.float32, 2e-5)])
+@pytest.mark.parametrize("variant", ["relu", "res_relu", "res"])
+def test_hip_batchnorm_fused_relu_and_residual_match_float64(shape, dtype, tol, variant):
+    """autograd.bn_act: y = [relu](bn(x) [+ residual]) inside the normalisation's launches (BtxBnFuse) against the same composition
+    of torch ops in float64 — y, dx, d(residual), dgamma, dbeta; the ReLU's backward mask is the bit per element the forward wrote"""
+    from bayesian_torch_amd import autograd as ag
+    dev = _dev()
+    torch.manual_seed(11)
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(C))
+        bn.bias.copy_(0.2 * torch.randn(C))
+    ref = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev).double()
+    ref.load_state_dict(bn.state_dict())
+    if dtype == torch.bfloat16:
+        bn = bn.to(torch.bfloat16)
+        with torch.no_grad():
+            for a, b in zip(ref.state_dict().values(), bn.state_dict().values()):
+                a.copy_(b.double())
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x = cl((torch.randn(*shape, device=dev) * 1.3 + 0.2).to(dtype))
+    r = cl(torch.randn(*shape, device=dev).to(dtype)) if "res" in variant else None
+    dy = cl(torch.randn(*shape, device=dev).to(dtype))
+    relu = "relu" in variant
+    bn.train(); ref.train()
+    x1 = x.clone().requires_grad_(True)
+    r1 = r.clone().requires_grad_(True) if r is not None else None
+    assert ag.bn_train_usable(bn, x1)
+    y = ag.bn_act(bn, x1, residual=r1, relu=relu)
+    y.backward(dy)
+    x2 = x.double().clone().requires_grad_(True)
+    r2 = r.double().clone().requires_grad_(True) if r is not None else None
+    yr = ref(x2)
+    if r2 is not None:
+        yr = yr + r2
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())  # noqa: E731
+    errs = dict(y=rel(y, yr), dx=rel(x1.grad, x2.grad), dgamma=rel(bn.weight.grad, ref.weight.grad), dbeta=rel(bn.bias.grad, ref.bias.grad),
+                rmean=rel(bn.running_mean, ref.running_mean))
+    if r is not None:
+        errs["dres"] = rel(r1.grad, r2.grad)
+    print("fused batchnorm %s %s %s: %s" % (variant, shape, dtype, ", ".join("%s %.2e" % kv for kv in errs.items())))
+    assert y.dtype == dtype and y.stride() == x.stride() and int(bn.num_batches_tracked) == 1
+    if relu:
+        assert float(y.min()) >= 0.0
+    for k, v in errs.items():
+        assert v < tol, (variant, k, v)
+    # a residual of another layout (or eval mode) takes torch's ops and still gives the same function
+    if r is not None:
+        y2 = ag.bn_act(bn, x, residual=r.contiguous(), relu=relu)
+        assert rel(y2, y) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+
+
 def test_training_step_with_hip_batchnorm_matches_torch_batchnorm():
     """one training step (README.md:114-125) of a converted ResNet18 at batch 8, f32 parity mode: loss and the gradients of the first
     and the last variational layer with hip_batchnorm(model) against the same model on torch's BatchNorm kernels"""
