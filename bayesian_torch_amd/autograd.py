@@ -24,15 +24,17 @@ from . import rng as _rng
 
 
 def fast_dgrad_ok(layer):
-    """the data gradient's weight operands in ONE launch (btx_dgrad_weights): Linear layers and stride-1 2-D convolutions on plain
-    layouts (no channel padding, no row-fused stem, groups == 1) whose padding does not exceed the dilated kernel extent"""
+    """the data gradient's weight operands in ONE launch (btx_dgrad_weights): Linear layers and 2-D convolutions on plain layouts
+    (no channel padding, no row-fused stem, groups == 1); at stride 1 the padding must not exceed the dilated kernel extent"""
     op = layer._op
     if layer._btx_cpad is not None or op.transposed or op.groups != 1:
         return False
     if op.nd == 0:
         return True
-    if op.nd == 2 and op.stride == (1, 1, 1) and op.in_channels > 4:
-        return all(d * (k - 1) - p >= 0 for d, k, p in zip(op.dilation[1:], op.kernel[1:], op.padding[1:]))
+    if op.nd == 2 and op.in_channels > 4:
+        if op.stride == (1, 1, 1):
+            return all(d * (k - 1) - p >= 0 for d, k, p in zip(op.dilation[1:], op.kernel[1:], op.padding[1:]))
+        return True  # strided: the transposed geometry on the un-flipped, channel-transposed kernel (the same one launch)
     return False
 
 
@@ -46,10 +48,17 @@ def _data_grad_hip(layer, dy, x_shape, nz, sample_idx, hashed_signs, mu, rho):
         mu_p, rho_p = BF.gemm_major_view(mu.detach(), op), BF.gemm_major_view(rho.detach(), op)
         if nd == 0:
             opT, taps, flip = BF.OpDesc(0, op.out_channels, op.in_channels), 1, False
-        else:
+        elif op.stride == (1, 1, 1):
             pad = tuple(d * (k - 1) - p for d, k, p in zip(op.dilation[1:], op.kernel[1:], op.padding[1:]))
             opT = BF.OpDesc(2, op.out_channels, op.in_channels, op.kernel[1:], 1, pad, op.dilation[1:], 1)
             taps, flip = op.kernel[1] * op.kernel[2], True
+        else:
+            # strided: dx = convT(dy, W); its GEMM-major operands [C][tap][N] are the channel transpose of the forward's [N][tap][C]
+            outpad = tuple((i + 2 * p - d * (k - 1) - 1) % s_ for i, p, d, k, s_ in
+                           zip(x_shape[2:], op.padding[1:], op.dilation[1:], op.kernel[1:], op.stride[1:]))
+            opT = BF.OpDesc(2, op.out_channels, op.in_channels, op.kernel[1:], op.stride[1:], op.padding[1:], op.dilation[1:], 1,
+                            transposed=True, output_padding=outpad)
+            taps, flip = op.kernel[1] * op.kernel[2], False
         sdev = getattr(layer, "_btx_sample_dev", None)  # captured training step: the sample index is a device word
         w_mu, w_rho, w_eps = BF.dgrad_weights_hip(mu_p, rho_p, op.out_channels, taps, op.in_channels, flip, _rng.seed(),
                                                   sample_idx, layer._btx_layer_id, sample_dev=sdev)
