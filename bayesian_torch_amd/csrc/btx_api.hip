@@ -1062,6 +1062,26 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     rc = make_plan(g, prec, flags, 64 * dma_nw, &pl);
     if (rc) return rc;
   }
+  // Parity-major pixel order (ContractParams.par_major) for the data gradient of a stride-2 2-D convolution — a transposed launch
+  // whose gather rule leaves 1, 2, 2 or 4 of a 3x3 filter's 9 taps per output-pixel parity class: with the pixels enumerated class by
+  // class every 256-pixel tile walks only its class's taps (2.25 of 9 on average) and needs no K split.  Single-sample launches of
+  // the generic LDS-DMA kernel with at least 8 pixel tiles and more than one tap.  BTX_NO_PAR_MAJOR=1 (tuning builds): raster order.
+  bool par_major = false;
+  int par_mqp = 0;
+  if (dma && !rowfuse && (flags & BTX_FLAG_TRANSPOSED) && lanes == 1 && g->groups == 1 && g->D == 1 && g->KD == 1 && g->sd == 1 &&
+      g->sh == 2 && g->sw == 2 && g->KH * g->KW <= 31 && g->KH * g->KW > 1 && (pl.Ho % 2) == 0 && (pl.Wo % 2) == 0 &&
+      pl.mtiles >= 8 && !tune_env("BTX_NO_PAR_MAJOR")) {
+    const int tp = 64 * dma_nw;
+    const long long mq = (long long)g->NB * (pl.Ho / 2) * (pl.Wo / 2);
+    const long long tiles_per_class = (mq + tp - 1) / tp;  // the last tile of a class is padded: no tile holds two classes
+    if (4 * tiles_per_class * pl.ntiles <= 0x7fffffffLL) {
+      par_major = true;
+      par_mqp = (int)(tiles_per_class * tp);
+      pl.mtiles = (int)(4 * tiles_per_class);
+      pl.ksplits = 1; pl.kper = pl.K;
+      pl.nwg = pl.mtiles * pl.ntiles * g->groups;
+    }
+  }
   // stem variant: row-fused small-C convolutions with the input rows of the tile resident in LDS (BTX_NO_STEM=1 disables)
   static const bool no_stem = tune_env("BTX_NO_STEM") != nullptr;
   StemPlan stp;
@@ -1208,6 +1228,12 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   p.sample_ptr = rng->sample_idx_dev;
   // BTX_FLAG_SWAP_SIGNS (data gradient of a Flipout layer): the op's input carries the forward's s_out, its output the
   // forward's s_in
+  p.fd_sd = make_fastdiv((uint32_t)g->sd); p.fd_sh = make_fastdiv((uint32_t)g->sh); p.fd_sw = make_fastdiv((uint32_t)g->sw);
+  if (par_major && !patch && !gemm8 && !stem) {
+    p.par_major = 1; p.par_Hh = pl.Ho / 2; p.par_Wh = pl.Wo / 2; p.par_Mq = g->NB * p.par_Hh * p.par_Wh; p.par_Mqp = par_mqp;
+    p.fd_par_Mqp = make_fastdiv((uint32_t)p.par_Mqp); p.fd_par_Hh = make_fastdiv((uint32_t)p.par_Hh);
+    p.fd_par_Wh = make_fastdiv((uint32_t)p.par_Wh);
+  }
   p.swap_signs = (flags & BTX_FLAG_SWAP_SIGNS) ? 1 : 0;
   p.reverse = (flags & BTX_FLAG_REVERSE) ? 1 : 0;
   sign_keys(rng, p.swap_signs ? BTX_STREAM_SIGN_OUT : BTX_STREAM_SIGN_IN, &p.kin_a, &p.kin_b);

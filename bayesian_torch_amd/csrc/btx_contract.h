@@ -122,6 +122,14 @@ struct ContractParams {
   FastDiv fd_inner, fd_ksplits, fd_ntiles, fd_Cg, fd_KW, fd_KH, fd_rtiles;  // wave-uniform index splits
   FastDiv fd_mtiles;
   int swap_signs;  // BTX_FLAG_SWAP_SIGNS: input signs from stream SIGN_OUT, output signs from SIGN_IN
+  // Parity-major pixel order of a stride-2 transposed 2-D launch (btx_api.hip par_major_ok: the data gradient of a stride-2
+  // convolution): logical pixel L = class * par_Mqp + q, class = 2 * (oh & 1) + (ow & 1), q < par_Mq the raster index of
+  // (image, oh / 2, ow / 2) on the par_Hh x par_Wh half-resolution grid, par_Mqp = par_Mq rounded up to whole pixel tiles.  A tile
+  // then lies inside ONE class, and of the KH x KW taps only those whose stride residue matches the class (1, 2, 2 or 4 of a 3x3
+  // filter's 9) reach any of its pixels: the others are not walked.  Workgroup t takes class t & 3, tile t >> 2 of that class.
+  int par_major, par_Mq, par_Mqp, par_Hh, par_Wh;
+  FastDiv fd_par_Mqp, fd_par_Hh, fd_par_Wh;
+  FastDiv fd_sd, fd_sh, fd_sw;  // transposed launches: the gather rule divides by the strides once per pixel, tap and K stage
   int wg_order;  // 0: workgroups that share a pixel tile are neighbours (same XCD L2 holds the activations);
                  // 1: workgroups that share a weight tile are (layers whose sampled weights outweigh their activations)
   void* trace;  // BTX_PT_TRACE builds: per-wave phase timings (measurement only)

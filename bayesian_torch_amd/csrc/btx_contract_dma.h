@@ -130,7 +130,31 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
 
   const int k_begin = split * p.kper;
   const int k_end = min(p.K, k_begin + p.kper);
-  const int nstages = (k_end - k_begin + BK - 1) / BK;
+  // parity-major transposed launches (ContractParams.par_major; ksplits == 1, KD == 1, Cg % BK == 0): every pixel of the tile has
+  // the parity class (oh & 1, ow & 1) of the tile, and tap (kh, kw) reaches such a pixel only if oh + ph - kh*dh and ow + pw - kw*dw
+  // are multiples of the stride 2 — the stages of the other taps are neither fetched nor multiplied.
+  uint32_t tapmask = 0xffffffffu;  // bit t: tap t = kh * KW + kw is walked
+  int spt = 1;                     // K stages per tap
+  bool par = false;
+  int tile_m0 = mtile * TP;        // first (logical) pixel of the tile
+  int par_nvalid = 0;              // parity-major: pixels of the tile that exist (the class's last tile is padded)
+  if constexpr (!PW) {
+    if (p.par_major) {
+      // tile t: class t & 3, tile t >> 2 of that class (classes alternate: every XCD's range of tiles holds all four, the classes'
+      // unequal stage counts even out); logical pixel = class * par_Mqp + q, q < par_Mq the class's raster index
+      par = true;
+      spt = p.Cg / BK;
+      const int cls = mtile & 3, q0 = (mtile >> 2) * TP;
+      tile_m0 = cls * p.par_Mqp + q0;
+      par_nvalid = min(TP, p.par_Mq - q0);
+      const int pi = cls >> 1, pj = cls & 1;
+      tapmask = 0u;
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw)
+          if ((((pi + p.ph + kh * p.dh) | (pj + p.pw + kw * p.dw)) & 1) == 0) tapmask |= 1u << (kh * p.KW + kw);
+    }
+  }
+  const int nstages = par ? __builtin_popcount(tapmask) * spt : (k_end - k_begin + BK - 1) / BK;
 
   const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.wt_bytes, 0x00020000);
   // ---- weight loader role: the stage's tile is 4 rows of mu (+ 4 rows of delta, Flipout) of 1 KiB in the pre-sampled
@@ -142,8 +166,18 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
                           (uint32_t)(wave & 3) * 1024u + (uint32_t)(k_begin / G) * 1024u;
   const int w_lds = DW_OFF + (wave & 3) * 1024;
 
-  auto issue_w = [&](int st) __attribute__((always_inline)) {
-    const uint32_t go = w_base + (uint32_t)st * (uint32_t)(BK / G) * 1024u;
+  int w_tap = par ? __builtin_ctz(tapmask | 0x80000000u) : 0, w_cs = 0;  // parity-major: the live tap / stage inside it of the next tile
+  auto issue_w = [&](int st) __attribute__((always_inline)) {  // called for st = 0, 1, 2, ... in order
+    uint32_t go = w_base + (uint32_t)st * (uint32_t)(BK / G) * 1024u;
+    if constexpr (!PW) {
+      if (par) {
+        go = w_base + (uint32_t)(w_tap * spt + w_cs) * (uint32_t)(BK / G) * 1024u;
+        if (++w_cs == spt) {
+          w_cs = 0;
+          do { ++w_tap; } while (w_tap < 32 && !((tapmask >> w_tap) & 1u));
+        }
+      }
+    }
     unsigned char* ld = smem + w_lds + (st % WD) * DW_STAGE;
     if (w_mu) dma16(wt_rsrc, go, ld);
     if (w_dl) dma16(wt_rsrc, go + p.wt_delta_off, ld + 4096);
@@ -160,9 +194,17 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   bool pb_ok[4];
   auto decode = [&](int mm_, int& bd_, int& bh_, int& bw_, int& nbase_, uint32_t& off_) __attribute__((always_inline)) {
     uint32_t t, t2, uow, uoh, uod, unb;
+    if (par) {  // logical pixel -> (class, image, oh / 2, ow / 2)   (Do == 1)
+      uint32_t cls, q, a, b;
+      fdivmod((uint32_t)mm_, p.fd_par_Mqp, (uint32_t)p.par_Mqp, cls, q);
+      fdivmod(q, p.fd_par_Wh, (uint32_t)p.par_Wh, t, b);
+      fdivmod(t, p.fd_par_Hh, (uint32_t)p.par_Hh, unb, a);
+      uoh = 2u * a + (cls >> 1); uow = 2u * b + (cls & 1u); uod = 0u;
+    } else {
     fdivmod((uint32_t)mm_, p.fd_Wo, (uint32_t)p.Wo, t, uow);
     fdivmod(t, p.fd_Ho, (uint32_t)p.Ho, t2, uoh);
     fdivmod(t2, p.fd_Do, (uint32_t)p.Do, unb, uod);
+    }
     const int ow = (int)uow, oh = (int)uoh, od = (int)uod, nb = (int)unb;
     nbase_ = nb * p.D;
     if (!p.transposed) {
@@ -178,8 +220,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   const bool pointwise = PW || (p.pointwise != 0);  // wave-uniform
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int mq = mtile * TP + wave * 64 + q * 16 + (lane >> 2);
-    pb_ok[q] = mq < p.M;
+    const int pl_ = wave * 64 + q * 16 + (lane >> 2);
+    const int mq = tile_m0 + pl_;
+    pb_ok[q] = par ? (pl_ < par_nvalid) : (mq < p.M);
     if (PW || pointwise) {
       pb_d[q] = pb_h[q] = pb_w[q] = pb_n[q] = 0;
       pb_off[q] = (uint32_t)(pb_ok[q] ? mq : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
@@ -216,10 +259,11 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   uint32_t sg_off;  // this thread's own pixel (tid): only the sign word needs it
   {
-    const int m = mtile * TP + tid;
+    const int m = tile_m0 + tid;
+    const bool m_ok = par ? (tid < par_nvalid) : (m < p.M);
     int a_, b_, c_, d_;
-    if (PW || pointwise) sg_off = (uint32_t)(m < p.M ? m : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
-    else if constexpr (!PW) decode(m < p.M ? m : 0, a_, b_, c_, d_, sg_off);
+    if (PW || pointwise) sg_off = (uint32_t)(m_ok ? m : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+    else if constexpr (!PW) decode(m_ok ? m : 0, a_, b_, c_, d_, sg_off);
   }
 
   // wave-uniform K walk: channel offset inside the tap and the tap itself
@@ -232,6 +276,11 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     fdivmod(tap, p.fd_KW, (uint32_t)p.KW, t2, kw0);
     fdivmod(t2, p.fd_KH, (uint32_t)p.KH, kd0, kh0);
     s_tap = (int)tap; s_c = (int)c0; s_kw = (int)kw0; s_kh = (int)kh0; s_kd = (int)kd0;
+    if (par) {  // the walk starts at the first live tap
+      s_tap = __builtin_ctz(tapmask | 0x80000000u);
+      fdivmod((uint32_t)s_tap, p.fd_KW, (uint32_t)p.KW, kh0, kw0);
+      s_kh = (int)kh0; s_kw = (int)kw0; s_kd = 0; s_c = 0;
+    }
   }
 
   int a_slot_issue = 0;  // ring slot the next issue_acts() fills
@@ -261,7 +310,8 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
         bo = pb_boff[q] + tap_boff;
       } else {
         const int td = pb_d[q] - s_kd * p.dd, th = pb_h[q] - s_kh * p.dh, tw = pb_w[q] - s_kw * p.dw;
-        const int id = td / p.sd, ih = th / p.sh, iw = tw / p.sw;
+        // (multiply-shift division: negative numerators come out wrong and are rejected by the sign tests below)
+        const int id = (int)fdiv((uint32_t)td, p.fd_sd), ih = (int)fdiv((uint32_t)th, p.fd_sh), iw = (int)fdiv((uint32_t)tw, p.fd_sw);
         ok = pb_ok[q] && td >= 0 && th >= 0 && tw >= 0 && (id * p.sd == td) && (ih * p.sh == th) &&
              (iw * p.sw == tw) && id < p.D && ih < p.H && iw < p.W;
         bo = ((uint32_t)(((pb_n[q] + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C +
@@ -274,11 +324,13 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
       // activations are zero, so the word is irrelevant there.  Transposed: recompute the input offset.)
       uint32_t off = sg_off + tap_off;
       if (!PW && p.transposed) {
-        const int m = mtile * TP + tid;
+        const int m = tile_m0 + tid;
         int bd_, bh_, bw_, nb_;
         uint32_t o_;
-        decode(m < p.M ? m : 0, bd_, bh_, bw_, nb_, o_);
-        const int id = (bd_ - s_kd * p.dd) / p.sd, ih = (bh_ - s_kh * p.dh) / p.sh, iw = (bw_ - s_kw * p.dw) / p.sw;
+        decode((par ? (tid < par_nvalid) : (m < p.M)) ? m : 0, bd_, bh_, bw_, nb_, o_);
+        // (a pixel whose tap falls outside — negative numerator — carries zero activations: its word is irrelevant)
+        const int id = (int)fdiv((uint32_t)(bd_ - s_kd * p.dd), p.fd_sd), ih = (int)fdiv((uint32_t)(bh_ - s_kh * p.dh), p.fd_sh),
+                  iw = (int)fdiv((uint32_t)(bw_ - s_kw * p.dw), p.fd_sw);
         off = (uint32_t)(((nb_ + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + s_c);
       }
       // sign layout: element pair e>>1 sits at bit 15-(e>>1) (even e) / 31-(e>>1) (odd e) of its word, so a stage that
@@ -301,8 +353,10 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     s_c += BK;
     if (!PW && s_c >= p.Cg) {
       s_c = 0;
-      ++s_tap;
-      if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; ++s_kd; } }
+      do {  // (parity-major: on to the next LIVE tap)
+        ++s_tap;
+        if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; ++s_kd; } }
+      } while (par && s_tap < 32 && !((tapmask >> s_tap) & 1u));
     }
     a_slot_issue = (a_slot_issue == DMA_D - 1) ? 0 : a_slot_issue + 1;
   };
@@ -394,8 +448,8 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   // =================== epilogue (btx_epilogue.h) ============================================================
   {
     BTX_SECTION_PARAMS(pe, logical2);
-    const uint32_t m0 = (uint32_t)mtile * (uint32_t)TP;
-    const int nvalid = min(TP, pe.M - (int)m0);
+    const uint32_t m0 = (uint32_t)tile_m0;
+    const int nvalid = par ? par_nvalid : min(TP, pe.M - (int)m0);
 #ifdef BTX_PT_TRACE
     tr_t2 = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
@@ -404,7 +458,16 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     staged_epilogue<KIND, NW, BTX_DMA_RPRE != 0>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid, ep_t);
     tr_ab = ep_t[0] - tr_t2; tr_bc = ep_t[1] - ep_t[0];
 #else
-    staged_epilogue<KIND, NW, BTX_DMA_RPRE != 0>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    bool par_ep = false;
+    if constexpr (!PW) par_ep = pe.par_major != 0;
+    if (par_ep) {
+      if constexpr (!PW) {
+        const PixParity pm = {pe, m0, nvalid};
+        staged_epilogue_pm<KIND, NW, PixParity, false>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pm);
+      }
+    } else {
+      staged_epilogue<KIND, NW, BTX_DMA_RPRE != 0>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
+    }
 #endif
   }
 #ifdef BTX_PT_TRACE

@@ -87,6 +87,31 @@ struct PixContig {
   };
   __device__ __forceinline__ Walk walk(int pl) const { return Walk{m0 + (uint32_t)pl, pl, nvalid}; }
 };
+// parity-major tiles (ContractParams.par_major): logical pixel L = m0 + pl -> the output pixel it names
+__device__ __forceinline__ uint32_t par_major_pixel(const ContractParams& p, uint32_t L) {
+  uint32_t cls, q, t, b, nb, a;
+  fdivmod(L, p.fd_par_Mqp, (uint32_t)p.par_Mqp, cls, q);
+  fdivmod(q, p.fd_par_Wh, (uint32_t)p.par_Wh, t, b);
+  fdivmod(t, p.fd_par_Hh, (uint32_t)p.par_Hh, nb, a);
+  return (nb * (uint32_t)p.Ho + 2u * a + (cls >> 1)) * (uint32_t)p.Wo + 2u * b + (cls & 1u);
+}
+struct PixParity {
+  const ContractParams& p;
+  uint32_t m0;
+  int nvalid;
+  __device__ __forceinline__ uint32_t operator()(int pl, bool& ok) const {
+    ok = pl < nvalid;
+    return ok ? par_major_pixel(p, m0 + (uint32_t)pl) : 0u;
+  }
+  __device__ __forceinline__ uint32_t first() const { return 0u; }
+  struct Walk {
+    const ContractParams& p;
+    uint32_t L; int pl, nvalid;
+    __device__ __forceinline__ uint32_t get(bool& ok) const { ok = pl < nvalid; return ok ? par_major_pixel(p, L) : 0u; }
+    __device__ __forceinline__ void step8() { L += 8u; pl += 8; }
+  };
+  __device__ __forceinline__ Walk walk(int pl) const { return Walk{p, m0 + (uint32_t)pl, pl, nvalid}; }
+};
 struct PixTall {  // tile = pt_R virtual rows from row0 x pt_Wt columns from col0; virtual row k = image k / pt_P, row k % pt_P
   const ContractParams& p;
   int row0, col0;

@@ -23,6 +23,12 @@ CASES = [
     ("Conv3dReparameterization", dict(in_channels=8, out_channels=8, kernel_size=3, prior_mean=0, prior_variance=1,
                                       posterior_mu_init=0, posterior_rho_init=-3.0, padding=1), (1, 8, 5, 6, 7)),
     ("ConvTranspose2dFlipout", dict(in_channels=16, out_channels=16, kernel_size=4, stride=2, padding=1), (2, 16, 6, 7)),
+    # stride-2 data gradients on enough pixels for the parity-major order of the transposed launch (ContractParams.par_major): tiles
+    # that straddle two parity classes, a ragged last tile (3 * 26 * 26 = 2028 pixels), 1x1 and 5x5 filters, a forward ConvTranspose
+    ("Conv2dFlipout", dict(in_channels=16, out_channels=32, kernel_size=3, stride=2, padding=1, bias=False), (3, 16, 26, 26)),
+    ("Conv2dFlipout", dict(in_channels=16, out_channels=32, kernel_size=1, stride=2, bias=False), (3, 16, 26, 26)),
+    ("Conv2dReparameterization", dict(in_channels=16, out_channels=16, kernel_size=5, stride=2, padding=2, bias=False), (2, 16, 36, 28)),
+    ("ConvTranspose2dFlipout", dict(in_channels=32, out_channels=16, kernel_size=3, stride=2, padding=1, output_padding=1), (2, 32, 18, 16)),
     # small-C stems: forward and weight gradient on the row-fused geometry
     ("Conv2dFlipout", dict(in_channels=3, out_channels=32, kernel_size=7, stride=2, padding=3, bias=False), (2, 3, 30, 26)),
     ("Conv2dReparameterization", dict(in_channels=3, out_channels=16, kernel_size=3, stride=1, padding=1), (2, 3, 11, 9)),
