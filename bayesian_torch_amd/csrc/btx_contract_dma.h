@@ -258,13 +258,18 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   for (int q = 0; q < 4; ++q) pb_boff[q] = (pb_off[q] + (uint32_t)(G * g_lane)) * (uint32_t)sizeof(ACT);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   uint32_t sg_off;  // this thread's own pixel (tid): only the sign word needs it
+  int sg_bd = 0, sg_bh = 0, sg_bw = 0, sg_nb = 0;
   {
     const int m = tile_m0 + tid;
     const bool m_ok = par ? (tid < par_nvalid) : (m < p.M);
-    int a_, b_, c_, d_;
     if (PW || pointwise) sg_off = (uint32_t)(m_ok ? m : 0) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
-    else if constexpr (!PW) decode(m_ok ? m : 0, a_, b_, c_, d_, sg_off);
+    else if constexpr (!PW) decode(m_ok ? m : 0, sg_bd, sg_bh, sg_bw, sg_nb, sg_off);
   }
+  // transposed launches: the gather rule (three divisions, eight compares per pixel) depends on the TAP, not on the channel block —
+  // evaluated once per tap and kept for the tap's Cg / BK stages
+  int tp_tap = -1;
+  bool tp_ok[4] = {false, false, false, false};
+  uint32_t tp_bo[4] = {0u, 0u, 0u, 0u}, tp_sg = 0u;
 
   // wave-uniform K walk: channel offset inside the tap and the tap itself
   int s_c, s_kd, s_kh, s_kw, s_tap;
@@ -294,6 +299,27 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
       tap_off = (uint32_t)(((s_kd * p.dd) * p.H + s_kh * p.dh) * p.W + s_kw * p.dw) * (uint32_t)p.C + (uint32_t)s_c;
     const uint32_t tap_boff = tap_off * (uint32_t)sizeof(ACT);
     unsigned char* as = smem + DA_OFF + a_slot_issue * DA_STAGE + wave * 4096;
+    if constexpr (!PW) {
+      if (p.transposed && tp_tap != s_tap) {  // wave-uniform: a new tap
+        tp_tap = s_tap;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int td = pb_d[q] - s_kd * p.dd, th = pb_h[q] - s_kh * p.dh, tw = pb_w[q] - s_kw * p.dw;
+          // (multiply-shift division: negative numerators come out wrong and are rejected by the sign tests below)
+          const int id = (int)fdiv((uint32_t)td, p.fd_sd), ih = (int)fdiv((uint32_t)th, p.fd_sh), iw = (int)fdiv((uint32_t)tw, p.fd_sw);
+          tp_ok[q] = pb_ok[q] && td >= 0 && th >= 0 && tw >= 0 && (id * p.sd == td) && (ih * p.sh == th) &&
+                     (iw * p.sw == tw) && id < p.D && ih < p.H && iw < p.W;
+          tp_bo[q] = ((uint32_t)(((pb_n[q] + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C +
+                      (uint32_t)(group * p.Cg + G * g_lane)) * (uint32_t)sizeof(ACT);
+        }
+        if constexpr (KIND == 1) {
+          // (a pixel whose tap falls outside — negative numerator — carries zero activations: its word is irrelevant)
+          const int id = (int)fdiv((uint32_t)(sg_bd - s_kd * p.dd), p.fd_sd), ih = (int)fdiv((uint32_t)(sg_bh - s_kh * p.dh), p.fd_sh),
+                    iw = (int)fdiv((uint32_t)(sg_bw - s_kw * p.dw), p.fd_sw);
+          tp_sg = (uint32_t)(((sg_nb + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg);
+        }
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       bool ok;
@@ -309,13 +335,8 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
         ok = pb_ok[q] && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         bo = pb_boff[q] + tap_boff;
       } else {
-        const int td = pb_d[q] - s_kd * p.dd, th = pb_h[q] - s_kh * p.dh, tw = pb_w[q] - s_kw * p.dw;
-        // (multiply-shift division: negative numerators come out wrong and are rejected by the sign tests below)
-        const int id = (int)fdiv((uint32_t)td, p.fd_sd), ih = (int)fdiv((uint32_t)th, p.fd_sh), iw = (int)fdiv((uint32_t)tw, p.fd_sw);
-        ok = pb_ok[q] && td >= 0 && th >= 0 && tw >= 0 && (id * p.sd == td) && (ih * p.sh == th) &&
-             (iw * p.sw == tw) && id < p.D && ih < p.H && iw < p.W;
-        bo = ((uint32_t)(((pb_n[q] + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C +
-              (uint32_t)(group * p.Cg + s_c + G * g_lane)) * (uint32_t)sizeof(ACT);
+        ok = tp_ok[q];
+        bo = tp_bo[q] + (uint32_t)s_c * (uint32_t)sizeof(ACT);
       }
       dma16(x_rsrc, ok ? bo : DMA_OOB, as + q * 1024);
     }
@@ -323,16 +344,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
       // one hashed word covers the 32 (bf16) / 16 (f32) channels of pixel `tid`'s stage.  (In the padding the
       // activations are zero, so the word is irrelevant there.  Transposed: recompute the input offset.)
       uint32_t off = sg_off + tap_off;
-      if (!PW && p.transposed) {
-        const int m = tile_m0 + tid;
-        int bd_, bh_, bw_, nb_;
-        uint32_t o_;
-        decode((par ? (tid < par_nvalid) : (m < p.M)) ? m : 0, bd_, bh_, bw_, nb_, o_);
-        // (a pixel whose tap falls outside — negative numerator — carries zero activations: its word is irrelevant)
-        const int id = (int)fdiv((uint32_t)(bd_ - s_kd * p.dd), p.fd_sd), ih = (int)fdiv((uint32_t)(bh_ - s_kh * p.dh), p.fd_sh),
-                  iw = (int)fdiv((uint32_t)(bw_ - s_kw * p.dw), p.fd_sw);
-        off = (uint32_t)(((nb_ + id) * p.H + ih) * p.W + iw) * (uint32_t)p.C + (uint32_t)(group * p.Cg + s_c);
-      }
+      if (!PW && p.transposed) off = tp_sg + (uint32_t)s_c;
       // sign layout: element pair e>>1 sits at bit 15-(e>>1) (even e) / 31-(e>>1) (odd e) of its word, so a stage that
       // starts at element offset e0 inside the word needs the word shifted left by e0>>1 within each 16-bit half
       const uint32_t n_in = p.x_bytes / (uint32_t)sizeof(ACT);
