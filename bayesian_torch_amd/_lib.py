@@ -70,7 +70,7 @@ EXPORTS = ("btx_abi_version", "btx_strerror", "btx_kl_workspace_bytes", "btx_kl_
            "btx_contract_workspace_bytes", "btx_contract_fwd", "btx_contract_fwd_ex", "btx_contract_fwd_lanes", "btx_contract_pool_shape", "btx_out_shape", "btx_fill_eps", "btx_fill_sign", "btx_rho_grad",
            "btx_mc_packed_floats", "btx_mc_accumulate", "btx_mc_accumulate_lanes", "btx_sampled_w_bytes", "btx_sample_weights", "btx_sampled_w_bytes_lanes", "btx_sample_weights_lanes", "btx_rowfuse_pack", "btx_maxpool2d_cl", "btx_avgpool_global_cl",
            "btx_bn_workspace_bytes", "btx_bn_train_fwd", "btx_bn_train_bwd", "btx_dgrad_weights",
-           "btx_wgrad_workspace_bytes", "btx_contract_wgrad_ws")
+           "btx_wgrad_workspace_bytes", "btx_contract_wgrad_ws", "btx_maxpool2d_cl_train", "btx_maxpool2d_cl_bwd")
 
 
 def lib_path():
@@ -145,6 +145,10 @@ def lib():
                                    i32, vp]
     L.btx_maxpool2d_cl.restype = i32
     L.btx_maxpool2d_cl.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.btx_maxpool2d_cl_train.restype = i32
+    L.btx_maxpool2d_cl_train.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.btx_maxpool2d_cl_bwd.restype = i32
+    L.btx_maxpool2d_cl_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     L.btx_avgpool_global_cl.restype = i32
     L.btx_avgpool_global_cl.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.btx_mc_accumulate.restype = i32

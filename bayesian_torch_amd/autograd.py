@@ -404,6 +404,46 @@ def bn_act(bn, x, residual=None, relu=True):
     return torch.relu(y) if relu else y
 
 
+def max_pool_train_usable(mp, x):
+    """nn.MaxPool2d `mp` on `x` can take btx_maxpool2d_cl_train / _bwd: a CUDA f32 / bf16 tensor in channels-last storage with
+    C % 8 == 0 that needs a gradient; square integer window <= 15, dilation 1, floor mode, no indices asked for"""
+    if not (isinstance(mp, torch.nn.MaxPool2d) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return False
+    sq = lambda v: v if isinstance(v, int) else (v[0] if (len(v) == 2 and v[0] == v[1]) else None)  # noqa: E731
+    k, s_, p_, d_ = sq(mp.kernel_size), sq(mp.stride if mp.stride is not None else mp.kernel_size), sq(mp.padding), sq(mp.dilation)
+    if None in (k, s_, p_, d_) or d_ != 1 or mp.ceil_mode or mp.return_indices or k > 15 or 2 * p_ > k:
+        return False
+    n, c, h, w = x.shape
+    if c % 8 != 0 or x.numel() == 0 or (h + 2 * p_ - k) // s_ + 1 <= 0 or (w + 2 * p_ - k) // s_ + 1 <= 0:
+        return False
+    return x.is_contiguous(memory_format=torch.channels_last)
+
+
+class MaxPool2dTrainFn(torch.autograd.Function):
+    """F.max_pool2d on the HIP backend under autograd: one byte per output element (the window position of its maximum) instead of
+    ATen's int64 index; forward and backward equal torch's bit for bit (tests/test_gpu_backward.py)"""
+
+    @staticmethod
+    def forward(ctx, x, k, s_, p_):
+        y, idx = BF.maxpool2d_train_hip(x, k, s_, p_)
+        ctx.save_for_backward(idx)
+        ctx.geom = (tuple(x.shape), k, s_, p_)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        shape, k, s_, p_ = ctx.geom
+        return BF.maxpool2d_bwd_hip(dy.contiguous(memory_format=torch.channels_last), idx, shape, k, s_, p_), None, None, None
+
+
+def max_pool_train(mp, x):
+    sq = lambda v: v if isinstance(v, int) else v[0]  # noqa: E731
+    return MaxPool2dTrainFn.apply(x, sq(mp.kernel_size), sq(mp.stride if mp.stride is not None else mp.kernel_size), sq(mp.padding))
+
+
 class GraphedTrainStep:
     """forward + loss + backward of `model` on a fixed batch, captured ONCE into a hipGraph and replayed per training step
     (reference README.md:114-125: `output = model(x); kl = get_kl_loss(model); loss = ce(output, y) + kl / batch_size;

@@ -394,6 +394,123 @@ __global__ __launch_bounds__(256) void maxpool2d_cl_kernel(const T* __restrict__
   }
 }
 
+// Training form (the reference's training loop runs nn.MaxPool2d under autograd: resnet_large.py self.maxpool): the same pass also
+// writes, per output element, the position kh * k + kw of its maximum inside the window — the FIRST maximum in scan order, as
+// torch's max_pool2d_with_indices picks it (`val > max || isnan(val)`: post-ReLU maps are full of ties at 0) — one byte instead of
+// ATen's int64 index; the backward routes dy with it.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2d_cl_idx_kernel(const T* __restrict__ x, T* __restrict__ out, uint8_t* __restrict__ idx,
+                                                               int NB, int H, int W, int C, int Ho, int Wo, int k, int s, int pad,
+                                                               long long total) {
+  const int cgs = C >> 3;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int cg = (int)(t % cgs);
+    long long r = t / cgs;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float m[8];
+    uint32_t id[8];
+    bool first = true;
+    for (int kh = 0; kh < k; ++kh) {
+      const int h = ho * s - pad + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int w = wo * s - pad + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const T* src = x + (((long long)n * H + h) * W + w) * C + cg * 8;
+        float v[8];
+        if constexpr (sizeof(T) == 2) {
+          const u32x4 q = *(const u32x4*)src;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[2 * j] = u2f(q[j] << 16); v[2 * j + 1] = u2f(q[j] & 0xffff0000u); }
+        } else {
+          const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = c[j]; }
+        }
+        const uint32_t pos = (uint32_t)(kh * k + kw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool take = first || v[j] > m[j] || v[j] != v[j];
+          m[j] = take ? v[j] : m[j];
+          id[j] = take ? pos : id[j];
+        }
+        first = false;
+      }
+    }
+    if (first) {  // a window entirely in the padding (2 * pad <= k rules it out; kept total)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; id[j] = 0u; }
+    }
+    T* dst = out + (((long long)n * Ho + ho) * Wo + wo) * C + cg * 8;
+    if constexpr (sizeof(T) == 2) {
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (f2u(m[2 * j]) >> 16) | (f2u(m[2 * j + 1]) & 0xffff0000u);  // exact: inputs are bf16
+      *(u32x4*)dst = o;
+    } else {
+      *(f32x4*)dst = (f32x4){m[0], m[1], m[2], m[3]};
+      *(f32x4*)(dst + 4) = (f32x4){m[4], m[5], m[6], m[7]};
+    }
+    u32x2 ib;
+    ib[0] = id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24);
+    ib[1] = id[4] | (id[5] << 8) | (id[6] << 16) | (id[7] << 24);
+    *(u32x2*)(idx + t * 8) = ib;
+  }
+}
+
+// dx[n][h][w][c] = sum of dy over the (at most ceil(k/s)^2) windows that cover (h, w) and whose recorded maximum sits there; f32
+// accumulation, one rounding (as ATen's max_pool_backward_nhwc).  A thread owns 8 channels of one INPUT pixel: no atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2d_cl_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                               T* __restrict__ dx, int NB, int H, int W, int C, int Ho, int Wo, int k,
+                                                               int s, int pad, long long total) {
+  const int cgs = C >> 3;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int cg = (int)(t % cgs);
+    long long r = t / cgs;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int th = h + pad - k + 1, tw = w + pad - k + 1;
+    const int ho_lo = th <= 0 ? 0 : (th + s - 1) / s, ho_hi = min(Ho - 1, (h + pad) / s);
+    const int wo_lo = tw <= 0 ? 0 : (tw + s - 1) / s, wo_hi = min(Wo - 1, (w + pad) / s);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      const int kh = h + pad - ho * s;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const uint32_t pos = (uint32_t)(kh * k + (w + pad - wo * s));
+        const long long o = (((long long)n * Ho + ho) * Wo + wo) * cgs + cg;
+        const u32x2 ib = *(const u32x2*)(idx + o * 8);
+        float g[8];
+        if constexpr (sizeof(T) == 2) {
+          const u32x4 q = *(const u32x4*)(dy + o * 8);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { g[2 * j] = u2f(q[j] << 16); g[2 * j + 1] = u2f(q[j] & 0xffff0000u); }
+        } else {
+          const f32x4 a = *(const f32x4*)(dy + o * 8), c = *(const f32x4*)(dy + o * 8 + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { g[j] = a[j]; g[4 + j] = c[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (((ib[j >> 2] >> (8 * (j & 3))) & 0xffu) == pos) ? g[j] : 0.f;
+      }
+    }
+    T* dst = dx + t * 8;
+    if constexpr (sizeof(T) == 2) {
+      *(u32x4*)dst = pack_granule<1>(acc);  // round to nearest even, as torch's float -> bfloat16
+    } else {
+      *(f32x4*)dst = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+      *(f32x4*)(dst + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+    }
+  }
+}
+
 
 // btx_avgpool_global_cl: global average pooling of channels-last activations ([NB][HW][C] -> [NB][C], f32 accumulate),
 // the op in front of the classifier of the reference's ResNets (resnet_large.py: avgpool).  One workgroup per image and
@@ -1540,6 +1657,52 @@ int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, 
   else if (dtype == BTX_ACT_F32)
     hipLaunchKernelGGL(maxpool2d_cl_kernel<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (float*)out, NB, H,
                        W, C, Ho, Wo, k, stride, pad, total);
+  else
+    return BTX_E_DTYPE;
+  return (int)hipGetLastError();
+}
+
+int btx_maxpool2d_cl_train(const void* x, void* out, uint8_t* idx, int dtype, int NB, int H, int W, int C, int k, int stride, int pad,
+                           void* stream) {
+  if (!x || !out || !idx) return BTX_E_NULL;
+  if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || 2 * pad > k) return BTX_E_SHAPE;
+  if (C % 8 || k > 15) return BTX_E_UNSUPPORTED;  // the window position must fit a byte
+  if ((((uintptr_t)x | (uintptr_t)out) & 15) || (((uintptr_t)idx) & 7)) return BTX_E_ALIGN;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return BTX_E_SHAPE;
+  const long long total = (long long)NB * Ho * Wo * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 262144) blocks = 262144;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == BTX_ACT_BF16)
+    hipLaunchKernelGGL(maxpool2d_cl_idx_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, (const __bf16*)x, (__bf16*)out, idx, NB, H, W,
+                       C, Ho, Wo, k, stride, pad, total);
+  else if (dtype == BTX_ACT_F32)
+    hipLaunchKernelGGL(maxpool2d_cl_idx_kernel<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)x, (float*)out, idx, NB, H, W, C,
+                       Ho, Wo, k, stride, pad, total);
+  else
+    return BTX_E_DTYPE;
+  return (int)hipGetLastError();
+}
+
+int btx_maxpool2d_cl_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int NB, int H, int W, int C, int k, int stride,
+                         int pad, void* stream) {
+  if (!dy || !idx || !dx) return BTX_E_NULL;
+  if (NB <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || 2 * pad > k) return BTX_E_SHAPE;
+  if (C % 8 || k > 15) return BTX_E_UNSUPPORTED;
+  if ((((uintptr_t)dy | (uintptr_t)dx) & 15) || (((uintptr_t)idx) & 7)) return BTX_E_ALIGN;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return BTX_E_SHAPE;
+  const long long total = (long long)NB * H * W * (C / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 262144) blocks = 262144;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == BTX_ACT_BF16)
+    hipLaunchKernelGGL(maxpool2d_cl_bwd_kernel<__bf16>, dim3((int)blocks), dim3(256), 0, st, (const __bf16*)dy, idx, (__bf16*)dx, NB, H, W,
+                       C, Ho, Wo, k, stride, pad, total);
+  else if (dtype == BTX_ACT_F32)
+    hipLaunchKernelGGL(maxpool2d_cl_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, st, (const float*)dy, idx, (float*)dx, NB, H, W, C,
+                       Ho, Wo, k, stride, pad, total);
   else
     return BTX_E_DTYPE;
   return (int)hipGetLastError();

@@ -807,6 +807,29 @@ def maxpool2d_hip(x, kernel, stride, padding):
     return out
 
 
+def maxpool2d_train_hip(x, kernel, stride, padding):
+    """(y, idx) of btx_maxpool2d_cl_train: max_pool2d of a channels-last CUDA tensor and, per output element, the window position of
+    its maximum (uint8 [N][Ho][Wo][C]) for maxpool2d_bwd_hip"""
+    L = _lib.lib()
+    n, c, h, w = x.shape
+    ho, wo = (h + 2 * padding - kernel) // stride + 1, (w + 2 * padding - kernel) // stride + 1
+    out = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    idx = torch.empty(n * ho * wo * c, dtype=torch.uint8, device=x.device)
+    _lib.check(L.btx_maxpool2d_cl_train(x.data_ptr(), out.data_ptr(), idx.data_ptr(), _lib.ACT_BF16 if x.dtype == torch.bfloat16 else _lib.ACT_F32,
+                                        n, h, w, c, kernel, stride, padding, torch.cuda.current_stream(x.device).cuda_stream))
+    return out, idx
+
+
+def maxpool2d_bwd_hip(dy, idx, x_shape, kernel, stride, padding):
+    """btx_maxpool2d_cl_bwd: the gradient of maxpool2d_train_hip's input (channels-last), dy channels-last"""
+    L = _lib.lib()
+    n, c, h, w = x_shape
+    dx = torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    _lib.check(L.btx_maxpool2d_cl_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), _lib.ACT_BF16 if dy.dtype == torch.bfloat16 else _lib.ACT_F32,
+                                      n, h, w, c, kernel, stride, padding, torch.cuda.current_stream(dy.device).cuda_stream))
+    return dx
+
+
 def avgpool_global_hip(x):
     """adaptive_avg_pool2d(x, 1).flatten(1) for channels-last CUDA tensors through btx_avgpool_global_cl (C % 8 == 0)"""
     L = _lib.lib()

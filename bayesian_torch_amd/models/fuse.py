@@ -183,7 +183,8 @@ def hip_batchnorm(model, fuse_act=True):
     models/deterministic/resnet_large.py:46-62, 85-105) also get their `relu(bn(.))` and
     `relu(bn(.) + identity)` inside the normalisation's launches while training on the GPU (one rounding instead of two or three;
     the ReLU's backward mask is a bit per element written by the forward).  Eval mode and CPU tensors keep the forward the block
-    had (the eval-mode folding of fuse_resnet included).  Returns the number of BatchNorm modules routed."""
+    had (the eval-mode folding of fuse_resnet included).  nn.MaxPool2d modules are routed the same way where a gradient is
+    needed (btx_maxpool2d_cl_train / _bwd).  Returns the number of BatchNorm modules routed."""
     from .. import autograd as _ag
     n = 0
     for m in model.modules():
@@ -197,6 +198,17 @@ def hip_batchnorm(model, fuse_act=True):
             object.__setattr__(m, "_btx_bn_orig", orig)
             m.forward = types.MethodType(fwd, m)
             n += 1
+        elif isinstance(m, nn.MaxPool2d) and "_btx_mp_orig" not in m.__dict__:
+            # the pooling layer behind the stem under autograd: btx_maxpool2d_cl_train / _bwd (a byte per output element instead of
+            # ATen's int64 indices); everything outside autograd.max_pool_train_usable keeps torch's op
+            orig_mp = m.forward
+
+            def fwd_mp(self, x, _orig=orig_mp):
+                if _ag.max_pool_train_usable(self, x):
+                    return _ag.max_pool_train(self, x)
+                return _orig(x)
+            object.__setattr__(m, "_btx_mp_orig", orig_mp)
+            m.forward = types.MethodType(fwd_mp, m)
     if fuse_act:
         for m in model.modules():
             if _plain_block(m) and "_btx_fwd_eval" not in m.__dict__:

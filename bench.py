@@ -791,7 +791,7 @@ def run_train_step(dev, steps=5):
     # each; the stem counted with its own 7x7x3 taps, not the padded row-fused geometry)
     gflop = 464.4 + (464.4 - 30.2) + 464.4
     return {"workload": "training step (README.md:114-125): dnn_to_bnn(ResNet18) Flipout bs64, bf16 activations, forward + "
-                        "CE + KL/B + backward through libbtx (bf16-MFMA weight gradients, HIP BatchNorm), one hipGraph replay per step (ms_per_step_eager: launched from Python)",
+                        "CE + KL/B + backward through libbtx (bf16-MFMA weight gradients through chunk slabs, HIP BatchNorm with the blocks' residual add + ReLU, HIP max-pool), one hipGraph replay per step (ms_per_step_eager: launched from Python)",
             "ms_per_step": ms, "ms_per_step_eager": ms_eager, "hipgraph": graphed, "achieved_tflops": gflop / ms,
             "loss_finite": loss_finite,
             "parity_vs_f32_mode": parity}

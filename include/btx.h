@@ -349,6 +349,15 @@ int btx_rowfuse_pack(const void* x, int in_dtype, const int64_t* strides_ncHW_ho
  * -> [NB][Ho][Wo][C], C % 8 == 0, 2*pad <= k; identical results to torch (max is exact). */
 int btx_maxpool2d_cl(const void* x, void* out, int dtype, int NB, int H, int W, int C, int k, int stride, int pad,
                      void* stream);
+/* The same under autograd (ABI 8; the reference's training loop runs self.maxpool with gradients enabled).  _train: also idx[NB][Ho][Wo][C]
+ * (uint8, 8-byte aligned) = kh * k + kw of each output element's maximum inside its window, the first maximum in scan order as
+ * torch.nn.functional.max_pool2d_with_indices picks it (k <= 15).  _bwd: dx[NB][H][W][C] from dy[NB][Ho][Wo][C] and idx — every
+ * input element sums dy over the windows whose recorded maximum it is (f32 accumulation, one rounding; no atomics, every element
+ * of dx is written).  Results equal torch's max_pool2d forward / backward bit for bit. */
+int btx_maxpool2d_cl_train(const void* x, void* out, uint8_t* idx, int dtype, int NB, int H, int W, int C, int k, int stride,
+                           int pad, void* stream);
+int btx_maxpool2d_cl_bwd(const void* dy, const uint8_t* idx, void* dx, int dtype, int NB, int H, int W, int C, int k, int stride,
+                         int pad, void* stream);
 
 /* §8(f)-4, the step either side of the path in the reference's TRAINING loop (README.md:114-125 on
  * models/deterministic/resnet_large.py:46-62: conv -> bn -> relu under model.train()): torch.nn.BatchNorm2d in training mode on

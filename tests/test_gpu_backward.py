@@ -719,3 +719,38 @@ def test_wgrad_workspace_too_small_is_refused():
     assert L.btx_contract_wgrad_ws(*args, ws.data_ptr(), need, None, None, st) == 0
     torch.cuda.synchronize()
     assert float(dw.abs().max()) == 0.0  # fully overwritten (x = dy = 0), no clearing needed
+
+
+@pytest.mark.parametrize("shape,dtype,k,s,p", [((64, 64, 112, 112), torch.bfloat16, 3, 2, 1), ((3, 16, 13, 17), torch.float32, 3, 2, 1),
+                                               ((2, 8, 9, 9), torch.float32, 2, 2, 0), ((2, 24, 10, 11), torch.bfloat16, 3, 1, 1),
+                                               ((2, 8, 12, 12), torch.float32, 5, 3, 2)])
+def test_hip_maxpool_under_autograd_equals_torch(shape, dtype, k, s, p):
+    """nn.MaxPool2d routed by hip_batchnorm(model) (btx_maxpool2d_cl_train / _bwd): outputs equal torch's exactly; the gradient goes
+    to the FIRST maximum of each window in scan order, as torch's does — post-ReLU maps (half the entries tie at 0) included"""
+    from bayesian_torch_amd.models.fuse import hip_batchnorm
+    from bayesian_torch_amd import autograd as ag
+    dev = _dev()
+    torch.manual_seed(3)
+    x = torch.relu(torch.randn(*shape, device=dev)).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy_shape = torch.nn.functional.max_pool2d(x[:1].float(), k, s, p).shape
+    dy = torch.randn((shape[0],) + tuple(dy_shape[1:]), device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    net = torch.nn.Sequential(torch.nn.MaxPool2d(k, s, p))
+    hip_batchnorm(net)
+    x1 = x.clone().requires_grad_(True)
+    assert ag.max_pool_train_usable(net[0], x1)
+    y = net(x1)
+    y.backward(dy)
+    x2 = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(x2, k, s, p)
+    yr.backward(dy)
+    assert y.shape == yr.shape and y.dtype == dtype and torch.equal(y, yr)
+    assert x1.grad.shape == x2.grad.shape and x1.grad.stride() == x.stride()
+    if dtype == torch.float32:
+        assert torch.allclose(x1.grad, x2.grad, rtol=1e-6, atol=1e-7)
+    else:
+        assert _rel(x1.grad, x2.grad) < 1e-3  # sums of up to (k/s)^2 bf16 values, rounded once: at most an ulp apart
+    assert float((x1.grad != 0).float().mean()) > 0.01
+    # no gradient wanted, NCHW storage, return_indices: torch's own op
+    assert not ag.max_pool_train_usable(net[0], x) and not ag.max_pool_train_usable(net[0], x.contiguous().requires_grad_(True))
+    with torch.no_grad():
+        assert torch.equal(net(x), yr.detach())

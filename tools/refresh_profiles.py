@@ -14,6 +14,8 @@ steps (each writes the files named in its docstring, with the command that produ
   persistent  profiles/<PREFIX>_persistent_kbench.txt                       persistent kernel A/B (tuning build)
   tall        profiles/<PREFIX>_tall_tiles_ab.txt                           tall-strip tiles A/B
   power       profiles/<PREFIX>_power_probe.txt                             socket power / clock under sustained launches
+  train       profiles/<PREFIX>_train_step_captured_trace.txt               kernel trace of the captured training step
+  wgrad       profiles/<PREFIX>_wgrad_bench.txt, _dgrad_bench.txt           weight-gradient paths / stride-2 data gradients per layer
 The measurement builds (build_variants/libbtx_{tune,trace,abl*}.so) are made by tools/build_variants.sh when missing.
 """
 import glob
@@ -76,7 +78,10 @@ def step_bench():
 def step_trace():
     # --steps / --warmup are multiples of the lane count (20 = the driver's --steps 20): every contract_taps_kernel launch of
     # the traced run carries the same number of MC sample lanes, so the trace's average IS the bench's avg_launch_us
-    for tag, extra in (("stats", ""), ("lanes1", " --lanes 1")):
+    tags = (("stats", ""), ("lanes1", " --lanes 1"))
+    if os.environ.get("BTX_TRACE_STATS_ONLY"):  # (a short GPU budget: the 20-lane trace only)
+        tags = tags[:1]
+    for tag, extra in tags:
         d = os.path.join(ROOT, "gpurun_out", "r4_kt_" + tag)
         shutil.rmtree(d, ignore_errors=True)
         cmd = "python %s/bench.py --steps 20 --warmup 20 --no-extras --no-cpu-baseline --no-traffic --no-sustain%s" % (ROOT, extra)
@@ -88,6 +93,32 @@ def step_trace():
               "%s" % (cmd.replace(ROOT + "/", ""), "lanes 1: one MC sample per launch — the dominant kernel's average here is a single-sample launch"
                       if extra else "the bench's default for --steps 20: 20 MC samples per launch (lanes), the per-launch timing replays included"), body)
         shutil.rmtree(d, ignore_errors=True)  # the raw trace (tens of MB) stays on the box: gpurun merges at most 64 MiB back
+
+
+def step_train():
+    """profiles/<PREFIX>_train_step_captured_trace.txt: per-kernel totals and one replay's kernel sequence of autograd.GraphedTrainStep"""
+    d = os.path.join(ROOT, "gpurun_out", "r5_train_trace")
+    shutil.rmtree(d, ignore_errors=True)
+    log = sh("rocprofv3 --kernel-trace -d %s -o t -- python %s/tools/train_profile.py --graph 20" % (d, ROOT), cwd="/tmp", timeout=400)
+    db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    body = sh("python tools/trace_report.py %s --sequence 420" % db[0]) if db else "(no trace written)\n"
+    rep = [l for l in log.splitlines() if "replays" in l]
+    write(PREFIX + "_train_step_captured_trace.txt",
+          "cd /tmp && rocprofv3 --kernel-trace -- python tools/train_profile.py --graph 20   (autograd.GraphedTrainStep on dnn_to_bnn(ResNet18) Flipout bs 64,\n"
+          "bf16, hip_batchnorm with fused residual / ReLU: 3 warm-up steps + 20 replays = 23 steps in the trace; %s under the profiler;\n"
+          "tools/trace_report.py: per-kernel totals, then the last 420 dispatches = one replay in launch order)" % (rep[-1].strip() if rep else "?"), body)
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def step_wgrad():
+    """profiles/<PREFIX>_wgrad_bench.txt, _dgrad_bench.txt: the weight-gradient paths and the stride-2 data gradients, layer by layer"""
+    lib = variant("tune", "-DBTX_TUNING")
+    write(PREFIX + "_wgrad_bench.txt", "BTX_LIB=build_variants/libbtx_tune.so python tools/wgrad_bench.py --ablate   (1 MI355X; columns: btx_contract_wgrad with f32\n"
+          "atomics | btx_contract_wgrad_ws on the tap-per-workgroup kernel | btx_contract_wgrad_ws as shipped (all-taps kernel on the 3x3/s1 rows))",
+          sh("python tools/wgrad_bench.py --ablate", env={"BTX_LIB": lib}, timeout=400))
+    write(PREFIX + "_dgrad_bench.txt", "BTX_LIB=build_variants/libbtx_tune.so python tools/dgrad_bench.py   (1 MI355X; autograd._data_grad_hip of the strided ResNet18\n"
+          "convolutions: transposed launch in raster order (BTX_NO_PAR_MAJOR=1) | parity-major order as shipped)",
+          sh("python tools/dgrad_bench.py", env={"BTX_LIB": lib}, timeout=300))
 
 
 def derived(rep):
