@@ -98,7 +98,9 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform
 // even compiled: the generic instantiation keeps ~40 launch parameters alive across its K loop, which hipcc spills into VGPR
 // lanes (733 v_readlane + 180 v_writelane in the bf16 Flipout kernel's ISA); this one reads seven.  Same arithmetic, same
 // order: bit-identical to the generic form (tests/test_gpu_contract.py).
-template <int PREC, int KIND, int NW, bool PW = false>
+// TR: transposed launches (the gather rule, its per-tap cache and the parity-major order) are an instantiation of their own — the
+// plain one keeps none of that state alive across its K loop (SGPR spills 280 -> see DESIGN.md section 5)
+template <int PREC, int KIND, int NW, bool PW = false, bool TR = false>
 __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const ContractParams) {
   BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   using LD = DmaLds<NW>;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   bool par = false;
   int tile_m0 = mtile * TP;        // first (logical) pixel of the tile
   int par_nvalid = 0;              // parity-major: pixels of the tile that exist (the class's last tile is padded)
-  if constexpr (!PW) {
+  if constexpr (!PW && TR) {
     if (p.par_major) {
       // tile t: class t & 3, tile t >> 2 of that class (classes alternate: every XCD's range of tiles holds all four, the classes'
       // unequal stage counts even out); logical pixel = class * par_Mqp + q, q < par_Mq the class's raster index
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     }
     const int ow = (int)uow, oh = (int)uoh, od = (int)uod, nb = (int)unb;
     nbase_ = nb * p.D;
-    if (!p.transposed) {
+    if (!TR) {
       bd_ = od * p.sd - p.pd; bh_ = oh * p.sh - p.ph; bw_ = ow * p.sw - p.pw;
     } else {
       bd_ = od + p.pd; bh_ = oh + p.ph; bw_ = ow + p.pw;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
   }
   // tap validity, one bitmask per axis and pixel (bit k: tap k of that axis reads inside the input), computed once per
   // workgroup with KD + KH + KW iterations; a tap is valid iff its three bits are set
-  const bool use_mask = !PW && (p.KD <= 32) && (p.KH <= 32) && (p.KW <= 32) && !p.transposed;  // uniform
+  const bool use_mask = !PW && (p.KD <= 32) && (p.KH <= 32) && (p.KW <= 32) && !TR;  // uniform
   uint32_t md[4] = {0u, 0u, 0u, 0u}, mh[4] = {0u, 0u, 0u, 0u}, mw[4] = {0u, 0u, 0u, 0u};
   if constexpr (PW) {
   } else if (pointwise) {
@@ -295,12 +297,12 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     // activations: one tap for the whole stage; tap_off is wave-uniform
     uint32_t tap_off = 0;
     if constexpr (PW) tap_off = (uint32_t)s_c;
-    else if (!p.transposed)
+    else if (!TR)
       tap_off = (uint32_t)(((s_kd * p.dd) * p.H + s_kh * p.dh) * p.W + s_kw * p.dw) * (uint32_t)p.C + (uint32_t)s_c;
     const uint32_t tap_boff = tap_off * (uint32_t)sizeof(ACT);
     unsigned char* as = smem + DA_OFF + a_slot_issue * DA_STAGE + wave * 4096;
     if constexpr (!PW) {
-      if (p.transposed && tp_tap != s_tap) {  // wave-uniform: a new tap
+      if (TR && tp_tap != s_tap) {  // wave-uniform: a new tap
         tp_tap = s_tap;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
       } else if (use_mask) {
         ok = ((md[q] >> s_kd) & (mh[q] >> s_kh) & (mw[q] >> s_kw) & 1u) != 0u;
         bo = pb_boff[q] + tap_boff;
-      } else if (!p.transposed) {
+      } else if (!TR) {
         const int id = pb_d[q] + s_kd * p.dd, ih = pb_h[q] + s_kh * p.dh, iw = pb_w[q] + s_kw * p.dw;
         ok = pb_ok[q] && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         bo = pb_boff[q] + tap_boff;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
       // one hashed word covers the 32 (bf16) / 16 (f32) channels of pixel `tid`'s stage.  (In the padding the
       // activations are zero, so the word is irrelevant there.  Transposed: recompute the input offset.)
       uint32_t off = sg_off + tap_off;
-      if (!PW && p.transposed) off = tp_sg + (uint32_t)s_c;
+      if (!PW && TR) off = tp_sg + (uint32_t)s_c;
       // sign layout: element pair e>>1 sits at bit 15-(e>>1) (even e) / 31-(e>>1) (odd e) of its word, so a stage that
       // starts at element offset e0 inside the word needs the word shifted left by e0>>1 within each 16-bit half
       const uint32_t n_in = p.x_bytes / (uint32_t)sizeof(ACT);
@@ -471,9 +473,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
     tr_ab = ep_t[0] - tr_t2; tr_bc = ep_t[1] - ep_t[0];
 #else
     bool par_ep = false;
-    if constexpr (!PW) par_ep = pe.par_major != 0;
+    if constexpr (!PW && TR) par_ep = pe.par_major != 0;
     if (par_ep) {
-      if constexpr (!PW) {
+      if constexpr (!PW && TR) {
         const PixParity pm = {pe, m0, nvalid};
         staged_epilogue_pm<KIND, NW, PixParity, false>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pm);
       }
@@ -503,9 +505,9 @@ __global__ __launch_bounds__(64 * NW, 2) void contract_dma_kernel(const Contract
 
 template <int PREC>
 static int launch_contract_dma_impl(int kind, const ContractParams& p, int nwg, hipStream_t st) {
-#define BTX_LAUNCH_DMA(KIND, NW, PW)                                                                                    \
+#define BTX_LAUNCH_DMA(KIND, NW, PW, TR)                                                                                \
   do {                                                                                                                  \
-    auto kfn = contract_dma_kernel<PREC, KIND, NW, PW>;                                                                 \
+    auto kfn = contract_dma_kernel<PREC, KIND, NW, PW, TR>;                                                             \
     static bool attr_done = false;                                                                                      \
     if (!attr_done) {                                                                                                   \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, DmaLds<NW>::BYTES); \
@@ -518,9 +520,11 @@ static int launch_contract_dma_impl(int kind, const ContractParams& p, int nwg, 
   if (rc) return rc;
   // the pointwise form where its contract holds (two workgroups per CU: the shapes that are all prologue and store side)
   const bool pw = p.pointwise && !p.transposed && !p.sign_unaligned && p.pt_nw == 4 && !p.pt_nopw;
-  if (pw) { if (kind == 0) BTX_LAUNCH_DMA(0, 4, true); else BTX_LAUNCH_DMA(1, 4, true); }
-  else if (p.pt_nw == 4) { if (kind == 0) BTX_LAUNCH_DMA(0, 4, false); else BTX_LAUNCH_DMA(1, 4, false); }
-  else { if (kind == 0) BTX_LAUNCH_DMA(0, 8, false); else BTX_LAUNCH_DMA(1, 8, false); }
+  if (pw) { if (kind == 0) BTX_LAUNCH_DMA(0, 4, true, false); else BTX_LAUNCH_DMA(1, 4, true, false); }
+  else if (p.pt_nw == 4 && p.transposed) { if (kind == 0) BTX_LAUNCH_DMA(0, 4, false, true); else BTX_LAUNCH_DMA(1, 4, false, true); }
+  else if (p.pt_nw == 4) { if (kind == 0) BTX_LAUNCH_DMA(0, 4, false, false); else BTX_LAUNCH_DMA(1, 4, false, false); }
+  else if (p.transposed) { if (kind == 0) BTX_LAUNCH_DMA(0, 8, false, true); else BTX_LAUNCH_DMA(1, 8, false, true); }
+  else { if (kind == 0) BTX_LAUNCH_DMA(0, 8, false, false); else BTX_LAUNCH_DMA(1, 8, false, false); }
 #undef BTX_LAUNCH_DMA
   return (int)hipGetLastError();
 }

@@ -51,7 +51,7 @@ def variant(name, flags):
 
 
 def step_bench():
-    out = sh("python bench.py --steps 20 --warmup 5", timeout=2400)  # the driver's invocation
+    out = sh("timeout -k 5 600 python bench.py --steps 20 --warmup 5", timeout=2400)  # the driver's invocation
     line = [l for l in out.splitlines() if l.startswith("{")][-1]  # the compact line (<= 6 KB), LAST on stdout
     c = json.loads(line)
     os.makedirs(OUT, exist_ok=True)
@@ -85,7 +85,7 @@ def step_trace():
         d = os.path.join(ROOT, "gpurun_out", "r4_kt_" + tag)
         shutil.rmtree(d, ignore_errors=True)
         cmd = "python %s/bench.py --steps 20 --warmup 20 --no-extras --no-cpu-baseline --no-traffic --no-sustain%s" % (ROOT, extra)
-        sh("rocprofv3 --kernel-trace --stats -d %s -o kt -- %s" % (d, cmd), cwd="/tmp", timeout=1200)
+        sh("timeout -k 5 400 rocprofv3 --kernel-trace --stats -d %s -o kt -- %s" % (d, cmd), cwd="/tmp", timeout=1200)
         db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
         body = sh("python tools/trace_report.py %s" % db[0]) if db else "(no trace written)\n"
         write(PREFIX + "_bench_kernel_trace_%s.txt" % tag,
@@ -99,7 +99,7 @@ def step_train():
     """profiles/<PREFIX>_train_step_captured_trace.txt: per-kernel totals and one replay's kernel sequence of autograd.GraphedTrainStep"""
     d = os.path.join(ROOT, "gpurun_out", "r5_train_trace")
     shutil.rmtree(d, ignore_errors=True)
-    log = sh("rocprofv3 --kernel-trace -d %s -o t -- python %s/tools/train_profile.py --graph 20" % (d, ROOT), cwd="/tmp", timeout=400)
+    log = sh("timeout -k 5 240 rocprofv3 --kernel-trace -d %s -o t -- python %s/tools/train_profile.py --graph 20" % (d, ROOT), cwd="/tmp", timeout=400)
     db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
     body = sh("python tools/trace_report.py %s --sequence 420" % db[0]) if db else "(no trace written)\n"
     rep = [l for l in log.splitlines() if "replays" in l]
