@@ -51,6 +51,8 @@ struct WgradParams {
   uint32_t seed_lo, seed_hi, layer;
   int swap;
   int tune;     // measurement builds (BTX_WGRAD_T3_ABL): 1 = no slab stores, 2 = no MFMA section (results wrong: time only)
+  int pair, Tw; // pair: a tap has 32 channels (row-fused stems) — a workgroup takes TWO taps, one per 32-column half of its x tile, and
+                // shares the dy tile between them (Tw = workgroups along the tap axis: ceil(T / 2), else T)
   int direct;   // slab mode with ONE chunk: its sums are the result — plain stores straight into dW, no reduction launch
   float* slab;  // btx_contract_wgrad_ws: [chunk][mean | delta][N*K] partial sums, plain stores (nullptr: f32 atomics into dW)
   FastDiv fd_Wo, fd_Ho, fd_Do, fd_T, fd_ctiles, fd_ntiles, fd_groups;
@@ -86,18 +88,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
 
   uint32_t u, u_chunk, u_tap, u_ct, u_nt, u_g;
-  fdivmod(blockIdx.x, p.fd_T, (uint32_t)p.T, u, u_tap);
+  fdivmod(blockIdx.x, p.fd_T, (uint32_t)p.Tw, u, u_tap);
   fdivmod(u, p.fd_ctiles, (uint32_t)p.ctiles, u, u_ct);
   fdivmod(u, p.fd_ntiles, (uint32_t)p.ntiles, u, u_nt);
   fdivmod(u, p.fd_groups, (uint32_t)p.groups, u_chunk, u_g);
-  const int tap = (int)u_tap, ct = (int)u_ct, nt = (int)u_nt, grp = (int)u_g, chunk = (int)u_chunk;
-  const int kw = tap % p.KW, kh = (tap / p.KW) % p.KH, kd = tap / (p.KW * p.KH);
+  const bool pair = FAST && p.pair != 0;
+  const int tap = pair ? 2 * (int)u_tap : (int)u_tap, ct = (int)u_ct, nt = (int)u_nt, grp = (int)u_g, chunk = (int)u_chunk;
   const int m_begin = chunk * p.chunk_px, m_end = min(p.M, m_begin + p.chunk_px);
   const bool do_bias = (tap == 0) && (ct == 0) && (p.dbm != nullptr);
-  const int ni_live = (p.Ng - nt * 64 > 32) ? 2 : 1, nj_live = (p.Cg - ct * 64 > 32) ? 2 : 1;
+  const int ni_live = (p.Ng - nt * 64 > 32) ? 2 : 1, nj_live = pair ? 2 : ((p.Cg - ct * 64 > 32) ? 2 : 1);
 
   // staging role: thread t loads 16 consecutive channels of pixel (t >> 2) of each tile: quarter q = t & 3
   const int s_px = tid >> 2, s_q = tid & 3;
+  // the tap and the channel run this thread stages of x (pair: quarters 0-1 = tap, quarters 2-3 = tap + 1, 32 channels each)
+  const int tapx = pair ? tap + (s_q >> 1) : tap;
+  const int xc0 = pair ? 16 * (s_q & 1) : ct * 64 + 16 * s_q;
+  const bool tapx_ok = tapx < p.T;
+  const int kw = tapx % p.KW, kh = (tapx / p.KW) % p.KH, kd = tapx / (p.KW * p.KH);
   f32x16 acc_m[2][2], acc_d[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -126,10 +133,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     fdivmod(t1, p.fd_Do, (uint32_t)p.Do, unb, uod);
     const int id = (int)uod * p.sd - p.pd + kd * p.dd, ih = (int)uoh * p.sh - p.ph + kh * p.dh,
               iw = (int)uow * p.sw - p.pw + kw * p.dw;
-    const bool in_ok = pix_ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W &&
-                       (ct * 64 + 16 * s_q < p.Cg);
+    const bool in_ok = pix_ok && tapx_ok && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W &&
+                       (xc0 < p.Cg);
     const bool out_ok = pix_ok && (nt * 64 + 16 * s_q < p.Ng);
-    const long long xo = ((((long long)unb * p.D + id) * p.H + ih) * p.W + iw) * p.C + grp * p.Cg + ct * 64 + 16 * s_q;
+    const long long xo = ((((long long)unb * p.D + id) * p.H + ih) * p.W + iw) * p.C + grp * p.Cg + xc0;
     const long long yo = (long long)m * p.N + grp * p.Ng + nt * 64 + 16 * s_q;
     const u32x4 z = {0u, 0u, 0u, 0u};
     const u32x4* yp = (const u32x4*)((const uint16_t*)p.dy + (out_ok ? yo : 0));
@@ -399,9 +406,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     for (int e = tid; e < 64 * 64; e += 256) {
       const int n = e >> 6, c = e & 63;
       const float v = red[e] + red[4096 + e] + red[8192 + e] + red[12288 + e];
-      const int ng = nt * 64 + n, cg = ct * 64 + c;
-      if (ng < p.Ng && cg < p.Cg) {
-        const size_t e = ((size_t)(grp * p.Ng + ng) * p.T + tap) * p.Cg + cg;
+      const int ng = nt * 64 + n;
+      const int tapc = pair ? tap + (c >> 5) : tap, cg = pair ? (c & 31) : ct * 64 + c;  // pair: column half -> tap
+      if (ng < p.Ng && cg < p.Cg && tapc < p.T) {
+        const size_t e = ((size_t)(grp * p.Ng + ng) * p.T + tapc) * p.Cg + cg;
         if (p.direct) dst[e] = v;
         else if (p.slab) p.slab[((size_t)chunk * (KIND == 1 ? 2 : 1) + which) * slab_e + e] = v;  // this chunk's slab: a plain store
         else atomicAdd(dst + e, v);
@@ -611,6 +619,7 @@ long long wgrad_target_wgs(bool slab) {
   const char* e = wg_tune_env(slab ? "BTX_WGRAD_SLAB_WGS" : "BTX_WGRAD_WGS");
   return e ? atoll(e) : (slab ? 512 : 2048);  // slabs: two 4-wave workgroups per CU
 }
+bool wgrad_pair_geom() { return wg_tune_env("BTX_WGRAD_NO_PAIR") == nullptr; }
 long long wgrad_taps3_target_wgs() {
   const char* e = wg_tune_env("BTX_WGRAD_T3_WGS");
   return e ? atoll(e) : 256;  // one 12-wave workgroup per CU
@@ -670,7 +679,15 @@ int wgrad_impl(int kind, const BtxGeom* g, const void* x, const void* dy, float*
   if (slab && (((uintptr_t)ws) & 15)) return BTX_E_ALIGN;
   p.slab = slab ? (float*)ws : nullptr;
   const bool taps3 = slab && wgrad_taps3_geom(p, act_dtype) && wgrad_taps3_ok(p, act_dtype, db_mu != nullptr);
-  const long long base = taps3 ? (long long)p.ntiles * p.ctiles : (long long)p.groups * p.ntiles * p.ctiles * p.T;
+  // bf16 fast path (the shapes of a ResNet body and its row-fused stem): whole 16-channel runs, x runs at multiples of 4
+  // elements (8-byte loads) or 16 (16-byte loads), hashed signs, 16-byte aligned tensors
+  const bool fast_ok = act_dtype == BTX_ACT_BF16 && (p.C % 4 == 0) && (p.Cg % 16 == 0) && (p.N % 16 == 0) && (p.Ng % 16 == 0) &&
+                       !p.sign_in && !p.sign_out && ((((uintptr_t)x) | ((uintptr_t)dy)) % 16 == 0);
+  // a tap of 32 channels (row-fused 7x7x3 stems: 8 columns x 4 channels) fills half of the 64-column x tile: two taps per workgroup,
+  // one dy tile for both (the kernel is bound by its loads per MFMA; profiles/r05_experiments.txt E16)
+  p.pair = (!taps3 && fast_ok && p.Cg == 32 && p.T >= 2 && wgrad_pair_geom()) ? 1 : 0;
+  p.Tw = p.pair ? (p.T + 1) / 2 : p.T;
+  const long long base = taps3 ? (long long)p.ntiles * p.ctiles : (long long)p.groups * p.ntiles * p.ctiles * p.Tw;
   long long chunks, cpx;
   wgrad_chunks(base, M, taps3 ? wgrad_taps3_target_wgs() : wgrad_target_wgs(slab), slab, &chunks, &cpx);
   p.chunks = (int)chunks; p.chunk_px = (int)cpx;
@@ -684,7 +701,7 @@ int wgrad_impl(int kind, const BtxGeom* g, const void* x, const void* dy, float*
   p.swap = swap ? 1 : 0;
   { const char* tn = wg_tune_env("BTX_WGRAD_T3_ABL"); p.tune = tn ? atoi(tn) : 0; }
   p.fd_Wo = make_fastdiv((uint32_t)p.Wo); p.fd_Ho = make_fastdiv((uint32_t)p.Ho); p.fd_Do = make_fastdiv((uint32_t)p.Do);
-  p.fd_T = make_fastdiv((uint32_t)p.T); p.fd_ctiles = make_fastdiv((uint32_t)p.ctiles);
+  p.fd_T = make_fastdiv((uint32_t)p.Tw); p.fd_ctiles = make_fastdiv((uint32_t)p.ctiles);
   p.fd_ntiles = make_fastdiv((uint32_t)p.ntiles); p.fd_groups = make_fastdiv((uint32_t)p.groups);
   hipStream_t st = (hipStream_t)stream;
   const size_t wbytes = E * sizeof(float);
@@ -717,10 +734,6 @@ int wgrad_impl(int kind, const BtxGeom* g, const void* x, const void* dy, float*
   } else {
   const int lds = (kind == BTX_KIND_FLIPOUT ? 4 : 2) * WG_TILE;
   const int lds_need = lds > 65536 ? lds : 65536;  // the cross-wave reduction uses 64 KiB
-  // bf16 fast path (the shapes of a ResNet body and its row-fused stem): whole 16-channel runs, x runs at multiples of 4
-  // elements (8-byte loads) or 16 (16-byte loads), hashed signs, 16-byte aligned tensors
-  const bool fast_ok = act_dtype == BTX_ACT_BF16 && (p.C % 4 == 0) && (p.Cg % 16 == 0) && (p.N % 16 == 0) && (p.Ng % 16 == 0) &&
-                       !p.sign_in && !p.sign_out && ((((uintptr_t)x) | ((uintptr_t)dy)) % 16 == 0);
 #define BTX_LAUNCH_WG(ACT, KIND, FAST)                                                                              \
   do {                                                                                                            \
     auto kfn = wgrad_kernel<ACT, KIND, FAST>;                                                                      \
@@ -790,6 +803,10 @@ extern "C" size_t btx_wgrad_workspace_bytes(int kind, const BtxGeom* g, int act_
   long long chunks, cpx;
   wgrad_chunks((long long)p.groups * p.ntiles * p.ctiles * p.T, p.M, wgrad_target_wgs(true), true, &chunks, &cpx);
   long long most = chunks;
+  if (p.Cg == 32 && p.T >= 2) {  // the two-taps-per-workgroup form (alignment decides at launch: the size covers both)
+    wgrad_chunks((long long)p.groups * p.ntiles * p.ctiles * ((p.T + 1) / 2), p.M, wgrad_target_wgs(true), true, &chunks, &cpx);
+    if (chunks > most) most = chunks;
+  }
   if (wgrad_taps3_geom(p, act_dtype)) {
     wgrad_chunks((long long)p.ntiles * p.ctiles, p.M, wgrad_taps3_target_wgs(), true, &chunks, &cpx);
     if (chunks > most) most = chunks;
