@@ -284,6 +284,8 @@ def _act_code(dt):
 def bn_train_usable(bn, x):
     """True when nn.BatchNorm{1,2,3}d `bn` in training mode on `x` can take the HIP kernels: CUDA tensor, f32 / bf16,
     channels-last storage (or 2-D [M, C]), C % 8 == 0, parameters and running estimates of one dtype (f32 or bf16)."""
+    if type(bn) not in (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d):
+        return False  # nn.SyncBatchNorm reduces its statistics across ranks, Lazy* variants have no parameters yet: torch's own path
     if not (bn.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.dim() in (2, 4, 5)):
         return False
     C = x.shape[1]
@@ -341,6 +343,7 @@ class BatchNormTrainFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable  # first-order only: create_graph=True raises instead of returning constants
     def backward(ctx, dy):
         L = _lib.lib()
         x, w, save_mean, save_invstd, mask = ctx.saved_tensors
@@ -433,6 +436,7 @@ class MaxPool2dTrainFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable  # first-order only: create_graph=True raises instead of returning constants
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         shape, k, s_, p_ = ctx.geom
@@ -487,6 +491,9 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._step()
+        # the graph writes its gradients into these pool tensors on every replay; `optimizer.zero_grad()` (set_to_none=True by
+        # default) between replays detaches them from the parameters, so run() attaches them again
+        self._grads = [(p_, p_.grad) for p_ in model.parameters() if p_.grad is not None]
 
     def _step(self):
         for p_ in self.model.parameters():
@@ -502,6 +509,9 @@ class GraphedTrainStep:
     def run(self, sample_idx):
         self.sample_dev.fill_(int(sample_idx) & 0x7FFFFFFF)
         self.graph.replay()
+        for p_, g_ in self._grads:
+            if p_.grad is not g_:
+                p_.grad = g_
         return self.loss
 
     def close(self):

@@ -1735,25 +1735,31 @@ int btx_mc_accumulate_lanes(const void* logits, int lanes, int bs, int C, int ac
   if (!logits || !packed) return BTX_E_NULL;
   if (bs <= 0 || C <= 0 || lanes <= 0) return BTX_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  // lanes per LDS chunk: up to 96 KiB of probabilities (the default dynamic-LDS limit needs no opt-in below 64 KiB; above it
-  // the attribute is set once per instantiation)
+  // lanes per LDS chunk: up to 96 KiB of probabilities.  Above the 64 KiB every kernel may use, the limit is an opt-in per
+  // function AND per device: asked for once per device, and a device that refuses keeps 64 KiB chunks.
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  const bool f32 = act_dtype == BTX_ACT_F32;
+  if (!f32 && act_dtype != BTX_ACT_BF16) return BTX_E_DTYPE;
+  static unsigned char big_lds[2][64];  // 0 not asked yet, 1 granted, 2 refused
+  unsigned char& st_big = big_lds[f32 ? 0 : 1][dev];
+  if (!st_big) {
+    const void* fn = f32 ? (const void*)mc_accumulate_kernel<float> : (const void*)mc_accumulate_kernel<__bf16>;
+    st_big = (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 98304 + 64) == hipSuccess) ? 1 : 2;
+    if (st_big == 2) (void)hipGetLastError();
+  }
+  const size_t chunk = (st_big == 1) ? (size_t)98304 : (size_t)65536;
   const size_t per_lane = (size_t)C * 4 + 4;
-  int LC = (int)((size_t)98304 / per_lane);
-  if (LC < 1) return BTX_E_UNSUPPORTED;  // a row of > 24 575 classes does not fit a chunk
+  int LC = (int)(chunk / per_lane);
+  if (LC < 1) return BTX_E_UNSUPPORTED;  // a row of > 24 575 classes does not fit a chunk (include/btx.h K6)
   if (LC > lanes) LC = lanes;
   const size_t lds = (size_t)LC * per_lane;
-  if (act_dtype == BTX_ACT_F32) {
-    static bool attr_f = false;
-    if (!attr_f) { (void)hipFuncSetAttribute((const void*)mc_accumulate_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304 + 64); attr_f = true; }
+  if (f32)
     hipLaunchKernelGGL(mc_accumulate_kernel<float>, dim3(bs), dim3(1024), lds, st, (const float*)logits, bs, C, kl, packed,
                        lanes, LC);
-  } else if (act_dtype == BTX_ACT_BF16) {
-    static bool attr_b = false;
-    if (!attr_b) { (void)hipFuncSetAttribute((const void*)mc_accumulate_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304 + 64); attr_b = true; }
+  else
     hipLaunchKernelGGL(mc_accumulate_kernel<__bf16>, dim3(bs), dim3(1024), lds, st, (const __bf16*)logits, bs, C, kl,
                        packed, lanes, LC);
-  } else
-    return BTX_E_DTYPE;
   return (int)hipGetLastError();
 }
 

@@ -25,10 +25,25 @@ def packed_numel(bs, num_classes):
     return 2 * bs * num_classes + bs + 2
 
 
+MC_MAX_CLASSES = 24575  # btx_mc_accumulate[_lanes] keeps a row of probabilities in LDS (include/btx.h K6)
+
+
+def _accumulate_torch(packed, logits, kl):
+    """the same statistics with torch ops on the tensor's own device: CPU tensors, and GPU rows wider than MC_MAX_CLASSES"""
+    bs, C = logits.shape
+    p = torch.softmax(logits.float(), dim=1)
+    packed[:bs * C] += p.reshape(-1)
+    packed[bs * C:2 * bs * C] += (p * p).reshape(-1)
+    packed[2 * bs * C:2 * bs * C + bs] += -(p * torch.log(p + 1e-15)).sum(dim=1)
+    packed[2 * bs * C + bs] += float(kl)
+    packed[2 * bs * C + bs + 1] += 1.0
+    return packed
+
+
 def accumulate(packed, logits, kl=0.0):
     """packed += statistics of one MC sample's logits [bs, C] (in place)."""
     bs, C = logits.shape
-    if logits.is_cuda:
+    if logits.is_cuda and C <= MC_MAX_CLASSES:
         lg = logits.contiguous()
         if lg.dtype == torch.float32:
             act = _lib.ACT_F32
@@ -40,13 +55,7 @@ def accumulate(packed, logits, kl=0.0):
                                           torch.cuda.current_stream(lg.device).cuda_stream)
         _lib.check(rc)
         return packed
-    p = torch.softmax(logits.float(), dim=1)
-    packed[:bs * C] += p.reshape(-1)
-    packed[bs * C:2 * bs * C] += (p * p).reshape(-1)
-    packed[2 * bs * C:2 * bs * C + bs] += -(p * torch.log(p + 1e-15)).sum(dim=1)
-    packed[2 * bs * C + bs] += float(kl)
-    packed[2 * bs * C + bs + 1] += 1.0
-    return packed
+    return _accumulate_torch(packed, logits, kl)
 
 
 def accumulate_lanes(packed, logits, lanes, kl=0.0):
@@ -55,7 +64,8 @@ def accumulate_lanes(packed, logits, lanes, kl=0.0):
     result equals `lanes` accumulate() calls bit for bit)."""
     lanes = int(lanes)
     bs = logits.shape[0] // lanes
-    if lanes == 1 or not logits.is_cuda or logits.dtype not in (torch.float32, torch.bfloat16):
+    if (lanes == 1 or not logits.is_cuda or logits.dtype not in (torch.float32, torch.bfloat16)
+            or logits.shape[1] > MC_MAX_CLASSES):
         for k in range(lanes):
             accumulate(packed, logits[k * bs:(k + 1) * bs], kl)
         return packed

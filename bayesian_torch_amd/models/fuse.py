@@ -162,6 +162,51 @@ def _bottleneck_forward_train(self, x):
 
 
 _KNOWN = ("bayesian_torch_amd.models.resnet", "torchvision.models.resnet")
+_BN_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
+
+
+class _Bound:
+    """`fn(module, ...)` as the module's instance-level `forward`.  Unlike a closure holding the ORIGINAL module's bound forward,
+    copy.deepcopy gives the copy a _Bound on the COPY (an EMA / AveragedModel copy normalising with the original's weights and
+    updating the original's running estimates was the bug), and unlike types.MethodType of a module-level function it pickles
+    (torch.save(model)): `fn` goes by reference, the module through the pickler's memo."""
+    __slots__ = ("fn", "__self__")
+
+    def __init__(self, fn, module):
+        self.fn, self.__self__ = fn, module
+
+    def __call__(self, *a, **k):
+        return self.fn(self.__self__, *a, **k)
+
+    def __getstate__(self):
+        return (self.fn, self.__self__)
+
+    def __setstate__(self, st):
+        self.fn, self.__self__ = st
+
+
+# The fallback of both is the CLASS's forward on this very module.
+def _bn_forward(self, x):
+    from .. import autograd as _ag
+    if _ag.bn_train_usable(self, x):
+        return _ag.batch_norm_train(self, x)
+    return type(self).forward(self, x)
+
+
+def _mp_forward(self, x):
+    from .. import autograd as _ag
+    if _ag.max_pool_train_usable(self, x):
+        return _ag.max_pool_train(self, x)
+    return type(self).forward(self, x)
+
+
+def _resnet_forward_train(self, x):
+    if not (self.training and x.is_cuda):
+        return self._btx_fwd_eval(x)
+    from .. import autograd as _ag
+    x = self.maxpool(_ag.bn_act(self.bn1, self.conv1(x)))
+    x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+    return self.fc(self.avgpool(x).flatten(1))
 
 
 def _plain_block(m):
@@ -185,30 +230,19 @@ def hip_batchnorm(model, fuse_act=True):
     the ReLU's backward mask is a bit per element written by the forward).  Eval mode and CPU tensors keep the forward the block
     had (the eval-mode folding of fuse_resnet included).  nn.MaxPool2d modules are routed the same way where a gradient is
     needed (btx_maxpool2d_cl_train / _bwd).  Returns the number of BatchNorm modules routed."""
-    from .. import autograd as _ag
     n = 0
     for m in model.modules():
-        if isinstance(m, nn.modules.batchnorm._BatchNorm) and "_btx_bn_orig" not in m.__dict__:
-            orig = m.forward
-
-            def fwd(self, x, _orig=orig):
-                if _ag.bn_train_usable(self, x):
-                    return _ag.batch_norm_train(self, x)
-                return _orig(x)
-            object.__setattr__(m, "_btx_bn_orig", orig)
-            m.forward = types.MethodType(fwd, m)
+        if type(m) in _BN_TYPES and "_btx_bn_orig" not in m.__dict__:
+            # exact nn.BatchNorm{1,2,3}d only: nn.SyncBatchNorm (cross-rank statistics) and the Lazy* variants (parameters
+            # that do not exist yet) are _BatchNorm subclasses too and keep torch's own forward
+            object.__setattr__(m, "_btx_bn_orig", True)
+            m.forward = _Bound(_bn_forward, m)
             n += 1
-        elif isinstance(m, nn.MaxPool2d) and "_btx_mp_orig" not in m.__dict__:
+        elif type(m) is nn.MaxPool2d and "_btx_mp_orig" not in m.__dict__:
             # the pooling layer behind the stem under autograd: btx_maxpool2d_cl_train / _bwd (a byte per output element instead of
             # ATen's int64 indices); everything outside autograd.max_pool_train_usable keeps torch's op
-            orig_mp = m.forward
-
-            def fwd_mp(self, x, _orig=orig_mp):
-                if _ag.max_pool_train_usable(self, x):
-                    return _ag.max_pool_train(self, x)
-                return _orig(x)
-            object.__setattr__(m, "_btx_mp_orig", orig_mp)
-            m.forward = types.MethodType(fwd_mp, m)
+            object.__setattr__(m, "_btx_mp_orig", True)
+            m.forward = _Bound(_mp_forward, m)
     if fuse_act:
         for m in model.modules():
             if _plain_block(m) and "_btx_fwd_eval" not in m.__dict__:
@@ -218,12 +252,5 @@ def hip_batchnorm(model, fuse_act=True):
         if (type(model).__module__ in _KNOWN and type(model).__name__ == "ResNet" and isinstance(getattr(model, "relu", None), nn.ReLU)
                 and "_btx_fwd_eval" not in model.__dict__):
             object.__setattr__(model, "_btx_fwd_eval", model.forward)
-
-            def stem_fwd(self, x):
-                if not (self.training and x.is_cuda):
-                    return self._btx_fwd_eval(x)
-                x = self.maxpool(_ag.bn_act(self.bn1, self.conv1(x)))
-                x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-                return self.fc(self.avgpool(x).flatten(1))
-            model.forward = types.MethodType(stem_fwd, model)
+            model.forward = types.MethodType(_resnet_forward_train, model)
     return n

@@ -405,7 +405,9 @@ int btx_fill_sign(int8_t* out, size_t n, const BtxRng* rng, uint32_t rng_stream,
 /* K6. Monte-Carlo predictive accumulation (what examples/main_bayesian_imagenet_dnn2bnn.py:483-499 and
  * utils/util.py:41-60 do on the host with torch.stack -> softmax -> mean / entropy).
  * packed layout (f32): [bs*C sum p | bs*C sum p^2 | bs sum H(p) | 1 sum kl | 1 sample count]
- * The buffer is accumulated in place (zero it first); one RCCL all-reduce(sum) of it merges ranks. */
+ * The buffer is accumulated in place (zero it first); one RCCL all-reduce(sum) of it merges ranks.
+ * Limit: a row of probabilities stays in LDS, C <= 24575 classes (16383 on a device that refuses the 96-KiB dynamic-LDS
+ * opt-in); wider rows return BTX_E_UNSUPPORTED (the Python face then uses torch ops on the device: mc.MC_MAX_CLASSES). */
 size_t btx_mc_packed_floats(int bs, int C);
 int btx_mc_accumulate(const void* logits, int bs, int C, int act_dtype, float kl,
                       float* packed, void* stream);

@@ -254,6 +254,38 @@ def test_hip_batchnorm_patch_leaves_cpu_and_eval_forwards_alone():
     assert hip_batchnorm(m) == 2 and "_btx_fwd_eval" not in m[0].__dict__
 
 
+def test_hip_batchnorm_survives_deepcopy_pickle_and_skips_sync_batchnorm():
+    """a deep copy of a patched model (EMA / AveragedModel, eval copies) must normalise with ITS OWN weights and running
+    estimates, torch.save(model) must work, nn.SyncBatchNorm (cross-rank statistics) and the Lazy* variants keep torch's forward"""
+    import copy
+    import io
+    from bayesian_torch_amd.models.fuse import hip_batchnorm
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.MaxPool2d(2))
+    assert hip_batchnorm(net) == 1
+    cp = copy.deepcopy(net)
+    assert cp[1].forward.__self__ is cp[1] and cp[2].forward.__self__ is cp[2]
+    with torch.no_grad():
+        cp[1].weight.mul_(3.0)
+    x = torch.randn(4, 3, 8, 8)
+    net.train(); cp.train()
+    rv = net[1].running_var.clone()
+    y_cp = cp(x)
+    assert torch.equal(net[1].running_var, rv)             # the copy's training forward leaves the original's estimates alone
+    assert not torch.equal(cp[1].running_var, rv)
+    assert not torch.allclose(y_cp, net(x))                 # and uses its own weight
+    buf = io.BytesIO()
+    torch.save(net, buf)                                    # no local closures in the patched forwards
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    net.eval(); back.eval()
+    assert torch.equal(back(x), net(x))
+    sync = torch.nn.Sequential(torch.nn.SyncBatchNorm(8), torch.nn.LazyBatchNorm2d())
+    assert hip_batchnorm(sync) == 0 and "forward" not in sync[0].__dict__
+    from bayesian_torch_amd.autograd import bn_train_usable
+    assert not bn_train_usable(torch.nn.SyncBatchNorm(8), torch.randn(2, 8, 4, 4))
+
+
 def test_deepcopy_gets_its_own_noise_identity_and_prior_detection():
     import copy
     from bayesian_torch_amd import layers as L
