@@ -752,6 +752,7 @@ static bool dma_shape_ok(const BtxGeom* g, int act_dtype, int prec, const Plan& 
 struct PatchPlan {
   int G, R, Rp, Wp, PP, NI, rtiles, nw, mi, astage, lds;
   int taps, kg, lds_g;  // tap-unrolled kernel (btx_contract_taps.h): 10*KH+KW or 0; K-groups per workgroup; LDS per group
+  int wide;             // tap-unrolled kernel, Reparameterization: 64-pixel x 128-channel wave tiles, ntiles / 2 grid n-tiles
   int tall, P, Wt, ncs;  // tall-strip tiles (ContractParams.pt_tall): virtual rows per image, strip width, strips per row tile
 };
 // Tall-strip tile of the tap-unrolled kernel: the batch as ONE tall image with P = max(H + ph, Ho) virtual rows per image
@@ -820,9 +821,11 @@ static bool patch_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, Patc
   pt->rtiles = (Ho + R - 1) / R;
   return pt->PP <= ppcap && G * R * Wo <= tp;
 }
-static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, Plan* pl, PatchPlan* pt) {
+// kind: BTX_KIND_* of the launch being planned, or -1 (the plan every kind can take)
+static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, Plan* pl, PatchPlan* pt, int kind = -1) {
   if (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_ROWFUSE)) return false;
   if (make_plan(g, prec, flags, DBM, pl)) return false;
+  pt->wide = 0;
   if (!dma_shape_ok(g, act_dtype, prec, *pl)) return false;
   if (g->D != 1 || g->KD != 1 || pl->Do != 1 || g->sh != 1 || g->sw != 1) return false;
   const int T = g->KH * g->KW;
@@ -867,10 +870,16 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   const int ncb = pl->Cg / bk;
   pl->mtiles = pt->tall ? pt->rtiles * pt->ncs : ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
-  const long long base1 = (long long)pl->mtiles * pl->ntiles * g->groups;
-  const long long base = base1 * plan_lanes(flags);
   const bool no_taps = tune_env("BTX_NO_TAPS") != nullptr;  // A/B: the run-time-tap patch kernel instead (read per call)
   pt->taps = (!no_taps && pt->nw == 4 && pt->mi == 2 && pt->NI <= 6 && g->KH == 3 && g->KW == 3) ? 33 : 0;
+  // Reparameterization on the tap-unrolled kernel: one accumulator set per output, so the wave can hold a 64-pixel x 128-channel
+  // tile (contract_taps_kernel<..., WIDE>) — taken when whole pairs of n-tiles exist and the halved grid still fills the
+  // workgroup slots (few-tile launches keep the narrow tile and its K-groups).  BTX_NO_WIDE=1 disables (A/B).
+  if (kind == BTX_KIND_REPARAM && pt->taps == 33 && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 && (pl->Ng % 128) == 0 &&
+      (long long)pl->mtiles * (pl->ntiles / 2) * g->groups * plan_lanes(flags) >= slots4() && !tune_env("BTX_NO_WIDE"))
+    pt->wide = 1;
+  const long long base1 = (long long)pl->mtiles * (pt->wide ? pl->ntiles / 2 : pl->ntiles) * g->groups;
+  const long long base = base1 * plan_lanes(flags);
   // Few pixel tiles (at most one 4-wave block per CU): 8-wave blocks of two K-groups — split-K inside the workgroup
   // through LDS instead of through HBM, and two waves per SIMD.  BTX_NO_KG=1 disables (A/B).
   // BTX_FLAG_CONCURRENT: plain 4-wave blocks — an 8-wave block takes the whole LDS of its CU, so two such launches of
@@ -1078,7 +1087,13 @@ size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, i
   Plan c;
   PatchPlan pt;
   if (make_patch_plan(g, act_dtype, prec, flags, &c, &pt) || make_patch2_plan(g, act_dtype, prec, flags, &c, &pt)) {
-    const size_t wc = pad256(plan_ws(c, g, lanes)) + patch_wt_bytes(c, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
+    size_t wc = pad256(plan_ws(c, g, lanes)) + patch_wt_bytes(c, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
+    Plan cw;
+    PatchPlan ptw;  // the wide Reparameterization tile halves the grid and may split K differently
+    if (make_patch_plan(g, act_dtype, prec, flags, &cw, &ptw, BTX_KIND_REPARAM) && ptw.wide) {
+      const size_t ww = pad256(plan_ws(cw, g, lanes)) + patch_wt_bytes(cw, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
+      if (ww > wc) wc = ww;
+    }
     if (wc > wa) wa = wc;
     if (pt.taps == 33) wa = pad256(wa) + BTX_QUEUE_BYTES;
   }
@@ -1228,7 +1243,7 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   bool patch = false;
   if (dma && !rowfuse && !no_patch) {
     Plan pp;
-    if (make_patch_plan(g, act_dtype, prec, flags, &pp, &pt)) { pl = pp; patch = true; }
+    if (make_patch_plan(g, act_dtype, prec, flags, &pp, &pt, kind)) { pl = pp; patch = true; }
     else if (make_patch2_plan(g, act_dtype, prec, flags, &pp, &pt)) { pl = pp; patch = true; }
   }
   int out_bf16 = (act_dtype == BTX_ACT_BF16) ? 1 : 0;
@@ -1412,6 +1427,11 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_mi = pt.mi; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
     { const char* tn = tune_env("BTX_TAPS_TUNE"); p.pt_tune = tn ? atoi(tn) : 0; }
     p.pt_taps = pt.taps; p.pt_kg = pt.kg; p.pt_lds_g = pt.lds_g;
+    p.pt_wide = (pt.taps == 33) ? pt.wide : 0;
+    if (p.pt_wide) {  // the grid's n-tiles are pairs of weight tiles (p.ntiles stays the tile count of the weight layout)
+      p.fd_ntiles = make_fastdiv((uint32_t)(pl.ntiles / 2));
+      p.fd_inner = make_fastdiv((uint32_t)((pl.ntiles / 2) * g->groups * pl.ksplits));
+    }
     p.pt_tall = pt.tall; p.pt_P = pt.P; p.pt_Wt = pt.Wt; p.pt_ncs = pt.ncs;
     p.fd_P = make_fastdiv((uint32_t)pt.P); p.fd_Wt = make_fastdiv((uint32_t)pt.Wt); p.fd_ncs = make_fastdiv((uint32_t)pt.ncs);
     // Persistent form of the tap-unrolled kernel (btx_contract_taps3.h): about two workgroups per CU, each walking one

@@ -140,6 +140,8 @@ struct ContractParams {
   int pt_kg;      // tap-unrolled kernel: K-groups per workgroup (1 | 2)
   int pt_lds_g;   //                      LDS bytes of one K-group
   int pt_taps;    // 10*KH + KW when the tap-unrolled kernel (btx_contract_taps.h) takes the launch, else 0
+  int pt_wide;    // tap-unrolled kernel, Reparameterization: 64-pixel x 128-channel wave tiles; the grid has ntiles / 2 n-tiles
+                  // (fd_ntiles and fd_inner are made for that count), workgroup n-tile t contracts weight tiles 2t and 2t + 1
   int sp_Hq, sp_Wq;  // stem + max-pool variant (btx_contract_stempool.h): pooled extent
   int st_sbytes;  // stem variant: bytes of the s_in word array in LDS  // waves per block (4 | 8), bytes per patch slot, dynamic LDS bytes of the block
   void* wt;  // pre-sampled weight tiles (workspace): [group*ntiles + ntile][K/G][64][16 B]; delta array at +wt_delta_off

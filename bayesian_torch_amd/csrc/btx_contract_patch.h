@@ -424,6 +424,12 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
         }
       }
 #endif
+      if constexpr (PREC == 1) {
+        if (p.pt_wide && kind == 0) {  // Reparameterization on 64 x 128 wave tiles (btx_contract_taps.h, WIDE)
+          BTX_LAUNCH_TP(0, 1, false, true);
+          return (int)hipGetLastError();
+        }
+      }
       if (kind == 0) BTX_LAUNCH_TP(0, 1); else BTX_LAUNCH_TP(1, 1);
     }
 #undef BTX_LAUNCH_TP

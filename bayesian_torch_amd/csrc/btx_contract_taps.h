@@ -79,15 +79,23 @@ constexpr int tp_pieces(int t) {
 // DIRECT (bf16, KG == 1; the host launches it when ContractParams.ep_direct): the store side runs from the fragment registers
 // (direct_epilogue, btx_epilogue.h) — its own instantiation of the kernel, because with both store sides behind a run-time
 // branch of one kernel hipcc spills (the staged side's address arithmetic is interleaved with the fold).
-template <int PREC, int KIND, int KH, int KW, int KG, bool DIRECT = false>
+// WIDE (Reparameterization, bf16, KG == 1; the host launches it when ContractParams.pt_wide): the wave's tile is 64 pixels x 128
+// channels — 2 x 4 MFMA tiles, the register budget Flipout spends on its second accumulator set.  A Reparameterization stage on
+// the 2 x 2 tile reads 8 fragments for 8 MFMAs and re-fetches the patch once per 64 output channels; here the stage's second
+// weight tile (n-tile 2*ntile + 1, in the LDS slot Flipout's delta tile takes) shares the activation fragments of the first:
+// 12 reads for 16 MFMAs, half the patch DMA per MFMA, the K loop of the Flipout kernel without its sign masks.  The workgroup
+// stores two 64-channel tiles, one after the other, through the same staging area.
+template <int PREC, int KIND, int KH, int KW, int KG, bool DIRECT = false, bool WIDE = false>
 __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const ContractParams) {
   static_assert(!DIRECT || (PREC == 1 && KG == 1), "direct store side: bf16, one K-group");
+  static_assert(!WIDE || (PREC == 1 && KG == 1 && KIND == 0 && !DIRECT), "wide tile: bf16 Reparameterization, one K-group");
+  constexpr int K2 = (KIND == 1 || WIDE) ? 1 : 0;  // two weight tiles per stage and two accumulator sets
   BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   constexpr int NW = 4, NT = 256, MI = 2, T = KH * KW;
   static_assert(T >= 5 && T <= 32, "tap-unrolled kernel: 5..32 taps");
   constexpr int MAXNI = TP_MAXNI;
   constexpr int PST = T - 3;                      // stages 0..T-4 of a block carry the next block's patch pieces
-  constexpr int WOPS = (KIND == 1) ? 2 : 1;       // weight DMA instructions per wave per stage
+  constexpr int WOPS = K2 ? 2 : 1;                // weight DMA instructions per wave per stage
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
   constexpr int BK = NG * G;
@@ -117,10 +125,11 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
 #define BTX_TR_P(i) do { } while (0)
 #endif
   uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
+  const uint32_t ntg = (uint32_t)(WIDE ? p.ntiles >> 1 : p.ntiles);  // n-tiles of the grid (wide: fd_ntiles / fd_inner are made for it)
   if (p.wg_order) fdivmod((uint32_t)logical, p.fd_mtiles, (uint32_t)p.mtiles, u_rem, u_mtile);  // weight-major (btx_api.hip)
-  else fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
+  else fdivmod((uint32_t)logical, p.fd_inner, ntg * (uint32_t)(p.groups * p.ksplits), u_mtile, u_rem);
   fdivmod(u_rem, p.fd_ksplits, (uint32_t)p.ksplits, u_t, u_split);
-  fdivmod(u_t, p.fd_ntiles, (uint32_t)p.ntiles, u_group, u_ntile);
+  fdivmod(u_t, p.fd_ntiles, ntg, u_group, u_ntile);
   const int mtile = (int)u_mtile, split = (int)u_split, ntile = (int)u_ntile, group = (int)u_group;
 
   // tile origin.  Plain tiles: pt_G whole images or pt_R rows of one image, full width.  Tall strips (pt_tall): pt_R rows
@@ -161,7 +170,8 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   // ---- weight loader: wave w fetches row w of the stage's mu tile (+ row w of its delta tile): 1 KiB each.
   //      byte offset = [tile base + k-granule row of the stage] (scalar) + [row w, lane] (vector, constant)
   const uint32_t w_voff = (uint32_t)lane * 16u + (uint32_t)wave * 1024u;
-  const uint32_t w_sbase = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u;
+  const uint32_t w_sbase = (uint32_t)(group * p.ntiles + (WIDE ? 2 * ntile : ntile)) * (uint32_t)(p.K / G) * 1024u;
+  const uint32_t w_second = WIDE ? (uint32_t)(p.K / G) * 1024u : p.wt_delta_off;  // the stage's second tile: next n-tile | delta
   const uint32_t CgG = (uint32_t)(p.Cg / G);
   const int w_lds = PT_W_OFF + wave * 1024;
   int wslot = 0;  // ring slot of the stage being multiplied
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
     const uint32_t soff = w_sbase + (tap * CgG + cb * (uint32_t)NG) * 1024u;
     unsigned char* ld = smem + w_lds + slot * DW_STAGE;
     dma16s(wt_rsrc, w_voff, soff, ld);
-    if constexpr (KIND == 1) dma16s(wt_rsrc, w_voff, soff + p.wt_delta_off, ld + 4096);
+    if constexpr (K2) dma16s(wt_rsrc, w_voff, soff + w_second, ld + 4096);
   };
   if (ncb > 0) issue_w(0u, (uint32_t)cb0, 0);
 
@@ -267,6 +277,12 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
       q0[mi] = ok ? (gi * p.pt_Rp + r) * p.pt_Wp + c : 0;
     }
   }
+#ifdef BTX_PT_NOJUMP
+  // MEASUREMENT ONLY (wrong results): the lane's patch pixel = its raster index — 32 consecutive pixels per MFMA tile, no +2 step
+  // at a row end, i.e. fragment reads free of LDS bank conflicts whatever the tap: the time the conflicts cost, as an upper bound
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) q0[mi] = (wave * 64 + mi * 32 + l31) & 127;
+#endif
   const int row_step = p.dh * p.pt_Wp;  // patch-pixel offset of tap (kh, kw) = kh*row_step + kw*dw (wave-uniform)
 
   // bf16, one K-group: the accumulators are started by the first stage's MFMAs (zero C operand, stage_mma<..., ZERO>) instead
@@ -382,12 +398,12 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
         DeltaFrag df;
         if constexpr (KG == 1) {
           // 3. delta weights of this stage, then the fragments of the next one
-          load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
+          load_delta<K2>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
           constexpr int t1 = (t + 1) % T, c1 = (t + 1) / T;
           load_frag(nxt, PAR ^ c1, (t1 / KW) * row_step + (t1 % KW) * p.dw, (wslot + 1) & 3, mia_tag);
           // 4. multiply
-          if constexpr (FIRST && t == 0) stage_mma<PREC, KIND, MI, MIA, true>(cur, df, accm, accd, l31, h);
-          else stage_mma<PREC, KIND, MI, MIA>(cur, df, accm, accd, l31, h);
+          if constexpr (FIRST && t == 0) stage_mma<PREC, K2, MI, MIA, true, KIND == 1>(cur, df, accm, accd, l31, h);
+          else stage_mma<PREC, K2, MI, MIA, false, KIND == 1>(cur, df, accm, accd, l31, h);
           // 5. W(s+2) — and, from stage T-3 on, every piece of the next patch — landed; meet the other waves
 #ifdef BTX_PT_TRACE
           {  // split the stage end: issue+MFMA | LDS reads back | VMEM wait | barrier
@@ -483,6 +499,15 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
         }
         direct_epilogue<KIND>(pe, rl, accm, accd, (float*)smem, tid_o, lane_o, ntile, group, gp, gok);
       } else {
+        if constexpr (WIDE) {
+          // the two 64-channel tiles one after the other; the barrier keeps the second tile's per-channel constants out of the
+          // LDS words a slower wave still reads for the first
+          if (tall) staged_epilogue_pm<0, NW, PixTall>(pe, rl, accm, accm, smem, tid, wave, lane, 2 * ntile, group, split, pmt);
+          else staged_epilogue<0, NW>(pe, rl, accm, accm, smem, tid, wave, lane, 2 * ntile, group, split, m0, nvalid);
+          __syncthreads();
+          if (tall) staged_epilogue_pm<0, NW, PixTall>(pe, rl, accd, accd, smem, tid, wave, lane, 2 * ntile + 1, group, split, pmt);
+          else staged_epilogue<0, NW>(pe, rl, accd, accd, smem, tid, wave, lane, 2 * ntile + 1, group, split, m0, nvalid);
+        } else
         if (tall) staged_epilogue_pm<KIND, NW, PixTall>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pmt);
         else staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
       }

@@ -77,7 +77,9 @@ __device__ __forceinline__ void load_delta(DeltaFrag& d, const unsigned char* ws
 // MFMAs wait for data they do not need.
 // MIA = the wave's 32-pixel tiles that hold real pixels (<= MI): the tiles behind them are tile padding and are skipped.
 // ZERO (bf16): first stage of a tile — the accumulators start from the MFMA's inline zero operand instead of 128 v_mov.
-template <int PREC, int KIND, int MI = 2, int MIA = MI, bool ZERO = false>
+// MASK == false (the wide Reparameterization tile, btx_contract_taps.h): the second weight tile is the next n-tile of the same
+// sampled weights — same activations, no signs.
+template <int PREC, int KIND, int MI = 2, int MIA = MI, bool ZERO = false, bool MASK = true>
 __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& dfrag, f32x16 (&accm)[MI][2],
                                           f32x16 (&accd)[MI][2], int l31, int h) {
     const u32x4 (&wd)[NG / 2][2] = dfrag.w;
@@ -153,7 +155,7 @@ __device__ __forceinline__ void stage_mma(StageFragT<MI>& f, const DeltaFrag& df
       for (int kk = 0; kk < NG / 2; ++kk) {
         const int row = 2 * kk + h;
         if constexpr (PREC == 1) {
-          if constexpr (!(BTX_PT_ABL & 16)) {
+          if constexpr (MASK && !(BTX_PT_ABL & 16)) {
 #pragma unroll
             for (int mi = 0; mi < MIA; ++mi) {
               const uint32_t swr = f.sw[mi] << (4 * row);

@@ -263,6 +263,8 @@ CPU_CASES = [
     ("stem", "Conv2dFlipout", dict(in_channels=3, out_channels=64, kernel_size=7, stride=2, padding=3, bias=False), (64, 3, 224, 224)),
     ("fc", "LinearFlipout", dict(in_features=512, out_features=1000), (64, 512)),
     ("reparam_28", "Conv2dReparameterization", dict(in_channels=128, out_channels=128, kernel_size=3, padding=1, bias=False), (64, 128, 28, 28)),
+    # 784 pixel tiles x 1 pair of n-tiles: the wide Reparameterization tile (64 px x 128 ch per wave) in a single launch, with bias
+    ("reparam_wide_56", "Conv2dReparameterization", dict(in_channels=64, out_channels=128, kernel_size=3, padding=1, bias=True), (64, 64, 56, 56)),
 ]
 
 
