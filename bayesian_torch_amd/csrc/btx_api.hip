@@ -878,6 +878,10 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
   if (kind == BTX_KIND_REPARAM && pt->taps == 33 && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 && (pl->Ng % 128) == 0 &&
       (long long)pl->mtiles * (pl->ntiles / 2) * g->groups * plan_lanes(flags) >= slots4() && !tune_env("BTX_NO_WIDE"))
     pt->wide = 1;
+  if (pt->wide && pt->lds < pt->nw * PT_EP_WAVE + 2048) {  // its store side keeps the constants of two channel tiles
+    pt->lds = pt->nw * PT_EP_WAVE + 2048;
+    pt->lds_g = (pt->lds + 15) & ~15;
+  }
   const long long base1 = (long long)pl->mtiles * (pt->wide ? pl->ntiles / 2 : pl->ntiles) * g->groups;
   const long long base = base1 * plan_lanes(flags);
   // Few pixel tiles (at most one 4-wave block per CU): 8-wave blocks of two K-groups — split-K inside the workgroup

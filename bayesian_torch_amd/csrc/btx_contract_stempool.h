@@ -341,18 +341,25 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     bool wr[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) wr[mi] = mi < mia && st_off[mi] >= 0;
+    // the per-channel constants of all four 8-channel runs first: read where they are used, every run starts with an LDS round
+    // trip the wave has nothing to put beside (one wave per SIMD in this role): Reparameterization staging 23.0k -> 19.4k cycles
+    // per band (profiles/r06_experiments.txt E5)
+    f32x4 bm_[4], bd_[4], sc_[4], sh_[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int cl = ni * 32 + 8 * q + 4 * h;
-      f32x4 bm, bd, sc, sh;
       if constexpr (BIAS) {
-        bm = *(const f32x4*)(ba_lds + cl);
-        bd = *(const f32x4*)(ba_lds + BN + cl);
+        bm_[q] = *(const f32x4*)(ba_lds + cl);
+        bd_[q] = *(const f32x4*)(ba_lds + BN + cl);
       }
       if constexpr (AFF) {
-        sc = *(const f32x4*)(ba_lds + 2 * BN + cl);
-        sh = *(const f32x4*)(ba_lds + 3 * BN + cl);
+        sc_[q] = *(const f32x4*)(ba_lds + 2 * BN + cl);
+        sh_[q] = *(const f32x4*)(ba_lds + 3 * BN + cl);
       }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bm = bm_[q], bd = bd_[q], sc = sc_[q], sh = sh_[q];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         f32x4 v;

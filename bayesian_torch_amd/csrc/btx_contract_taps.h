@@ -42,6 +42,17 @@ __device__ __forceinline__ void end_stage() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// the lane view of the prologue: BTX_TAPS_FLAT=1 reads every field of the lane arithmetic in ONE batch of scalar loads
+// (lane_view_flat, btx_contract.h) instead of one dependent batch per `if` of lane_view
+#ifndef BTX_TAPS_FLAT
+#define BTX_TAPS_FLAT 0
+#endif
+#if BTX_TAPS_FLAT
+#define BTX_TAPS_PARAMS(name, logical_var) BTX_SECTION_PARAMS_FLAT(name, logical_var)
+#else
+#define BTX_TAPS_PARAMS(name, logical_var) BTX_SECTION_PARAMS(name, logical_var)
+#endif
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   static_assert(!DIRECT || (PREC == 1 && KG == 1), "direct store side: bf16, one K-group");
   static_assert(!WIDE || (PREC == 1 && KG == 1 && KIND == 0 && !DIRECT), "wide tile: bf16 Reparameterization, one K-group");
   constexpr int K2 = (KIND == 1 || WIDE) ? 1 : 0;  // two weight tiles per stage and two accumulator sets
-  BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
+  BTX_TAPS_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   constexpr int NW = 4, NT = 256, MI = 2, T = KH * KW;
   static_assert(T >= 5 && T <= 32, "tap-unrolled kernel: 5..32 taps");
   constexpr int MAXNI = TP_MAXNI;
@@ -207,12 +218,19 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
   const int g_lane = (lane & 3) ^ ((lane >> 4) & 3);
   uint32_t pp_boff[MAXNI];
   uint32_t pmask = 0;  // bit j: piece j of this wave exists
+  // all table reads first (one LDS round trip instead of one per piece; entries behind pt_PP hold whatever the slot held)
+  uint32_t pp_e[MAXNI];
+#pragma unroll
+  for (int j = 0; j < MAXNI; ++j) {
+    const int q = 16 * (wave + NW * j) + (lane >> 2);
+    pp_e[j] = pix_tab[q < p.pt_PP ? q : 0];
+  }
 #pragma unroll
   for (int j = 0; j < MAXNI; ++j) {
     const int q = 16 * (wave + NW * j) + (lane >> 2);
     uint32_t bo = DMA_OOB;
     if (j < p.pt_NI && q < p.pt_PP) {
-      const uint32_t e = pix_tab[q];
+      const uint32_t e = pp_e[j];
       if (e != 0xffffffffu) bo = (e + (uint32_t)(G * g_lane)) * (uint32_t)ESZ;
     }
     pp_boff[j] = bo;
@@ -500,13 +518,27 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
         direct_epilogue<KIND>(pe, rl, accm, accd, (float*)smem, tid_o, lane_o, ntile, group, gp, gok);
       } else {
         if constexpr (WIDE) {
-          // the two 64-channel tiles one after the other; the barrier keeps the second tile's per-channel constants out of the
-          // LDS words a slower wave still reads for the first
-          if (tall) staged_epilogue_pm<0, NW, PixTall>(pe, rl, accm, accm, smem, tid, wave, lane, 2 * ntile, group, split, pmt);
-          else staged_epilogue<0, NW>(pe, rl, accm, accm, smem, tid, wave, lane, 2 * ntile, group, split, m0, nvalid);
-          __syncthreads();
-          if (tall) staged_epilogue_pm<0, NW, PixTall>(pe, rl, accd, accd, smem, tid, wave, lane, 2 * ntile + 1, group, split, pmt);
-          else staged_epilogue<0, NW>(pe, rl, accd, accd, smem, tid, wave, lane, 2 * ntile + 1, group, split, m0, nvalid);
+          // the two 64-channel tiles one after the other through the wave's private staging area; the per-channel constants of
+          // BOTH are written first (waves 0 and 1, side by side behind the staging areas: the host reserves 2 KiB there for a
+          // wide launch), so the store side has one workgroup barrier, not three
+          float* const ba0 = (float*)(smem + NW * PT_EP_WAVE);
+          float* const ba1 = ba0 + 4 * BN;
+          {
+            const bool has_bias = (split == 0) && (pe.mu_b != nullptr);
+            const bool has_aff = (pe.ksplits == 1) && ((pe.ep_scale != nullptr) || (pe.ep_shift != nullptr));
+            if (has_bias || has_aff) {
+              if (tid < 64) ep_fill_constants<0>(pe, rl, ba0, tid, 2 * ntile, group, has_bias, has_aff);
+              else if (tid < 128) ep_fill_constants<0>(pe, rl, ba1, tid - 64, 2 * ntile + 1, group, has_bias, has_aff);
+            }
+            __syncthreads();
+          }
+          if (tall) {
+            staged_epilogue_pm<0, NW, PixTall>(pe, rl, accm, accm, smem, tid, wave, lane, 2 * ntile, group, split, pmt, nullptr, -1, true, ba0);
+            staged_epilogue_pm<0, NW, PixTall>(pe, rl, accd, accd, smem, tid, wave, lane, 2 * ntile + 1, group, split, pmt, nullptr, -1, true, ba1);
+          } else {
+            staged_epilogue<0, NW>(pe, rl, accm, accm, smem, tid, wave, lane, 2 * ntile, group, split, m0, nvalid, nullptr, -1, true, ba0);
+            staged_epilogue<0, NW>(pe, rl, accd, accd, smem, tid, wave, lane, 2 * ntile + 1, group, split, m0, nvalid, nullptr, -1, true, ba1);
+          }
         } else
         if (tall) staged_epilogue_pm<KIND, NW, PixTall>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, pmt);
         else staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);

@@ -525,7 +525,11 @@ class Runner:
                 gr.close()
 
 
-def timed_mc(runner, my_indices, warm_indices, world, dev, repeats=1):
+def timed_mc(runner, my_indices, warm_indices, world, dev, repeats=1, min_seconds=0.0):
+    """The timed region — EXACTLY len(my_indices) MC samples between barrier + synchronize on both sides — run `repeats` times, and
+    on until the regions add up to `min_seconds`: a 20-step region is ~10 ms of GPU time, the package's clock / power management
+    settles over hundreds of ms.  Every rank runs the same number of regions (the count follows the slowest rank's first region).
+    Returns the per-region times (max over ranks)."""
     def barrier():
         if world > 1:
             dist.barrier()
@@ -537,7 +541,8 @@ def timed_mc(runner, my_indices, warm_indices, world, dev, repeats=1):
         runner.run(warm_indices)
         if grouped:
             dist.all_reduce(runner.packed)  # warm the communicator too
-        for _ in range(max(1, repeats)):  # the SAME timed region `repeats` times: a 20-step region is ~10 ms of GPU time
+
+        def region():
             runner.zero()
             barrier()
             t0 = time.perf_counter()
@@ -547,10 +552,26 @@ def timed_mc(runner, my_indices, warm_indices, world, dev, repeats=1):
                 dist.all_reduce(runner.packed, op=dist.ReduceOp.SUM)
             barrier()
             runs.append(time.perf_counter() - t0)
+        region()
+        n = max(1, repeats)
+        if min_seconds > 0:
+            t1 = torch.tensor([runs[0]], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            n = max(n, min(2000, int(min_seconds / max(float(t1[0]), 1e-6)) + 1))
+        for _ in range(n - 1):
+            region()
     t = torch.tensor(runs, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # per region: the slowest rank
     return [float(v) for v in t]
+
+
+def settled(runs):
+    """the figure a list of back-to-back regions reports: the median of its second half (the first half carries the clock ramp of a
+    package that was idle a moment ago); fewer than 8 regions: the median of all"""
+    tail = sorted(runs[len(runs) // 2:]) if len(runs) >= 8 else sorted(runs)
+    return tail[len(tail) // 2]
 
 
 def logits_parity(model_fn, x, prec, sample=3):
@@ -576,7 +597,7 @@ def logits_parity(model_fn, x, prec, sample=3):
 
 def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, world=1, rank=0, graph=True, fuse=True,
                       presample=True, scaling="weak", total=None, per_launch=True, parity=False, prewarm=PREWARM_STEPS,
-                      concurrent_hint=None, lane_mode="launch", repeats=5, sustain=0.0):
+                      concurrent_hint=None, lane_mode="launch", repeats=5, sustain=0.0, min_seconds=0.0):
     import bayesian_torch_amd as bt
     from bayesian_torch_amd import mc
     bt.manual_seed(2024)
@@ -599,8 +620,8 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
     warm = [10_000_000 + w * world + rank for w in range(nwarm)]
     runner = Runner(model, x, kl, 1000, lanes, graph, presample, sizes=(len(mine), len(warm)), concurrent_hint=concurrent_hint,
                     lane_mode=lane_mode)
-    runs = timed_mc(runner, mine, warm, world, dev, repeats=repeats)
-    elapsed = sorted(runs)[len(runs) // 2]  # median of the repeated regions; every region is reported
+    runs = timed_mc(runner, mine, warm, world, dev, repeats=repeats, min_seconds=min_seconds)
+    elapsed = settled(runs)  # median of the settled half of the back-to-back regions; the first five are listed, the rest summarised
     stats = runner.packed.clone()
     lanes_used = runner.graphed.lanes if runner.graphed is not None else 0
     sustained = None
@@ -613,7 +634,10 @@ def run_resnet_config(arch, typ, prec, bs, moped, steps, warmup, lanes, dev, wor
     res = {"elapsed": elapsed, "n_global": n_global, "per_rank": len(mine), "kl": kl, "lanes": lanes_used,
            "lane_mode": lane_mode if lanes_used > 1 else "single",
            "ms_per_step": 1e3 * elapsed / max(len(mine), 1), "value": n_global / elapsed,
-           "ms_per_step_runs": [1e3 * r / max(len(mine), 1) for r in runs]}
+           "ms_per_step_runs": [1e3 * r / max(len(mine), 1) for r in runs[:5]], "timed_regions": len(runs),
+           "timed_seconds": sum(runs),
+           "ms_per_step_all_regions": {"min": 1e3 * min(runs) / max(len(mine), 1), "max": 1e3 * max(runs) / max(len(mine), 1),
+                                       "mean": 1e3 * sum(runs) / len(runs) / max(len(mine), 1)}}
     if sustained is not None:
         res["sustained"] = sustained
     known = KL_KNOWN.get((arch, moped))
@@ -877,6 +901,7 @@ def compact_line(out):
     (incl. traffic ratio, clock/power, the readings inside north_star's 1e-4) and `cpu_baseline`; per-launch tables,
     traffic breakdowns and prose stay in gpurun_out/bench_detail.json (also echoed to stderr)."""
     top = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "ms_per_step_runs",
+           "timed_regions", "timed_seconds", "ms_per_step_all_regions",
            "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "dry_run", "total_samples", "collective",
            "kl_rel_err", "logits_rel_l2_vs_unfused_f32", "gpu_over_cpu", "sustained")
     line = {k: out[k] for k in top if k in out}
@@ -1036,8 +1061,11 @@ def main():
     ap.add_argument("--lane-mode", default="launch", choices=["launch", "streams"], help="launch: the samples of a replay "
                     "are lanes of ONE launch per layer (btx_contract_fwd_lanes); streams: one launch per (layer, sample), "
                     "each sample on its own stream (the round-2 form)")
-    ap.add_argument("--repeats", type=int, default=5, help="the timed region (the same --steps MC samples) is run this many "
-                    "times; value / ms_per_step are the median region, every region is listed in ms_per_step_runs")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region (the same --steps MC samples) is run at least this "
+                    "many times, back to back")
+    ap.add_argument("--settle-seconds", type=float, default=1.0, help="...and on until the regions add up to this long: value / "
+                    "ms_per_step are the median of the SECOND half of the regions (settled clock); ms_per_step_runs lists the "
+                    "first five, ms_per_step_all_regions min / max / mean of all")
     ap.add_argument("--no-presample", action="store_true")
     ap.add_argument("--latency-plan", action="store_true", help="A/B: plan every launch for its own latency (split-K to fill "
                     "idle CUs) although several MC samples are in flight")
@@ -1098,7 +1126,8 @@ def main():
                              per_launch=not args.no_launch_timing and rank == 0,
                              concurrent_hint=False if args.latency_plan else None,
                              parity=(rank == 0 and world == 1 and not args.no_extras), lane_mode=args.lane_mode,
-                             repeats=args.repeats, sustain=0.0 if args.no_sustain else 2.0)
+                             repeats=args.repeats, sustain=0.0 if args.no_sustain else 2.0,
+                             min_seconds=args.settle_seconds)
     if rank == 0:
         peak = MFMA_PEAK_TFLOPS[args.prec]
         roofline = None
@@ -1159,7 +1188,10 @@ def main():
             "value": head["value"], "unit": "MC-samples/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
             "collective": "rccl all_reduce in the timed region" if grouped else "none (1 process, no group)",
             "steps": head["per_rank"], "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "ms_per_step_runs": head["ms_per_step_runs"], "timed_regions": len(head["ms_per_step_runs"]),
+            "ms_per_step_runs": head["ms_per_step_runs"], "timed_regions": head["timed_regions"],
+            "timed_seconds": head["timed_seconds"], "ms_per_step_all_regions": head["ms_per_step_all_regions"],
+            "value_is": "len(steps) / median region of the settled (second) half of `timed_regions` back-to-back regions of "
+                        "exactly `steps` MC samples each (barrier + synchronize on both sides of every region)",
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "dnn_to_bnn(%s) %s%s, 224x224, batch %d, %d MC samples per GPU (%d in total), %s init "
                                    "(seed 0), activations %s, eval-BN/ReLU/residual %s, %s" % (
@@ -1182,18 +1214,20 @@ def main():
             extra = {}
             try:
                 r = run_resnet_config("resnet18", "Reparameterization", "bf16", 64, False, 16, 3, 16, dev, parity=True,
-                                      prewarm=3)
+                                      prewarm=3, min_seconds=0.5)
                 extra["cfg3"] = summarise_extra("cfg3: dnn_to_bnn(ResNet18) Reparameterization bs64 bf16", r, "bf16")
                 r = run_resnet_config("resnet18", "Flipout", "f32", 64, False, 3, 1, 1, dev, prewarm=1, parity=True)
                 extra["cfg4_f32_parity_mode"] = summarise_extra(
                     "cfg4 shard in f32 parity mode (v_mfma_f32_32x32x2_f32, f32 activations)", r, "f32")
                 # north_star's 1e-4 tolerance at throughput: f32 activations, split-bf16 operands, three bf16 MFMAs per product
-                r = run_resnet_config("resnet18", "Flipout", "bf16x3", 64, False, 20, 0, 20, dev, parity=True, prewarm=3)
+                r = run_resnet_config("resnet18", "Flipout", "bf16x3", 64, False, 20, 0, 20, dev, parity=True, prewarm=3,
+                                      min_seconds=0.5)
                 extra["cfg4_bf16x3"] = summarise_extra(
                     "cfg4 shard in split-bf16 mode (f32 activations, 3x v_mfma_f32_32x32x16_bf16 per product; fractions "
                     "against a third of the bf16 peak)", r, "bf16x3", table=True)
                 extra["cfg2"] = run_mlp_config(dev)
-                r = run_resnet_config("resnet50", "Flipout", "bf16", 128, True, 16, 2, 16, dev, parity=True, prewarm=3)
+                r = run_resnet_config("resnet50", "Flipout", "bf16", 128, True, 16, 2, 16, dev, parity=True, prewarm=3,
+                                      min_seconds=0.5)
                 extra["cfg5"] = summarise_extra("cfg5 shard: dnn_to_bnn(ResNet50) Flipout + MOPED(0.5) bs128 bf16", r, "bf16",
                                                 table=True)
                 r = run_resnet_config("resnet50", "Flipout", "bf16x3", 128, True, 16, 0, 16, dev, parity=True, prewarm=2,

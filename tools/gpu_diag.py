@@ -298,6 +298,7 @@ if __name__ == "__main__":
     ap.add_argument("--lanes", type=int, default=8)
     ap.add_argument("--throughput-plan", action="store_true")
     ap.add_argument("--bare", action="store_true", help="g8trace: no BN affine / residual / ReLU in the store side")
+    ap.add_argument("--typ", default="Flipout", help="trace: Flipout | Reparameterization")
     a = ap.parse_args()
     if a.throughput_plan:
         from bayesian_torch_amd import functional as _BF
@@ -319,7 +320,7 @@ if __name__ == "__main__":
         g8trace(a.prec.split(",")[0], *c, bs=a.bs, warm=a.warm, full=not a.bare)
     if "trace" in a.what:
         c = [int(v) for v in a.shape.split(",")]
-        trace(a.prec.split(",")[0], *c, bs=a.bs, warm=a.warm)
+        trace(a.prec.split(",")[0], *c, typ=a.typ, bs=a.bs, warm=a.warm)
     if "parity" in a.what:
         parity()
     if "perf" in a.what:
