@@ -298,7 +298,7 @@ if __name__ == "__main__":
     ap.add_argument("--lanes", type=int, default=8)
     ap.add_argument("--throughput-plan", action="store_true")
     ap.add_argument("--bare", action="store_true", help="g8trace: no BN affine / residual / ReLU in the store side")
-    ap.add_argument("--typ", default="Flipout", help="trace: Flipout | Reparameterization")
+    ap.add_argument("--typ", default="Flipout", help="one / timeone / trace: Flipout | Reparameterization")
     a = ap.parse_args()
     if a.throughput_plan:
         from bayesian_torch_amd import functional as _BF
@@ -308,7 +308,7 @@ if __name__ == "__main__":
         lanes_run(a.prec.split(",")[0], a.iters, *c, bs=a.bs, lanes=a.lanes)
     if "one" in a.what or "timeone" in a.what:
         c = [int(v) for v in a.shape.split(",")]
-        us = one(a.prec.split(",")[0], a.iters, *c, bs=a.bs)
+        us = one(a.prec.split(",")[0], a.iters, *c, typ=a.typ, bs=a.bs)
         if "timeone" in a.what:
             print("shape %s: %.1f us / launch" % (a.shape, us))
     if "gtime" in a.what:

@@ -8,6 +8,8 @@ steps (each writes the files named in its docstring, with the command that produ
   bench       profiles/<PREFIX>_bench_line.json (+ _summary.txt)            python bench.py (the driver's default invocation)
   trace       profiles/<PREFIX>_bench_kernel_trace_stats.txt, _lanes1.txt   rocprofv3 --kernel-trace of the bench command
   pmc         profiles/<PREFIX>_pmc_taps_lanes.txt                          SQ counters of contract_taps_kernel, many-tiles regime
+  cfg3        profiles/<PREFIX>_cfg3_kernel_trace_stats.txt, _cfg3_pmc_taps.txt, _cfg3_bench_line.json   BASELINE cfg3 (Reparameterization):
+                                                                            kernel trace of its bench command, SQ counters of its wide kernel
   phase       profiles/<PREFIX>_phase_timers.txt, r03_phase_timers_sustained.txt   block phase timers (trace build)
   ablation    profiles/<PREFIX>_kloop_ablation.txt                          what the K loop pays for (ablation builds)
   ubench      profiles/<PREFIX>_mfma_mix_ubench.txt                         tools/ubench/mfma_mix.hip
@@ -28,7 +30,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "profiles")
 ENV = dict(os.environ, TMPDIR="/tmp")
-PREFIX = "r05"  # file-name prefix of the round being measured
+PREFIX = "r06"  # file-name prefix of the round being measured
 SHAPES = ["64,64,56,1,3", "128,128,28,1,3", "256,256,14,1,3", "512,512,7,1,3"]
 
 
@@ -60,7 +62,9 @@ def step_bench():
     json.dump(d, open(os.path.join(OUT, PREFIX + "_bench_detail.json"), "w"), indent=1)
     r = d["roofline"]
     body = "final stdout line: %d bytes\n" % len(line)
-    body += "value %.1f %s  ms/step %.4f  regions %s\n" % (d["value"], d["unit"], d["ms_per_step"], ["%.3f" % v for v in d["ms_per_step_runs"]])
+    body += "value %.1f %s  ms/step %.4f  = the median of the settled half of %d back-to-back regions (%.2f s); first five %s; all regions %s\n" % (
+        d["value"], d["unit"], d["ms_per_step"], d["timed_regions"], d["timed_seconds"], ["%.3f" % v for v in d["ms_per_step_runs"]],
+        json.dumps(d.get("ms_per_step_all_regions")))
     body += "sustained (2 s of replays): %s\n" % json.dumps(d.get("sustained"))
     body += "roofline.frac %.4f (contraction only %.4f)  e2e %.4f  sampling %.1f us per %d-lane launch\n" % (
         r["frac"], r["frac_contraction_only"], r["frac_e2e"], r["sampling_us_per_launch"], r["mc_samples_per_launch"])
@@ -82,7 +86,7 @@ def step_trace():
     if os.environ.get("BTX_TRACE_STATS_ONLY"):  # (a short GPU budget: the 20-lane trace only)
         tags = tags[:1]
     for tag, extra in tags:
-        d = os.path.join(ROOT, "gpurun_out", "r4_kt_" + tag)
+        d = os.path.join(ROOT, "gpurun_out", "r6_kt_" + tag)
         shutil.rmtree(d, ignore_errors=True)
         cmd = "python %s/bench.py --steps 20 --warmup 20 --no-extras --no-cpu-baseline --no-traffic --no-sustain%s" % (ROOT, extra)
         sh("timeout -k 5 400 rocprofv3 --kernel-trace --stats -d %s -o kt -- %s" % (d, cmd), cwd="/tmp", timeout=1200)
@@ -143,17 +147,60 @@ def step_pmc():
     body = ""
     for shp in SHAPES[:2]:
         for i, s in enumerate(sets):
-            d = os.path.join(ROOT, "gpurun_out", "r4_pmc%d_%s" % (i, shp.replace(",", "_")))
+            d = os.path.join(ROOT, "gpurun_out", "r6_pmc%d_%s" % (i, shp.replace(",", "_")))
             shutil.rmtree(d, ignore_errors=True)
             sh("rocprofv3 --pmc %s --kernel-trace -d %s -o pmc -- python %s/tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 "
                "--bs 1280 --shape %s" % (s, d, ROOT, shp), cwd="/tmp", timeout=400)
-        rep = sh("python tools/pmc_report.py 'gpurun_out/r4_pmc*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
+        rep = sh("python tools/pmc_report.py 'gpurun_out/r6_pmc*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
         body += "== %s\n" % shp + derived(rep) + rep
-        for d in glob.glob(os.path.join(ROOT, "gpurun_out", "r4_pmc*_%s" % shp.replace(",", "_"))):
+        for d in glob.glob(os.path.join(ROOT, "gpurun_out", "r6_pmc*_%s" % shp.replace(",", "_"))):
             shutil.rmtree(d, ignore_errors=True)
     write(PREFIX + "_pmc_taps_lanes.txt",
           "rocprofv3 --pmc <set> --kernel-trace -- python tools/gpu_diag.py one --throughput-plan --prec bf16 --iters 6 --bs 1280 --shape <s>\n"
-          "(one pass per counter set; batch 1280 = the tiles of the bench's 20 MC sample lanes; contract_taps_kernel; tools/pmc_report.py)", body)
+          "(one pass per counter set, collected THIS round into fresh gpurun_out/r6_pmc* directories; batch 1280 = the tiles of the bench's 20 MC sample lanes; contract_taps_kernel; tools/pmc_report.py)", body)
+
+
+def step_cfg3():
+    """BASELINE cfg3 — dnn_to_bnn(ResNet18) Reparameterization bs 64, 16 MC samples as lanes: the bench command's own line and
+    per-launch table, its rocprofv3 kernel trace, and the SQ counters of contract_taps_kernel<bf16, Reparameterization, WIDE>"""
+    cmd = "python %s/bench.py --type Reparameterization --steps 16 --warmup 16 --no-extras --no-cpu-baseline --no-traffic" % ROOT
+    out = sh("timeout -k 5 400 " + cmd, timeout=900)
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    json.dump(json.loads(line), open(os.path.join(OUT, PREFIX + "_cfg3_bench_line.json"), "w"), indent=1)
+    d = json.load(open(os.path.join(ROOT, "gpurun_out", "bench_detail.json")))
+    r = d["roofline"]
+    body = "value %.1f %s  ms/step %.4f  (settled half of %d regions over %.2f s)  sustained %s\n" % (
+        d["value"], d["unit"], d["ms_per_step"], d["timed_regions"], d["timed_seconds"], json.dumps(d.get("sustained")))
+    body += "dominant kernel (13 stride-1 3x3 launches, sampling share included) %.4f of the bf16 MFMA peak (contraction only %.4f), e2e %.4f\n" % (
+        r["frac"], r["frac_contraction_only"], r["frac_e2e"])
+    for row in r["per_launch"]:
+        body += "  %-46s %8.1f us  %7.1f TFLOP/s  %5.2f TB/s  %s %.3f\n" % (row["launch"], row["us"], row["tflops"], row["tbs"], row["bound"], row["frac_incl_sampling"])
+    write(PREFIX + "_cfg3_per_launch.txt", cmd.replace(ROOT + "/", "") + "   (1 MI355X; per launch: 16 MC sample lanes, re-issued 10x in a hipGraph between HIP events)", body)
+    dd = os.path.join(ROOT, "gpurun_out", "r6_kt_cfg3")
+    shutil.rmtree(dd, ignore_errors=True)
+    sh("timeout -k 5 400 rocprofv3 --kernel-trace --stats -d %s -o kt -- %s --no-sustain" % (dd, cmd), cwd="/tmp", timeout=1200)
+    db = glob.glob(os.path.join(dd, "**", "*.db"), recursive=True)
+    write(PREFIX + "_cfg3_kernel_trace_stats.txt", "cd /tmp && rocprofv3 --kernel-trace --stats -- %s --no-sustain   (tools/trace_report.py on the result)" % cmd.replace(ROOT + "/", ""),
+          sh("python tools/trace_report.py %s" % db[0]) if db else "(no trace written)\n")
+    shutil.rmtree(dd, ignore_errors=True)
+    sets = ["SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES",
+            "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_MFMA",
+            "GRBM_GUI_ACTIVE"]
+    body = ""
+    for shp in SHAPES[:3]:
+        for i, s_ in enumerate(sets):
+            d_ = os.path.join(ROOT, "gpurun_out", "r6_pmc3_%d_%s" % (i, shp.replace(",", "_")))
+            shutil.rmtree(d_, ignore_errors=True)
+            sh("rocprofv3 --pmc %s --kernel-trace -d %s -o pmc -- python %s/tools/gpu_diag.py one --typ Reparameterization --throughput-plan --prec bf16 "
+               "--iters 6 --bs 1024 --shape %s" % (s_, d_, ROOT, shp), cwd="/tmp", timeout=400)
+        rep = sh("python tools/pmc_report.py 'gpurun_out/r6_pmc3_*_%s/pmc_results.db' --kernel taps" % shp.replace(",", "_"))
+        body += "== %s\n" % shp + derived(rep) + rep
+        for d_ in glob.glob(os.path.join(ROOT, "gpurun_out", "r6_pmc3_*_%s" % shp.replace(",", "_"))):
+            shutil.rmtree(d_, ignore_errors=True)
+    write(PREFIX + "_cfg3_pmc_taps.txt",
+          "rocprofv3 --pmc <set> --kernel-trace -- python tools/gpu_diag.py one --typ Reparameterization --throughput-plan --prec bf16 --iters 6 --bs 1024 --shape <s>\n"
+          "(one pass per counter set, collected this round into fresh r6_pmc3_* directories; batch 1024 = the tiles of cfg3's 16 MC sample lanes;\n"
+          "56x56: the narrow tile (one n-tile), 28x28 / 14x14: contract_taps_kernel<bf16, Reparameterization, WIDE>; tools/pmc_report.py)", body)
 
 
 def step_phase():
