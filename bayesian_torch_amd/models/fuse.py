@@ -29,6 +29,99 @@ def _is_var(m):
     return hasattr(m, "forward_fused")
 
 
+# ---- "is this module's forward the dataflow the fused forms assume?" — decided by RUNNING it, not by its class name -------------
+# Attribute names prove nothing about a forward (a pre-activation block has conv1 / bn1 / conv2 / bn2 / downsample too), and a
+# class-name list stops at the classes it knows.  A deep copy of the module on the CPU, in eval mode, is run twice on a small random
+# input — once through its CLASS's forward, once through the textbook dataflow below — and must agree.  The copy's rho parameters
+# are set to -40 first (sigma ~ 4e-18): its variational layers then compute with their means whatever noise they draw, so the two
+# runs do not have to call the layers in the same order.  A module that fails the probe is left alone, with a warning.
+def _out(o):
+    return o[0] if isinstance(o, tuple) else o
+
+
+def _textbook_block(m, x):
+    """reference models/deterministic/resnet_large.py:46-62 (BasicBlock), 85-105 (Bottleneck)"""
+    y = torch.relu(m.bn1(_out(m.conv1(x))))
+    y = m.bn2(_out(m.conv2(y)))
+    if hasattr(m, "conv3") and hasattr(m, "bn3"):
+        y = m.bn3(_out(m.conv3(torch.relu(y))))
+    idt = x if m.downsample is None else m.downsample(x)
+    return torch.relu(y + _out(idt))
+
+
+def _textbook_resnet(m, x):
+    """resnet_large.py:156-171"""
+    x = m.maxpool(torch.relu(m.bn1(_out(m.conv1(x)))))
+    x = m.layer4(m.layer3(m.layer2(m.layer1(x))))
+    return _out(m.fc(m.avgpool(x).flatten(1)))
+
+
+def _behaves_like(m, ref_fn, shapes):
+    import copy
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            probe = copy.deepcopy(m).to("cpu").float().eval()
+            with torch.no_grad():
+                for name, prm in probe.named_parameters():
+                    if name.rsplit(".", 1)[-1].startswith("rho_"):
+                        prm.fill_(-40.0)
+        except Exception:  # noqa — a module that cannot be copied cannot be probed: not fused
+            return False
+        for shp in shapes:
+            try:
+                with torch.no_grad(), torch.random.fork_rng(devices=[]):
+                    x = torch.randn(*shp, generator=torch.Generator().manual_seed(7))
+                    torch.manual_seed(1234)
+                    a = _out(type(probe).forward(probe, x))
+                    torch.manual_seed(1234)
+                    b = ref_fn(probe, x)
+                return bool(a.shape == b.shape and torch.allclose(a, b, rtol=1e-5, atol=1e-6))
+            except Exception:  # noqa — e.g. an input too small for the model's pooling: try the next shape
+                continue
+    return False
+
+
+def _cin(conv):
+    for k in ("in_channels", "in_features"):
+        if hasattr(conv, k):
+            return int(getattr(conv, k))
+    return None
+
+
+def block_is_textbook(m):
+    """conv1 / bn1 / conv2 / bn2 [/ conv3 / bn3] / downsample with the reference's BasicBlock / Bottleneck dataflow (probed, cached)"""
+    if "_btx_textbook" in m.__dict__:
+        return m.__dict__["_btx_textbook"]
+    ok = all(hasattr(m, k) for k in ("conv1", "bn1", "conv2", "bn2", "downsample")) and _cin(m.conv1) is not None
+    if ok:
+        ok = _behaves_like(m, _textbook_block, [(2, _cin(m.conv1), 8, 8)])
+        if not ok:
+            import warnings
+            warnings.warn("bayesian_torch_amd.models.fuse: %s has conv1/bn1/conv2/bn2/downsample but not the ResNet block dataflow "
+                          "(relu(bn(conv)) ... + identity, relu): left unfused" % type(m).__name__)
+    object.__setattr__(m, "_btx_textbook", bool(ok))
+    return bool(ok)
+
+
+def resnet_is_textbook(model):
+    """conv1 -> bn1 -> relu -> maxpool -> layer1..4 -> avgpool -> flatten -> fc (probed on a 64^2, then a 224^2 input; cached)"""
+    if "_btx_textbook" in model.__dict__:
+        return model.__dict__["_btx_textbook"]
+    ok = all(hasattr(model, k) for k in ("conv1", "bn1", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool", "fc"))
+    ok = ok and _cin(model.conv1) is not None
+    if ok:
+        c = _cin(model.conv1)
+        ok = _behaves_like(model, _textbook_resnet, [(1, c, 64, 64), (1, c, 224, 224)])
+        if not ok:
+            import warnings
+            warnings.warn("bayesian_torch_amd.models.fuse: %s has a ResNet's attributes but not its forward: stem / head left unfused"
+                          % type(model).__name__)
+    object.__setattr__(model, "_btx_textbook", bool(ok))
+    return bool(ok)
+
+
 class _Folded:
     """conv (variational) + eval-mode BN folded into the conv's store.  A plain object, NOT an nn.Module: it is attached
     with object.__setattr__, so the module tree — and with it state_dict() / load_state_dict() keys, .to(), .parameters()
@@ -76,7 +169,8 @@ def fuse_resnet(model):
     n = 0
     for m in model.modules():
         names = [k for k in ("conv1", "bn1", "conv2", "bn2") if hasattr(m, k)]
-        if len(names) == 4 and hasattr(m, "downsample") and _is_var(m.conv1) and _is_var(m.conv2):
+        if (len(names) == 4 and hasattr(m, "downsample") and _is_var(m.conv1) and _is_var(m.conv2)
+                and ("_f1" in m.__dict__ or block_is_textbook(m))):
             object.__setattr__(m, "_f1", _Folded(m.conv1, m.bn1))
             object.__setattr__(m, "_f2", _Folded(m.conv2, m.bn2))
             if hasattr(m, "conv3") and _is_var(m.conv3):
@@ -89,7 +183,8 @@ def fuse_resnet(model):
                 object.__setattr__(m, "_fds", _Folded(ds[0], ds[1]))
             n += 1
     # stem: conv1 -> bn1 -> relu -> maxpool
-    if hasattr(model, "conv1") and hasattr(model, "bn1") and hasattr(model, "maxpool") and _is_var(model.conv1):
+    if (hasattr(model, "conv1") and hasattr(model, "bn1") and hasattr(model, "maxpool") and _is_var(model.conv1)
+            and ("_stem" in model.__dict__ or resnet_is_textbook(model))):
         object.__setattr__(model, "_stem", _Folded(model.conv1, model.bn1))
 
         def pool(mp, y):
@@ -161,7 +256,6 @@ def _bottleneck_forward_train(self, x):
     return _ag.bn_act(self.bn3, self.conv3(y), residual=idt)
 
 
-_KNOWN = ("bayesian_torch_amd.models.resnet", "torchvision.models.resnet")
 _BN_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
 
 
@@ -210,11 +304,12 @@ def _resnet_forward_train(self, x):
 
 
 def _plain_block(m):
-    """a block whose forward is KNOWN to be the textbook one — conv/bn pairs, one shared ReLU, `downsample` — i.e. the classes of
-    models/resnet.py and torchvision.models.resnet (same attribute names on a user's own block prove nothing about its forward)"""
-    t = type(m)
-    return (t.__module__ in _KNOWN and t.__name__ in ("BasicBlock", "Bottleneck") and isinstance(getattr(m, "relu", None), nn.ReLU)
-            and all(isinstance(getattr(m, k, None), nn.modules.batchnorm._BatchNorm) for k in ("bn1", "bn2")))
+    """a block whose forward IS the textbook one — conv / bn pairs, ReLU, `downsample` — decided by running it (block_is_textbook):
+    the classes of models/resnet.py and torchvision.models.resnet pass, so does a user's own block with the same dataflow; a block
+    that merely has the same attribute names does not"""
+    return (isinstance(getattr(m, "relu", None), nn.ReLU)
+            and all(isinstance(getattr(m, k, None), nn.modules.batchnorm._BatchNorm) for k in ("bn1", "bn2"))
+            and block_is_textbook(m))
 
 
 def hip_batchnorm(model, fuse_act=True):
@@ -249,8 +344,9 @@ def hip_batchnorm(model, fuse_act=True):
                 object.__setattr__(m, "_btx_fwd_eval", m.forward)
                 three = hasattr(m, "conv3") and hasattr(m, "bn3")
                 m.forward = types.MethodType(_bottleneck_forward_train if three else _basic_forward_train, m)
-        if (type(model).__module__ in _KNOWN and type(model).__name__ == "ResNet" and isinstance(getattr(model, "relu", None), nn.ReLU)
-                and "_btx_fwd_eval" not in model.__dict__):
+        if (isinstance(getattr(model, "relu", None), nn.ReLU) and "_btx_fwd_eval" not in model.__dict__
+                and all(hasattr(model, k) for k in ("conv1", "bn1", "maxpool", "layer1", "layer4", "avgpool", "fc"))
+                and resnet_is_textbook(model)):
             object.__setattr__(model, "_btx_fwd_eval", model.forward)
             model.forward = types.MethodType(_resnet_forward_train, model)
     return n

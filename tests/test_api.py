@@ -254,6 +254,50 @@ def test_hip_batchnorm_patch_leaves_cpu_and_eval_forwards_alone():
     assert hip_batchnorm(m) == 2 and "_btx_fwd_eval" not in m[0].__dict__
 
 
+def test_fused_forms_are_chosen_by_running_the_block_not_by_its_class_name():
+    """fuse_resnet / hip_batchnorm decide by a behavioural probe (models/fuse.py block_is_textbook): a user's own block class with the
+    ResNet dataflow is fused, a pre-activation block with the same attribute names is left alone (and warned about) — its outputs
+    must not change"""
+    import warnings
+    import bayesian_torch_amd as bt
+    from bayesian_torch_amd.models.fuse import fuse_resnet, hip_batchnorm, block_is_textbook
+    params = dict(prior_mu=0.0, prior_sigma=1.0, posterior_mu_init=0.0, posterior_rho_init=-3.0, type="Reparameterization",
+                  moped_enable=False, moped_delta=0.5)
+
+    class MyBlock(torch.nn.Module):               # not models.resnet / torchvision: same dataflow, identity evaluated last
+        def __init__(self, c, pre):
+            super().__init__()
+            self.conv1, self.bn1 = torch.nn.Conv2d(c, c, 3, padding=1, bias=False), torch.nn.BatchNorm2d(c)
+            self.conv2, self.bn2 = torch.nn.Conv2d(c, c, 3, padding=1, bias=False), torch.nn.BatchNorm2d(c)
+            self.relu, self.downsample, self.pre = torch.nn.ReLU(), None, pre
+
+        def forward(self, x):
+            if self.pre:                          # pre-activation: bn -> relu -> conv
+                return self.conv2(self.relu(self.bn2(self.conv1(self.relu(self.bn1(x)))))) + x
+            y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+            return self.relu(y + x)
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(MyBlock(8, False), MyBlock(8, True))
+    bt.dnn_to_bnn(net, params)
+    net.eval()
+    for bn in (net[0].bn1, net[0].bn2, net[1].bn1, net[1].bn2):
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(2, 8, 6, 6)
+    torch.manual_seed(3)
+    ref = net(x)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert block_is_textbook(net[0]) and not block_is_textbook(net[1])
+        assert fuse_resnet(net) == 1              # only the textbook block
+        assert any("left unfused" in str(i.message) for i in w)
+    assert "_f1" in net[0].__dict__ and "_f1" not in net[1].__dict__
+    torch.manual_seed(3)
+    assert torch.allclose(net(x), ref, rtol=1e-5, atol=1e-6)   # CPU: the folded form == BN after conv; the other block untouched
+    assert hip_batchnorm(net) == 4
+    assert "_btx_fwd_eval" in net[0].__dict__ and "_btx_fwd_eval" not in net[1].__dict__
+
+
 def test_hip_batchnorm_survives_deepcopy_pickle_and_skips_sync_batchnorm():
     """a deep copy of a patched model (EMA / AveragedModel, eval copies) must normalise with ITS OWN weights and running
     estimates, torch.save(model) must work, nn.SyncBatchNorm (cross-rank statistics) and the Lazy* variants keep torch's forward"""
