@@ -46,6 +46,9 @@ namespace btx {
 #ifndef BTX_STEM_STEPS
 #define BTX_STEM_STEPS 1  // step layout of a Flipout K phase (run_k): 0 = round 2's (sign copy + mean) | delta 0-3 | delta 4-6,
 #endif                    // 1 = sign copy | mean | delta
+#ifndef BTX_STEM_PASS3
+#define BTX_STEM_PASS3 1  // fragments two stages ahead in the Reparameterization pass and in Flipout's mean pass (run_pass3)
+#endif
 constexpr int SP_HROWS = 2;  // conv rows per half tile
 constexpr int SP_LROWS = 3;  // LDS rows (64 channels each) of the store side: r0, r1 and the carry row
 constexpr int SP_MAXST = 7;  // K-stages whose weight tiles stay resident
@@ -108,6 +111,12 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
 #define SP_T(var) { __builtin_amdgcn_sched_barrier(0); const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); var += n_ - tr_x; tr_x = n_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define SP_T(var)
+#endif
+#if defined(BTX_PT_TRACE) && defined(BTX_SP_TR2)  // the passes of a Flipout K role without their barrier waits (tr[0] mean, tr[1] delta, tr[2] waits)
+  uint32_t tr_m = 0, tr_d = 0, tr_w = 0, tr_y = 0;
+#define SP_T2(var) { __builtin_amdgcn_sched_barrier(0); const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); var += n_ - tr_y; tr_y = n_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define SP_T2(var)
 #endif
 #define SP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
   const RngLive rl = rng_live<KIND>(p);
@@ -295,6 +304,85 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     if (s < nstages) iter(s, fb, fa, std::false_type{});
     return nb;
   };
+  // The same pass with the fragments requested TWO stages ahead (round 6).  Measured (profiles/r06_experiments.txt E6): a pass
+  // takes as long without its MFMAs as with them — a stage's eight fragment reads come back after ~500 cycles (the store group's
+  // LDS traffic and the patch DMA queue in front of them), its eight MFMAs cover 256: with one stage of lead every stage exposes
+  // half a round trip.  Three register sets give two stages (512 cycles) of lead.  What makes it work as C++:
+  //   * never more than 15 LDS requests in flight — the counter has 4 bits, and a compiler whose wait insertion cannot count
+  //     what is outstanding waits for everything in front of every MFMA: the 8th request of a stage goes out behind an
+  //     lgkmcnt(14), i.e. after the oldest request of the stage in front has returned;
+  //   * every stage requests "the stage after next" — the last two as well (reads of LDS bytes nobody uses): with `if` around
+  //     requests and waits the wait insertion also walks the paths that take one branch and skip the other;
+  //   * the waits are s_waitcnt BUILTINS (instructions the wait insertion sees), pinned by sched_barrier.
+  // Needs (nstages - 1) % 3 == 0 (7 for the ResNet stem: one body starts the accumulators, one body per register set rotates);
+  // one accumulator set may be live beside the three fragment sets (Reparameterization; Flipout's mean pass, whose delta
+  // accumulators are not yet live), not two.
+  auto run_pass3 = [&](const unsigned char* abase, int woff, f32x16 (&acc)[2][2], int bs0, int bs1) __attribute__((always_inline)) {
+    int l_j = 0, l_row = 0, l_b = 0, l_s = 0;  // the stage whose fragments are requested next
+    // requests 0..7 of a stage: (k-half, a0, a1, w0, w1) — the first k-half's fragments first
+    auto req = [&](SpFrag& f, auto i_tag) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_tag)::value, kk = i >> 2, j = i & 3;
+      const int row = 2 * kk + h;
+      if constexpr (j < 2) f.a[kk][j] = *(const u32x4*)(abase + l_b + eo[j] + row * 16);
+      else f.w[kk][j - 2] = *(const u32x4*)(smem + W_OFF + l_s * DW_STAGE + woff + (row * BN + (j - 2) * 32 + l31) * 16);
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+      ++l_s;
+      l_b += BK * 2;
+      if (++l_j == spr) { l_j = 0; l_row += RowE * 2; l_b = l_row; }
+    };
+    auto mma_half = [&](const SpFrag& f, auto kk_tag, auto zero_tag) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kk_tag)::value;
+      constexpr bool ZERO = decltype(zero_tag)::value;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.w[kk][ni]),
+                                                               __builtin_bit_cast(bf16x8, f.a[kk][mi]),
+                                                               (ZERO && kk == 0) ? zc : acc[mi][ni], 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    int nb = 0;
+    // stage s_ from `cur`; `pre` takes the fragments of stage s_ + 2.  In flight at the top: the 8 requests of stage s_ + 1.
+    auto stage = [&](SpFrag& cur, SpFrag& pre, int s_, auto zero_tag) __attribute__((always_inline)) {
+      if (s_ == bs0 || s_ == bs1) { SP_BARRIER(); ++nb; }
+      __builtin_amdgcn_s_waitcnt(0xc07f | (8 << 8));   // lgkmcnt(8): stage s_ is here
+      __builtin_amdgcn_sched_barrier(0);
+      static_for_ep<0, 7>([&](auto i_tag) __attribute__((always_inline)) { req(pre, i_tag); });  // 8 + 7 = 15 in flight
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(cur, I0{}, zero_tag);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xc07f | (14 << 8));  // lgkmcnt(14): the oldest of them has returned
+      __builtin_amdgcn_sched_barrier(0);
+      req(pre, std::integral_constant<int, 7>{});
+      advance();
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(cur, I1{}, zero_tag);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    SpFrag f0, f1, f2;
+    static_for_ep<0, 8>([&](auto i_tag) __attribute__((always_inline)) { req(f0, i_tag); });
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    static_for_ep<0, 7>([&](auto i_tag) __attribute__((always_inline)) { req(f1, i_tag); });
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f | (14 << 8));
+    __builtin_amdgcn_sched_barrier(0);
+    req(f1, std::integral_constant<int, 7>{});
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    stage(f0, f2, 0, std::true_type{});
+    for (int s_ = 1; s_ < nstages; s_ += 3) {
+      stage(f1, f0, s_, std::false_type{});
+      stage(f2, f1, s_ + 1, std::false_type{});
+      stage(f0, f2, s_ + 2, std::false_type{});
+    }
+    return nb;
+  };
   // the K role of one phase: three workgroup barriers (the store group runs its three steps beside it)
   auto run_k = [&](int u, auto mia_tag) __attribute__((always_inline)) {
     const unsigned char* raw = smem + A_OFF + (u & 1) * p.pt_astage;
@@ -312,14 +400,20 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       // (Also measured, not kept: the sign copy sliced into the shadow of the mean pass's MFMAs with the delta pass in two
       // steps: 1350 us; the copy's LDS reads four chunks deep instead of one at a time: no change.)
       SP_BARRIER();  // the signed copy is complete (build_signed ran before this call)
-      run_pass(raw, 0, accm, -1, -1, mia_tag);
+      SP_T2(tr_w)
+      if (decltype(mia_tag)::value == 2 && BTX_STEM_PASS3 && (nstages - 1) % 3 == 0) run_pass3(raw, 0, accm, -1, -1);  // (accd is not live yet)
+      else run_pass(raw, 0, accm, -1, -1, mia_tag);
+      SP_T2(tr_m)
       SP_BARRIER();
+      SP_T2(tr_w)
       run_pass(smem + X_OFF, 4096, accd, -1, -1, mia_tag);
+      SP_T2(tr_d)
       nb = 2;
 #endif
     } else {
       const int t3 = (nstages + 2) / 3;
-      nb = run_pass(raw, 0, accm, t3, 2 * t3, mia_tag);
+      if (decltype(mia_tag)::value == 2 && BTX_STEM_PASS3 && (nstages - 1) % 3 == 0) nb = run_pass3(raw, 0, accm, t3, 2 * t3);
+      else nb = run_pass(raw, 0, accm, t3, 2 * t3, mia_tag);
     }
     for (; nb < 2; ++nb) SP_BARRIER();
   };
@@ -523,12 +617,16 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     if (lane == 0) {
       uint32_t* tr = (uint32_t*)p.trace + (size_t)(blockIdx.x * 8 + wave) * 8;
       tr[0] = tr_pro; tr[1] = tr_bld; tr[2] = tr_k; tr[3] = tr_st; tr[4] = tr_pool; tr[5] = tr_t3 - tr_t0; tr[6] = tr_bar;
+#ifdef BTX_SP_TR2
+      tr[0] = tr_m; tr[1] = tr_d; tr[6] = tr_w;
+#endif
       tr[7] = tr_t0;
     }
   }
 #endif
 }
 #undef SP_T
+#undef SP_T2
 #undef SP_BARRIER
 
 static int launch_stem_pool_impl(int kind, const ContractParams& p, int nwg, hipStream_t st) {
