@@ -918,8 +918,9 @@ static bool make_patch_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t 
 
 // Tile plan of the stride-2 form of the tap-unrolled kernel (btx_contract_taps2.h): 3x3 / stride 2 / pad 1, one phase
 // plane of (R+1) x (Wo+1) pixels per image of the tile in each of three LDS slots.
-static bool make_patch2_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, Plan* pl, PatchPlan* pt) {
+static bool make_patch2_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t flags, Plan* pl, PatchPlan* pt, int kind = -1) {
   if (flags & (BTX_FLAG_TRANSPOSED | BTX_FLAG_ROWFUSE)) return false;
+  pt->wide = 0;
   if (tune_env("BTX_NO_TAPS2")) return false;  // A/B: the per-tap LDS-DMA kernel instead
   if (make_plan(g, prec, flags, DBM, pl)) return false;
   if (!dma_shape_ok(g, act_dtype, prec, *pl)) return false;
@@ -943,7 +944,13 @@ static bool make_patch2_plan(const BtxGeom* g, int act_dtype, int prec, uint32_t
   const int bk = NG * (prec == BTX_PREC_BF16 ? 8 : 4);
   const int ncb = pl->Cg / bk;
   pl->mtiles = ((g->NB + pt->G - 1) / pt->G) * pt->rtiles;
-  const long long base1 = (long long)pl->mtiles * pl->ntiles * g->groups;
+  // Reparameterization: 64-pixel x 128-channel wave tiles (contract_taps2_kernel<..., WIDE>) under the conditions of the stride-1 plan
+  if (kind == BTX_KIND_REPARAM && prec == BTX_PREC_BF16 && act_dtype == BTX_ACT_BF16 && (pl->Ng % 128) == 0 &&
+      (long long)pl->mtiles * (pl->ntiles / 2) * g->groups * plan_lanes(flags) >= slots4() && !tune_env("BTX_NO_WIDE")) {
+    pt->wide = 1;
+    if (pt->lds < 4 * PT_EP_WAVE + 2048) { pt->lds = 4 * PT_EP_WAVE + 2048; pt->lds_g = (pt->lds + 15) & ~15; }
+  }
+  const long long base1 = (long long)pl->mtiles * (pt->wide ? pl->ntiles / 2 : pl->ntiles) * g->groups;
   const long long base = base1 * plan_lanes(flags);
   pt->taps = 332;
   pt->kg = 1;
@@ -1094,7 +1101,8 @@ size_t btx_contract_workspace_bytes(const BtxGeom* g, int kind, int act_dtype, i
     size_t wc = pad256(plan_ws(c, g, lanes)) + patch_wt_bytes(c, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
     Plan cw;
     PatchPlan ptw;  // the wide Reparameterization tile halves the grid and may split K differently
-    if (make_patch_plan(g, act_dtype, prec, flags, &cw, &ptw, BTX_KIND_REPARAM) && ptw.wide) {
+    if ((make_patch_plan(g, act_dtype, prec, flags, &cw, &ptw, BTX_KIND_REPARAM) ||
+         make_patch2_plan(g, act_dtype, prec, flags, &cw, &ptw, BTX_KIND_REPARAM)) && ptw.wide) {
       const size_t ww = pad256(plan_ws(cw, g, lanes)) + patch_wt_bytes(cw, g, BTX_KIND_FLIPOUT, prec, nullptr, lanes);
       if (ww > wc) wc = ww;
     }
@@ -1248,7 +1256,7 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
   if (dma && !rowfuse && !no_patch) {
     Plan pp;
     if (make_patch_plan(g, act_dtype, prec, flags, &pp, &pt, kind)) { pl = pp; patch = true; }
-    else if (make_patch2_plan(g, act_dtype, prec, flags, &pp, &pt)) { pl = pp; patch = true; }
+    else if (make_patch2_plan(g, act_dtype, prec, flags, &pp, &pt, kind)) { pl = pp; patch = true; }
   }
   int out_bf16 = (act_dtype == BTX_ACT_BF16) ? 1 : 0;
   if (flags & (BTX_FLAG_OUT_F32 | BTX_FLAG_OUT_BF16)) {
@@ -1431,7 +1439,7 @@ static int contract_fwd_impl(int kind, const BtxGeom* g, const void* x, const fl
     p.pt_rtiles = pt.rtiles; p.pt_nw = pt.nw; p.pt_mi = pt.mi; p.pt_astage = pt.astage; p.pt_lds = pt.lds;
     { const char* tn = tune_env("BTX_TAPS_TUNE"); p.pt_tune = tn ? atoi(tn) : 0; }
     p.pt_taps = pt.taps; p.pt_kg = pt.kg; p.pt_lds_g = pt.lds_g;
-    p.pt_wide = (pt.taps == 33) ? pt.wide : 0;
+    p.pt_wide = (pt.taps == 33 || pt.taps == 332) ? pt.wide : 0;
     if (p.pt_wide) {  // the grid's n-tiles are pairs of weight tiles (p.ntiles stays the tile count of the weight layout)
       p.fd_ntiles = make_fastdiv((uint32_t)(pl.ntiles / 2));
       p.fd_inner = make_fastdiv((uint32_t)((pl.ntiles / 2) * g->groups * pl.ksplits));

@@ -367,9 +367,9 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
   int rc = launch_presample_impl<PREC>(kind, p, st);
   if (rc) return rc;
   if (p.pt_taps == 332) {  // 3x3 / stride 2 / pad 1: the phase-plane form of the tap-unrolled kernel (btx_contract_taps2.h)
-#define BTX_LAUNCH_T2(KIND)                                                                                       \
+#define BTX_LAUNCH_T2(KIND, ...)                                                                                  \
   do {                                                                                                            \
-    auto kfn = contract_taps2_kernel<PREC, KIND>;                                                                 \
+    auto kfn = contract_taps2_kernel<PREC, KIND, ##__VA_ARGS__>;                                                  \
     static bool attr_done = false;                                                                                \
     if (!attr_done) {                                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);   \
@@ -378,6 +378,12 @@ static int launch_contract_patch_impl(int kind, const ContractParams& p, int nwg
     }                                                                                                             \
     hipLaunchKernelGGL(kfn, dim3(nwg), dim3(256), p.pt_lds, st, p);                                               \
   } while (0)
+    if constexpr (PREC == 1) {
+      if (p.pt_wide && kind == 0) {  // Reparameterization on 64 x 128 wave tiles
+        BTX_LAUNCH_T2(0, true);
+        return (int)hipGetLastError();
+      }
+    }
     if (kind == 0) BTX_LAUNCH_T2(0); else BTX_LAUNCH_T2(1);
 #undef BTX_LAUNCH_T2
     return (int)hipGetLastError();

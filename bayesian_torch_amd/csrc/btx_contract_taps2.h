@@ -44,11 +44,17 @@ constexpr int t2_np(int s) { return (s == 0 || s == 5 || s == 7) ? 3 : ((s == 1 
 constexpr int t2_p0(int s) { return (s == 1 || s == 6 || s == 8) ? 3 : 0; }          // first piece fetched in the stage
 constexpr int t2_fseq(int s) { return s < 2 ? 2 : (s == 4 ? 3 : (s < 7 ? 4 : 5)); }  // plane it belongs to (4, 5: next block)
 
-template <int PREC, int KIND>
+// WIDE (Reparameterization, bf16; ContractParams.pt_wide): the wave's tile is 64 pixels x 128 channels as in
+// contract_taps_kernel<..., WIDE> — the stage's second weight tile (n-tile 2 * ntile + 1) in the LDS slot of Flipout's delta tile,
+// the same activation fragments, no sign masks, two 64-channel tiles stored one after the other.  A stride-2 stage pays 3.3x the
+// patch DMA per MFMA of a stride-1 one (four phase planes per output pixel): sharing the planes between two n-tiles halves it.
+template <int PREC, int KIND, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractParams) {
+  static_assert(!WIDE || (PREC == 1 && KIND == 0), "wide tile: bf16 Reparameterization");
   BTX_SECTION_PARAMS(p, logical);  // prologue + K loop; the store side has its own view (btx_contract.h)
   constexpr int NW = 4, NT = 256, MI = 2, T = T2_T, MAXNI = T2_MAXNI, WD = T2_WD;
-  constexpr int WOPS = (KIND == 1) ? 2 : 1;  // weight DMA instructions per wave per stage
+  constexpr int K2 = (KIND == 1 || WIDE) ? 1 : 0;  // two weight tiles per stage and two accumulator sets
+  constexpr int WOPS = K2 ? 2 : 1;  // weight DMA instructions per wave per stage
   using ACT = typename std::conditional<PREC == 1, __bf16, float>::type;
   constexpr int G = (PREC == 1) ? 8 : 4;
   constexpr int BK = NG * G;
@@ -65,10 +71,11 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   uint32_t u_mtile, u_rem, u_split, u_ntile, u_group, u_t;
+  const uint32_t ntg = (uint32_t)(WIDE ? p.ntiles >> 1 : p.ntiles);  // n-tiles of the grid (wide: fd_ntiles / fd_inner are made for it)
   if (p.wg_order) fdivmod((uint32_t)logical, p.fd_mtiles, (uint32_t)p.mtiles, u_rem, u_mtile);
-  else fdivmod((uint32_t)logical, p.fd_inner, (uint32_t)(p.ntiles * p.groups * p.ksplits), u_mtile, u_rem);
+  else fdivmod((uint32_t)logical, p.fd_inner, ntg * (uint32_t)(p.groups * p.ksplits), u_mtile, u_rem);
   fdivmod(u_rem, p.fd_ksplits, (uint32_t)p.ksplits, u_t, u_split);
-  fdivmod(u_t, p.fd_ntiles, (uint32_t)p.ntiles, u_group, u_ntile);
+  fdivmod(u_t, p.fd_ntiles, ntg, u_group, u_ntile);
   const int mtile = (int)u_mtile, split = (int)u_split, ntile = (int)u_ntile, group = (int)u_group;
 
   uint32_t u_ig, u_rt;
@@ -87,7 +94,8 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
 
   // ---- weight loader (as in btx_contract_taps.h): wave w fetches row w of the stage's mu tile (+ row w of its delta tile)
   const uint32_t w_voff = (uint32_t)lane * 16u + (uint32_t)wave * 1024u;
-  const uint32_t w_sbase = (uint32_t)(group * p.ntiles + ntile) * (uint32_t)(p.K / G) * 1024u;
+  const uint32_t w_sbase = (uint32_t)(group * p.ntiles + (WIDE ? 2 * ntile : ntile)) * (uint32_t)(p.K / G) * 1024u;
+  const uint32_t w_second = WIDE ? (uint32_t)(p.K / G) * 1024u : p.wt_delta_off;  // the stage's second tile: next n-tile | delta
   const uint32_t CgG = (uint32_t)(p.Cg / G);
   const int w_lds = PT_W_OFF + wave * 1024;
   int wslot = 0;  // ring slot of the stage being multiplied
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
     const uint32_t soff = w_sbase + (tap * CgG + cb * (uint32_t)NG) * 1024u;
     unsigned char* ld = smem + w_lds + slot * DW_STAGE;
     dma16s(wt_rsrc, w_voff, soff, ld);
-    if constexpr (KIND == 1) dma16s(wt_rsrc, w_voff, soff + p.wt_delta_off, ld + 4096);
+    if constexpr (K2) dma16s(wt_rsrc, w_voff, soff + w_second, ld + 4096);
   };
   if (ncb > 0) issue_w((uint32_t)t2_tap(0), (uint32_t)cb0, 0);
 
@@ -278,14 +286,14 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
           // 3. this stage's fragments (no prefetch across the stage boundary: the weight ring is three deep — W(s+1) is only
           //    guaranteed at the end of this stage — and the other block of the CU covers the LDS latency)
           DeltaFrag df;
-          load_delta<KIND>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
+          load_delta<K2>(df, smem + PT_W_OFF + wslot * DW_STAGE, l31, h);
           {
             constexpr int TP = t2_tap(s);
             const int so = slot_of(t2_seq(s));
             load_frag(fa, so * a_stage, so * s_stage, ((TP / 3) == 2 ? Wp : 0) + ((TP % 3) == 2 ? 1 : 0), wslot, mia_tag);
           }
           // 4. multiply
-          stage_mma<PREC, KIND, MI, MIA>(fa, df, accm, accd, l31, h);
+          stage_mma<PREC, K2, MI, MIA, false, KIND == 1>(fa, df, accm, accd, l31, h);
           // 5. everything issued before this stage has landed (W(s+1), and any plane that starts at s+1); meet the others
           if (!last) end_stage<WOPS + NP>();
           else end_stage<((s + 2 < T) ? WOPS : 0) + ((t2_fseq(s) < 4) ? NP : 0)>();
@@ -307,6 +315,19 @@ __global__ __launch_bounds__(256, 2) void contract_taps2_kernel(const ContractPa
     const int nimg = min(pe.pt_G, pe.NB - img0), nrow = min(pe.pt_R, pe.Ho - row0);
     const int nvalid = nimg * nrow * pe.Wo;
     const uint32_t m0 = (uint32_t)(img0 * pe.Ho + row0) * (uint32_t)pe.Wo;
+    if constexpr (WIDE) {  // as in contract_taps_kernel: both tiles' constants first, one workgroup barrier
+      float* const ba0 = (float*)(smem + NW * PT_EP_WAVE);
+      float* const ba1 = ba0 + 4 * BN;
+      const bool has_bias = (split == 0) && (pe.mu_b != nullptr);
+      const bool has_aff = (pe.ksplits == 1) && ((pe.ep_scale != nullptr) || (pe.ep_shift != nullptr));
+      if (has_bias || has_aff) {
+        if (tid < 64) ep_fill_constants<0>(pe, rl, ba0, tid, 2 * ntile, group, has_bias, has_aff);
+        else if (tid < 128) ep_fill_constants<0>(pe, rl, ba1, tid - 64, 2 * ntile + 1, group, has_bias, has_aff);
+      }
+      __syncthreads();
+      staged_epilogue<0, NW>(pe, rl, accm, accm, smem, tid, wave, lane, 2 * ntile, group, split, m0, nvalid, nullptr, -1, true, ba0);
+      staged_epilogue<0, NW>(pe, rl, accd, accd, smem, tid, wave, lane, 2 * ntile + 1, group, split, m0, nvalid, nullptr, -1, true, ba1);
+    } else
     staged_epilogue<KIND, NW>(pe, rl, accm, accd, smem, tid, wave, lane, ntile, group, split, m0, nvalid);
   }
 }

@@ -265,6 +265,8 @@ CPU_CASES = [
     ("reparam_28", "Conv2dReparameterization", dict(in_channels=128, out_channels=128, kernel_size=3, padding=1, bias=False), (64, 128, 28, 28)),
     # 784 pixel tiles x 1 pair of n-tiles: the wide Reparameterization tile (64 px x 128 ch per wave) in a single launch, with bias
     ("reparam_wide_56", "Conv2dReparameterization", dict(in_channels=64, out_channels=128, kernel_size=3, padding=1, bias=True), (64, 64, 56, 56)),
+    # stride 2, 512 pixel tiles x 1 pair of n-tiles: the wide tile of the phase-plane kernel in a single launch
+    ("reparam_wide_s2", "Conv2dReparameterization", dict(in_channels=64, out_channels=128, kernel_size=3, stride=2, padding=1, bias=False), (128, 64, 56, 56)),
 ]
 
 

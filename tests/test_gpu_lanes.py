@@ -31,6 +31,8 @@ LAYER_CASES = [
     # launch of the same layer keeps the narrow tile — same K order, so still bit for bit
     ("Conv2dReparameterization", dict(in_channels=64, out_channels=128, kernel_size=3, padding=1, bias=True), (64, 64, 28, 28)),
     ("Conv2dReparameterization", dict(in_channels=128, out_channels=256, kernel_size=3, padding=1, bias=False), (48, 128, 28, 28)),
+    # the same for the stride-2 kernel (contract_taps2_kernel<..., WIDE>): 256 pixel tiles per lane, 3 lanes -> wide; alone -> narrow
+    ("Conv2dReparameterization", dict(in_channels=64, out_channels=128, kernel_size=3, stride=2, padding=1, bias=True), (64, 64, 56, 56)),
     ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=3, stride=2, padding=1, bias=False), (4, 64, 28, 28)),  # taps2
     ("Conv2dFlipout", dict(in_channels=64, out_channels=128, kernel_size=1, stride=2, bias=False), (4, 64, 28, 28)),   # LDS-DMA kernel
     ("Conv2dFlipout", dict(in_channels=32, out_channels=32, kernel_size=5, padding=2, bias=False), (2, 32, 12, 12)),    # run-time-tap patch kernel
