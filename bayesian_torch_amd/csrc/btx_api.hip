@@ -1035,7 +1035,7 @@ static bool make_stem_pool_plan(const BtxGeom* g, int act_dtype, int prec, const
   const long long sbytes = ((pb / 2 + 31) / 32 + 3) * 4;
   const long long sb16 = (sbytes + 127) / 128 * 128;  // keeps the store-side rows 128-byte aligned (chunk swizzle in address bits)
   // weights | raw patch x2 | signed patch copy | sign words x2 | store-side rows r0, r1, carry (128 B per pixel) | constants
-  const long long lds = (long long)nstages * 8192 + 3 * astage + 2 * sb16 + 3LL * pl.Wo * 128 + 1024;
+  const long long lds = (long long)nstages * 8192 + 3 * astage + 2 * sb16 + 3LL * pl.Wo * 128 + 1024 + 64;  // (+ the pool's two `ninf` chunks)
   if (lds > 163840) return false;
   // bands: about one workgroup per CU (every band pays two phases of fill / drain, a closing one-row half tile and the
   // fetch of the layer's weight tiles).  With MC sample lanes the launch has `lanes` times the (image, n-tile) units, so the
