@@ -46,6 +46,12 @@ namespace btx {
 #ifndef BTX_STEM_STEPS
 #define BTX_STEM_STEPS 1  // step layout of a Flipout K phase (run_k): 0 = round 2's (sign copy + mean) | delta 0-3 | delta 4-6,
 #endif                    // 1 = sign copy | mean | delta
+#ifndef BTX_STEM_NB
+#define BTX_STEM_NB 1  // workgroup barriers INSIDE a phase (besides its closing one).  2 (rounds 2-5): sign copy | mean | delta against
+#endif                 // stage 0-31 | stage 32-63 | pool.  1 (round 6): [copy +] first part | rest against staging | pool — the barrier between
+                       // the two staging halves guarded nothing (the pool is what reads the rows), and with the store role's steps now 2.1k |
+                       // 1.6k cycles (Reparameterization) the three-way split left the K role's first third (patch DMA issue + stages) alone
+                       // on the critical path
 #ifndef BTX_STEM_PASS3
 #define BTX_STEM_PASS3 1  // fragments two stages ahead in the Reparameterization pass and in Flipout's mean pass (run_pass3)
 #endif
@@ -426,23 +432,29 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       // 2.5) = 9.35k; one K step per store step: 2.35 + 2.6 + 2.6 = 7.55k.  Measured at 20 lanes: 1300 -> 1200 us per launch.
       // (Also measured, not kept: the sign copy sliced into the shadow of the mean pass's MFMAs with the delta pass in two
       // steps: 1350 us; the copy's LDS reads four chunks deep instead of one at a time: no change.)
+#if BTX_STEM_NB == 2
       SP_BARRIER();  // the signed copy is complete (build_signed ran before this call)
+#endif
       SP_T2(tr_w)
       if (decltype(mia_tag)::value == 2 && BTX_STEM_PASS3 && (nstages - 1) % 3 == 0) run_pass3(raw, 0, accm, -1, -1);  // (accd is not live yet)
       else run_pass(raw, 0, accm, -1, -1, mia_tag);
       SP_T2(tr_m)
-      SP_BARRIER();
+      SP_BARRIER();  // (BTX_STEM_NB == 1: this is the barrier behind which every wave's part of the signed copy is complete)
       SP_T2(tr_w)
       run_pass(smem + X_OFF, 4096, accd, -1, -1, mia_tag);
       SP_T2(tr_d)
-      nb = 2;
+      nb = BTX_STEM_NB;
 #endif
     } else {
-      const int t3 = (nstages + 2) / 3;
-      if (decltype(mia_tag)::value == 2 && BTX_STEM_PASS3 && (nstages - 1) % 3 == 0) nb = run_pass3(raw, 0, accm, t3, 2 * t3);
-      else nb = run_pass(raw, 0, accm, t3, 2 * t3, mia_tag);
+#if BTX_STEM_NB == 2
+      const int b0_ = (nstages + 2) / 3, b1_ = 2 * b0_;
+#else
+      const int b0_ = (nstages * 4 + 3) / 7 > 0 ? (nstages * 4 + 3) / 7 : -1, b1_ = -1;  // one inner barrier, before stage 4 of 7
+#endif
+      if (decltype(mia_tag)::value == 2 && BTX_STEM_PASS3 && (nstages - 1) % 3 == 0) nb = run_pass3(raw, 0, accm, b0_, b1_);
+      else nb = run_pass(raw, 0, accm, b0_, b1_, mia_tag);
     }
-    for (; nb < 2; ++nb) SP_BARRIER();
+    for (; nb < BTX_STEM_NB; ++nb) SP_BARRIER();
   };
 
   // =================== store role ================================================================================
@@ -627,23 +639,27 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
         const int mia = mia_of(ph);
         if (mia == 2) run_k(ph, std::integral_constant<int, 2>{});
         else if (mia == 1) { clear_acc(1); run_k(ph, std::integral_constant<int, 1>{}); }
-        else { clear_acc(0); SP_BARRIER(); SP_BARRIER(); }
+        else { clear_acc(0); for (int b_ = 0; b_ < BTX_STEM_NB; ++b_) SP_BARRIER(); }
         SP_T(tr_k)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next patch: issued a whole K loop ago
       } else {
         clear_acc(0);
-        SP_BARRIER(); SP_BARRIER();
+        for (int b_ = 0; b_ < BTX_STEM_NB; ++b_) SP_BARRIER();
       }
     } else {
       // ---------------- store role: half tile ph-1 (this group's accumulators of the previous phase)
       const int u = ph - 1;
+      // (measured, not kept: the next patch requested HERE, by the group that multiplies it next phase — the K role's step gets 1k
+      // cycles shorter, the band not one cycle: E10)
       if (ph + 1 < NH) write_signs(ph + 1, gtid, 256);
       if (u >= 0) {
         const int mia = mia_of(u);
         stage_dispatch(u, mia, std::integral_constant<int, 0>{});
         SP_T(tr_st)
+#if BTX_STEM_NB == 2
         SP_BARRIER();
         SP_T(tr_bar)
+#endif
         stage_dispatch(u, mia, std::integral_constant<int, 1>{});
         SP_T(tr_st)
         SP_BARRIER();
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
         carry_pending = true;
         SP_T(tr_pool)
       } else {
-        SP_BARRIER(); SP_BARRIER();
+        for (int b_ = 0; b_ < BTX_STEM_NB; ++b_) SP_BARRIER();
       }
     }
     SP_BARRIER();
