@@ -816,6 +816,15 @@ static bool patch_tile(const BtxGeom* g, const Plan& pl, int tp, int ppcap, Patc
     if (rmax < 1) return false;
     const int nrt = (Ho + rmax - 1) / rmax;
     R = (Ho + nrt - 1) / nrt;
+    // equal row tiles, unless the tallest tile that fits issues fewer 32-pixel MFMA tiles over the image (a tile's tail of < 32
+    // pixels still costs a whole MFMA tile per stage): 28 rows of 28 pixels as 7 + 7 + 7 + 7 are 4 x 7 = 28 MFMA tiles, as
+    // 8 + 8 + 8 + 4 they are 3 x 7 + 4 = 25 (the stride-2 3x3 layer at 56 -> 28: -10.7 % of its MFMAs)
+    auto mfma_tiles = [&](int r) {
+      long long n = 0;
+      for (int row = 0; row < Ho; row += r) n += ((long long)((Ho - row < r) ? Ho - row : r) * Wo + 31) / 32;
+      return n;
+    };
+    if (rmax > R && (Ho % rmax == 0 || 2 * (Ho % rmax) >= rmax) && mfma_tiles(rmax) < mfma_tiles(R)) R = rmax;  // (no sliver of a last tile)
   }
   pt->G = G; pt->R = R; pt->Rp = R + halo_r; pt->Wp = Wp; pt->PP = G * pt->Rp * Wp;
   pt->rtiles = (Ho + R - 1) / R;
