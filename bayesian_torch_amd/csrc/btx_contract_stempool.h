@@ -52,6 +52,9 @@ namespace btx {
                        // the two staging halves guarded nothing (the pool is what reads the rows), and with the store role's steps now 2.1k |
                        // 1.6k cycles (Reparameterization) the three-way split left the K role's first third (patch DMA issue + stages) alone
                        // on the critical path
+#ifndef BTX_STEM_PRIO
+#define BTX_STEM_PRIO 2
+#endif
 #ifndef BTX_STEM_PASS3
 #define BTX_STEM_PASS3 1  // fragments two stages ahead in the Reparameterization pass and in Flipout's mean pass (run_pass3)
 #endif
@@ -420,6 +423,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
   auto run_k = [&](int u, auto mia_tag) __attribute__((always_inline)) {
     const unsigned char* raw = smem + A_OFF + (u & 1) * p.pt_astage;
     int nb;
+    // the K role's wave ahead of the store role's in the SIMD's issue arbitration: Flipout band 139.2k -> 136.8k cycles (E11)
+    __builtin_amdgcn_s_setprio(BTX_STEM_PRIO);
     if constexpr (KIND == 1) {
 #if BTX_STEM_STEPS == 0
       run_pass(raw, 0, accm, -1, -1, mia_tag);
@@ -455,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       else nb = run_pass(raw, 0, accm, b0_, b1_, mia_tag);
     }
     for (; nb < BTX_STEM_NB; ++nb) SP_BARRIER();
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // =================== store role ================================================================================
