@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdint.h>
+#include "../../bayesian_torch_amd/csrc/btx_rng.h"  // BTX-RNG v1: Philox4x32-10 + Box-Muller (the kernels' own generator)
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -23,7 +25,11 @@ __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& a)
 }
 
 // MI x NI tiles of 32 pixels x 32 channels per wave; MASK: s_in masks; RD: fragment reads per stage (1 = all, 2 = every 2nd stage)
-template <int MI, int NI, bool AG, bool MASK, int RD, int BPC, int DMA = 0>
+// SAMPLE (round 6, row g3 of the verdict: "in-kernel sampling on the convolution fast path"): every stage, each of the block's 256
+// threads draws the 8 normals of its 16 bytes of the stage's 4-KiB delta tile (2 x Philox4x32-10 + 4 Box-Muller pairs, hardware
+// log / sqrt / sin / cos as in btx_presample.h), multiplies by a sigma it has in a register, rounds to bf16 and stores the granule —
+// what a workgroup of the tap kernel would have to do per stage to make its own sigma * eps tile instead of DMA-ing a pre-sampled one.
+template <int MI, int NI, bool AG, bool MASK, int RD, int BPC, int DMA = 0, bool SAMPLE = false>
 __global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned* clk, const unsigned char* wbuf = nullptr,
                                               const unsigned char* xbuf = nullptr, unsigned xbytes = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -84,6 +90,15 @@ __global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned*
   // stage s multiplies `cur` while the fragments of stage s+1 are read into `nxt` (as the kernel does)
   auto stage = [&](Frag& cur, Frag& nxt, int s) __attribute__((always_inline)) {
     dma(s + 3);
+    if constexpr (SAMPLE) {
+      float z[8];
+      btx_normal4_hw((uint32_t)(s * 512 + 2 * tid), 7u, 3u, 0u, 0x1234u, 0x5678u, z);
+      btx_normal4_hw((uint32_t)(s * 512 + 2 * tid + 1), 7u, 3u, 0u, 0x1234u, 0x5678u, z + 4);
+      const float sg = 0.0486f + 1e-6f * (float)lane;
+      typedef __attribute__((ext_vector_type(8))) float f32x8_;
+      const f32x8_ v = {z[0] * sg, z[1] * sg, z[2] * sg, z[3] * sg, z[4] * sg, z[5] * sg, z[6] * sg, z[7] * sg};
+      *(bf16x8*)(lds + 12288 + 4096 + ((s & 1) ? 8192 : 0) + tid * 16) = __builtin_convertvector(v, bf16x8);
+    }
     if (RD == 1 || (s & 2) == 0) load(nxt, s + 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -132,9 +147,9 @@ __global__ __launch_bounds__(256, BPC) void k(int stages, float* sink, unsigned*
 static unsigned char* g_wbuf = nullptr;
 static unsigned char* g_xbuf = nullptr;
 static const unsigned g_xbytes = 1u << 30;
-template <int MI, int NI, bool AG, bool MASK, int RD, int BPC, int DMA = 0>
+template <int MI, int NI, bool AG, bool MASK, int RD, int BPC, int DMA = 0, bool SAMPLE = false>
 void run(const char* name, float* sink, unsigned* clk) {
-  auto fn = k<MI, NI, AG, MASK, RD, BPC, DMA>;
+  auto fn = k<MI, NI, AG, MASK, RD, BPC, DMA, SAMPLE>;
   const int lds_bytes = BPC == 2 ? 81920 : 163840;  // pins the blocks per CU (DMA rings: 64 KiB .. 108 KiB > the 80 KiB of a block when BPC == 2: folded below)
   hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   const int grid = 256 * BPC;
@@ -174,6 +189,7 @@ int main() {
     run<2, 2, false, true, 1, 2, 1>("G  A + weight-tile DMA (8 KiB per block-stage from L2)", sink, clk);
     run<2, 2, false, true, 1, 2, 2>("H  G + 4 KiB per block-stage of activations from HBM", sink, clk);
     run<4, 2, true, true, 1, 1, 1>("I  B + weight-tile DMA (8 KiB per 512-pixel block-stage)", sink, clk);
+    run<2, 2, false, true, 1, 2, 0, true>("J  A + the stage's delta tile sampled in the block (8 normals/thread)", sink, clk);
   }
   return 0;
 }
