@@ -143,3 +143,39 @@ def test_bench_final_line_is_compact_and_last(tmp_path, capsys, monkeypatch):
     full["cpu_baseline"]["sample"] = "z" * 2500
     s = bench.compact_line(full)
     assert len(s) <= bench.LINE_LIMIT and "roofline" in json.loads(s) and "cpu_baseline" in json.loads(s)
+
+
+def test_timed_regions_settle_and_every_region_is_exactly_the_steps():
+    """bench.timed_mc: each timed region runs EXACTLY the given MC sample indices between barrier + synchronize; with
+    min_seconds the same region repeats back to back until the regions add up to that long; bench.settled() = the median of
+    the second half (the first half carries the clock ramp)"""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class FakeRunner:
+        def __init__(self):
+            self.packed = torch.zeros(4)
+            self.calls = []
+
+        def run(self, idx):
+            self.calls.append(list(idx))
+            import time
+            time.sleep(0.002)
+
+        def zero(self):
+            self.packed.zero_()
+
+        def fold(self):
+            pass
+
+    r = FakeRunner()
+    runs = bench.timed_mc(r, [5, 6, 7], [100], 1, torch.device("cpu"), repeats=3, min_seconds=0.05)
+    assert r.calls[0] == [100] and all(c == [5, 6, 7] for c in r.calls[1:])
+    assert len(runs) == len(r.calls) - 1 and len(runs) >= 3 and 0.04 < sum(runs) < 0.5
+    r2 = FakeRunner()
+    assert len(bench.timed_mc(r2, [1], [0], 1, torch.device("cpu"), repeats=4)) == 4   # no settling asked for: `repeats` regions
+    assert bench.settled([9.0, 8.0, 7.0, 1.0, 2.0, 3.0, 2.5, 2.2]) == 2.5              # median of the second half [2.0, 3.0, 2.5, 2.2] -> sorted[2]
+    assert bench.settled([3.0, 1.0, 2.0]) == 2.0                                      # fewer than 8 regions: the median of all
