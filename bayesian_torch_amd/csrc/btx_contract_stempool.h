@@ -46,6 +46,9 @@ namespace btx {
 #ifndef BTX_STEM_STEPS
 #define BTX_STEM_STEPS 1  // step layout of a Flipout K phase (run_k): 0 = round 2's (sign copy + mean) | delta 0-3 | delta 4-6,
 #endif                    // 1 = sign copy | mean | delta
+#ifndef BTX_SP_ABL
+#define BTX_SP_ABL 0  // measurement-only ablation bits (wrong results; tools/r06/e6.sh, with -DBTX_STEM_PASS3=0 -DBTX_STEM_NB=2): 1 no MFMA in
+#endif                // the two-register-set passes (run_pass), 2 no fragment reads after their first stage, 4 the store role does nothing
 #ifndef BTX_STEM_NB
 #define BTX_STEM_NB 1  // workgroup barriers INSIDE a phase (besides its closing one).  2 (rounds 2-5): sign copy | mean | delta against
 #endif                 // stage 0-31 | stage 32-63 | pool.  1 (round 6): [copy +] first part | rest against staging | pool — the barrier between
@@ -93,6 +96,7 @@ __device__ __forceinline__ void sp_mma(const SpFrag& f, f32x16 (&acc)[2][2]) {
     for (int mi = 0; mi < MIA; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
+        if constexpr (BTX_SP_ABL & 1) { asm volatile("" ::"v"(f.w[kk][ni]), "v"(f.a[kk][mi])); acc[mi][ni][0] += 1.f; continue; }
         if constexpr (ZERO) {
           const f32x16 zc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.w[kk][ni]),
@@ -328,7 +332,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
     load(fa, 0);
     auto iter = [&](int s, SpFrag& cur, SpFrag& nxt, auto zero_tag) __attribute__((always_inline)) {
       if (s == bs0 || s == bs1) { SP_BARRIER(); ++nb; }
-      if (s + 1 < nstages) load(nxt, s + 1);
+      if constexpr (BTX_SP_ABL & 2) { nxt = cur; asm volatile("" : "+v"(nxt.a[0][0]), "+v"(nxt.w[0][0])); }
+      else if (s + 1 < nstages) load(nxt, s + 1);
       sp_mma<MIA, decltype(zero_tag)::value>(cur, acc);
     };
     iter(0, fa, fb, std::true_type{});
@@ -658,7 +663,9 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const ContractParams 
       // (measured, not kept: the next patch requested HERE, by the group that multiplies it next phase — the K role's step gets 1k
       // cycles shorter, the band not one cycle: E10)
       if (ph + 1 < NH) write_signs(ph + 1, gtid, 256);
-      if (u >= 0) {
+      if ((BTX_SP_ABL & 4) && u >= 0) {
+        for (int b_ = 0; b_ < BTX_STEM_NB; ++b_) SP_BARRIER();
+      } else if (u >= 0) {
         const int mia = mia_of(u);
         stage_dispatch(u, mia, std::integral_constant<int, 0>{});
         SP_T(tr_st)
