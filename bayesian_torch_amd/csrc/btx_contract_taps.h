@@ -495,6 +495,13 @@ __global__ __launch_bounds__(256 * KG, 2) void contract_taps_kernel(const Contra
 #endif
 
   // =================== epilogue (btx_epilogue.h) ============================================================
+  if constexpr (BTX_PT_ABL & 32) {  // measurement builds: no store side at all (the accumulators stay live up to here)
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) asm volatile("" ::"v"(accm[a][b]), "v"(accd[a][b]));
+    return;
+  }
   {
     BTX_SECTION_PARAMS(pe, logical2);  // the store side's own reads
     const int nimg = min(pe.pt_G, pe.NB - img0), nrow = min(pe.pt_R, pe.Ho - row0);
