@@ -13,6 +13,9 @@
 #pragma once
 #include <type_traits>
 #include "btx_contract.h"
+#ifndef BTX_PT_ABL
+#define BTX_PT_ABL 0
+#endif
 
 namespace btx {
 
@@ -430,6 +433,8 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
                 const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, io_bytes, 0x00020000);
                 __builtin_amdgcn_raw_buffer_store_b128((u32x4){p0[0], p0[1], p1[0], p1[1]}, out_rsrc, io_voff,
                                                        io_step * (uint32_t)(hf * NP + i), 0);
+              } else if constexpr (BTX_PT_ABL & 64) {  // measurement builds: everything but the store itself
+                asm volatile("" ::"v"(p0), "v"(p1), "v"(idx[i]));
               } else {
                 *(u32x4*)((__bf16*)p.out + idx[i]) = (u32x4){p0[0], p0[1], p1[0], p1[1]};
               }
