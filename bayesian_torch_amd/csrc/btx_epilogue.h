@@ -16,6 +16,9 @@
 #ifndef BTX_PT_ABL
 #define BTX_PT_ABL 0
 #endif
+#ifndef BTX_EP_PRED_STORES
+#define BTX_EP_PRED_STORES 0  // A/B: 1 = the bf16 stores of stage 2 under `if (pixel exists)` again (rounds 1-5)
+#endif
 
 namespace btx {
 
@@ -420,6 +423,18 @@ __device__ __forceinline__ void staged_epilogue_pm(const ContractParams& p, cons
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
           }
+          if constexpr (OUTK == 1 && !BUFIO && !(BTX_PT_ABL & 64) && !BTX_EP_PRED_STORES) {
+            // bf16 outputs: the store is a buffer store whose offset is out of the descriptor's range for a pixel that does not
+            // exist (dropped by the hardware) — no exec-mask block per store.  Under `if (pk[i])` each of the lane's eight stores
+            // sat in a basic block of its own together with its ReLU / rounding arithmetic (s_and_saveexec .. s_or exec around
+            // every global_store in the ISA): nothing of one pixel could be scheduled beside another's.  (Round 6, E15; byte
+            // offsets fit 32 bits: the host admits M * N < 2^31 elements.)
+            const f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+            const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_convertvector(x0, bf16x4));
+            const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_convertvector(x1, bf16x4));
+            const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, io_bytes, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){p0[0], p0[1], p1[0], p1[1]}, out_rsrc, pk[i] ? idx[i] * 2u : 0xfffffff0u, 0, 0);
+          } else
           if (pk[i]) {
             if constexpr (OUTK == 0) {
               float* dst = p.partial + (size_t)split * p.M * p.N + idx[i];
