@@ -722,7 +722,11 @@ static int make_plan(const BtxGeom* g, int prec, uint32_t flags, int bm, Plan* p
       // enough that the launch is not a long thin tail of its own stream.  Launches with MC sample lanes take the same
       // plan, decided by the grid of ONE lane: the K split — the f32 summation order — of a sample then does not depend
       // on how many samples share its launch, nor on how the samples were grouped over launches and ranks.
-      if (throughput_plan(flags) && base1 * c >= 64) { ks = c; break; }
+      // 16 workgroups of at most 16 stages are enough as well: ResNet18's fc (16 n-tiles of 16 stages per lane) in ONE piece —
+      // 4 splits of 4 stages + the reduce launch measured 77 us per 20 lanes against 39 (profiles/r06_experiments.txt E18)
+      long long tp_min = 64, tp_short = 16;
+      if (const char* e = tune_env("BTX_TP_MINWG")) { tp_min = atoll(e); tp_short = 1 << 30; }  // A/B (E18)
+      if (throughput_plan(flags) && (base1 * c >= tp_min || (base1 * c >= tp_short && (stages + c - 1) / c <= 16))) { ks = c; break; }
     }
   }
   int per_stages = (stages + ks - 1) / ks;
